@@ -1,0 +1,166 @@
+/*
+ * sin3dm_hip.h — C ABI of libsin3dm_hip.so, the MI355X (gfx950) implementation of the Sin3DM
+ * denoising path.  Plain pointers and sizes only; no torch types.  The reference has no FFI of its
+ * own (it is pure Python/PyTorch): each entry point below names the reference Python
+ * interface it stands under (paths relative to /root/reference/).  INTEGRATION.md shows the ctypes
+ * stub that binds them.
+ *
+ * Conventions
+ *   - return 0 on success, a negative s3d_status otherwise; the message is s3d_last_error()
+ *     (thread-local).  Nothing throws or aborts across this boundary.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every compute call only enqueues work on it and never synchronises.
+ *   - all tensors are fp32 device pointers owned by the caller, in the REFERENCE layouts
+ *     (NCHW composed triplanes, [N,3] points ...); the library re-lays them out internally (NHWC).
+ *   - parameters are copied and repacked into library-owned device memory; workspaces belong to the
+ *     handle and grow on demand.  Handles are not thread-safe: one host thread per handle.
+ */
+#ifndef SIN3DM_HIP_H
+#define SIN3DM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S3D_ABI_VERSION 1
+#define S3D_API __attribute__((visibility("default")))
+
+typedef enum {
+    S3D_OK = 0,
+    S3D_ERR_INVALID = -1,     /* bad argument / shape (the shim raises AssertionError/ValueError) */
+    S3D_ERR_MISSING = -2,     /* forward called with parameters not all set                      */
+    S3D_ERR_HIP = -3,         /* a HIP runtime call failed                                        */
+    S3D_ERR_UNSUPPORTED = -4  /* a configuration the reference itself cannot construct/run        */
+} s3d_status;
+
+S3D_API int s3d_abi_version(void);
+S3D_API const char* s3d_last_error(void);
+/* number of visible HIP devices, or a negative s3d_status: lets the shim fail loudly without torch */
+S3D_API int s3d_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Denoiser: TriplaneUNetModelSmall / TriplaneUNetModelSmallRaw
+ *   constructor  src/diffusion/unet_triplane.py:346-449 (Raw: :544-646)
+ *   forward      src/diffusion/unet_triplane.py:465-510 (Raw: :664-702)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct s3d_unet s3d_unet;
+
+typedef struct {
+    int32_t in_channels;            /* 12 = fdim_geo + fdim_tex   (src/utils/parser_util.py:131-132) */
+    int32_t model_channels;         /* 64 default, 128 for BASELINE config 2                          */
+    int32_t out_channels;
+    int32_t num_res_blocks;         /* only 1 is constructible in the reference       */
+    int32_t n_levels;               /* len(channel_mult)                                              */
+    int32_t channel_mult[8];
+    int32_t use_scale_shift_norm;   /* FiLM h*(1+scale)+shift (default True) vs h+emb                 */
+    int32_t is_rollout;             /* 1: TriplaneUNetModelSmall, 0: ...SmallRaw                      */
+} s3d_unet_cfg;
+
+S3D_API int s3d_unet_create(const s3d_unet_cfg* cfg, s3d_unet** out);
+S3D_API void s3d_unet_destroy(s3d_unet* m);
+
+/* Number of parameter tensors the configuration expects and the i-th one's state_dict name/shape
+ * (the names of nn.Module.state_dict(), e.g. "input_blocks.1.1.in_layers.2.conv_xz.weight"). */
+S3D_API int s3d_unet_num_params(const s3d_unet* m);
+S3D_API int s3d_unet_param_info(const s3d_unet* m, int i, const char** name, int64_t shape[4], int* ndim);
+
+/* load_state_dict, one tensor at a time: `data` is a HOST fp32 pointer in the PyTorch layout
+ * (conv OIHW, linear [out,in]); the tensor is repacked for the kernels and uploaded. */
+S3D_API int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data, const int64_t* shape, int ndim);
+
+/* forward(x, timesteps, H, W, D): x,out [B,C,H+D,W+D] device fp32; t [B] device fp32 (already in
+ * the original 0..999 index space, i.e. after _WrappedModel, src/diffusion/respace.py:123-128). */
+S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D,
+                     float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sampler update: GaussianDiffusion.p_mean_variance + p_sample / ddim_sample
+ *   src/diffusion/gaussian_diffusion.py:233-327, 396-440, 538-600
+ * One fused element-wise kernel per step.  `tables` is a device fp32 array [S3D_TAB_ROWS][T]
+ * (the float64 schedule tables gathered-then-cast exactly like _extract_into_tensor, :934-947).
+ * ------------------------------------------------------------------------------------------ */
+enum { S3D_TAB_SQRT_RECIP = 0, S3D_TAB_SQRT_RECIPM1, S3D_TAB_COEF1, S3D_TAB_COEF2, S3D_TAB_LOGVAR,
+       S3D_TAB_ACP, S3D_TAB_ACP_PREV, S3D_TAB_ROWS };
+enum { S3D_STEP_DDPM = 0, S3D_STEP_DDIM = 1, S3D_STEP_MEAN_ONLY = 2 };
+enum { S3D_MEAN_START_X = 0, S3D_MEAN_EPSILON = 1 };
+
+typedef struct {
+    int32_t mode;                /* S3D_STEP_*                                                     */
+    int32_t mean_type;           /* S3D_MEAN_*  (predict_xstart=True -> START_X)                    */
+    int32_t clip_denoised;       /* clamp x0 to [-1,1]                                              */
+    int32_t is_mask_t0;          /* ddim in-painting branch (:568-577)                              */
+    float eta;                   /* ddim eta                                                        */
+    int32_t T;                   /* table length                                                    */
+    int64_t batch;               /* B                                                               */
+    int64_t per_sample;          /* C*(H+D)*(W+D)                                                   */
+    const float* model_out;      /* [B, per_sample]                                                 */
+    const float* x;              /* x_t                                                             */
+    const float* noise;          /* eps ~ N(0,1); may be NULL for MEAN_ONLY or ddim eta == 0        */
+    const int64_t* t;            /* [B] device int64 indices into the (respaced) tables             */
+    const float* tables;         /* [S3D_TAB_ROWS][T] device fp32                                   */
+    const float* y0;             /* optional in-painting target / mask (both or neither)            */
+    const float* mask;
+    float* sample;               /* out: x_{t-1}   (NULL for MEAN_ONLY)                              */
+    float* pred_xstart;          /* out                                                             */
+    float* mean;                 /* out, optional (posterior mean; DDPM / MEAN_ONLY)                */
+} s3d_sampler_args;
+
+S3D_API int s3d_sampler_step(const s3d_sampler_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Leaf operators, exported so the parity tests can pin each kernel to the reference op it replaces
+ * (SURVEY.md §8c item 3).  Planes are NCHW device tensors xy[B,C,H,W], xz[B,C,H,D], yz[B,C,W,D].
+ * ------------------------------------------------------------------------------------------ */
+/* TriplaneConv.forward  src/diffusion/unet_triplane.py:31-60; weights: 3 host OIHW tensors + biases */
+S3D_API int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, int C, int H, int W, int D,
+                         int Cout, int ksize, int is_rollout, const float* const weight[3],
+                         const float* const bias[3], void* stream);
+/* TriplaneNorm + TriplaneSiLU  src/diffusion/unet_triplane.py:63-95; gamma/beta: host [C] per plane */
+S3D_API int s3d_op_triplane_norm_silu(const float* const in[3], float* const out[3], int B, int C, int H, int W, int D,
+                              const float* const gamma[3], const float* const beta[3], void* stream);
+/* TriplaneDownsample2x / TriplaneUpsample2x / size-targeted bilinear resize
+ * src/diffusion/unet_triplane.py:106-145, 494-499.  mode 0: avg-pool 2x2, 1: bilinear to (ho[i], wo[i]) */
+S3D_API int s3d_op_triplane_resample(const float* const in[3], float* const out[3], int B, int C, const int hi[3],
+                             const int wi[3], const int ho[3], const int wo[3], int mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Decoder: AutoEncoderGroupSkip.decode + ShapeAutoEncoder.decode_batch/decode_grid
+ *   src/encoding/networks.py:192-220 ; src/encoding/model.py:319-349 ; src/encoding/utils3d.py:13-25
+ * ------------------------------------------------------------------------------------------ */
+typedef struct s3d_decoder s3d_decoder;
+
+typedef struct {
+    int32_t geo_feat_channels;   /* 4   */
+    int32_t tex_feat_channels;   /* 8   */
+    int32_t feat_channel_up;     /* 64  */
+    int32_t mlp_hidden_channels; /* 256 */
+    int32_t mlp_hidden_layers;   /* 4   */
+    int32_t tex_channels;        /* 3   */
+} s3d_decoder_cfg;
+
+S3D_API int s3d_decoder_create(const s3d_decoder_cfg* cfg, s3d_decoder** out);
+S3D_API void s3d_decoder_destroy(s3d_decoder* d);
+S3D_API int s3d_decoder_num_params(const s3d_decoder* d);
+S3D_API int s3d_decoder_param_info(const s3d_decoder* d, int i, const char** name, int64_t shape[4], int* ndim);
+S3D_API int s3d_decoder_set_param(s3d_decoder* d, const char* name, const float* data, const int64_t* shape, int ndim);
+/* Runs geo_convs / tex_convs once for a triplane (the reference redoes them for every 16 384-point
+ * chunk, src/encoding/model.py:327-330 -> networks.py:203-212, with identical results).
+ * xy [1,Cg+Ct,H,W], xz [1,Cg+Ct,H,D], yz [1,Cg+Ct,W,D] device fp32. */
+S3D_API int s3d_decoder_prepare_triplane(s3d_decoder* d, const float* xy, const float* xz, const float* yz,
+                                 int H, int W, int D, void* stream);
+/* net.decode(points, feat_maps, aabb): pts [N,3] device, aabb[6] host -> out [N, 1+tex_channels]
+ * = (sdf, sigmoid(rgb)); clamp_color != 0 additionally applies decode_batch's clamp(0,1) (:332). */
+S3D_API int s3d_decoder_decode_points(s3d_decoder* d, const float* pts, int64_t N, const float aabb[6],
+                              int clamp_color, float* out, void* stream);
+/* decode_grid: cell-centred grid over aabb with res_i = floor(reso*size_i/max(size)); writes
+ * out [res0,res1,res2, 1+tex_channels] and the three resolutions. */
+S3D_API int s3d_decoder_grid_dims(const float aabb[6], int reso, int dims[3]);
+S3D_API int s3d_decoder_decode_grid(s3d_decoder* d, int reso, const float aabb[6], float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIN3DM_HIP_H */

@@ -1,0 +1,191 @@
+// s3d_common.h — internal declarations shared by the HIP translation units of libsin3dm_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sin3dm_hip.h"
+
+namespace s3d {
+
+// ------------------------------------------------------------------ errors
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* get_error();
+
+#define S3D_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            s3d::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return S3D_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define S3D_CHECK(cond, code, ...)                                                                 \
+    do {                                                                                           \
+        if (!(cond)) {                                                                             \
+            s3d::set_error(__VA_ARGS__);                                                           \
+            return (code);                                                                         \
+        }                                                                                          \
+    } while (0)
+
+#define S3D_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int rc__ = (expr);                                                                         \
+        if (rc__ != 0) return rc__;                                                                \
+    } while (0)
+
+// ------------------------------------------------------------------ device memory helpers
+struct DevBuf {                       // owning device allocation (grow-only)
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct Arena {                        // bump allocator over one DevBuf; two-pass (measure, then run)
+    DevBuf buf;
+    size_t off = 0, high = 0;
+    bool measuring = false;
+    void reset() { off = 0; }
+    template <class T>
+    T* alloc(size_t n) {
+        size_t bytes = (n * sizeof(T) + 255) & ~size_t(255);
+        size_t o = off;
+        off += bytes;
+        if (off > high) high = off;
+        if (measuring) return reinterpret_cast<T*>(uintptr_t(256));   // never dereferenced
+        return reinterpret_cast<T*>(static_cast<char*>(buf.p) + o);
+    }
+};
+
+int upload(DevBuf& dst, const void* host, size_t bytes);
+
+// ------------------------------------------------------------------ plane geometry
+// The three planes of a triplane: xy[H,W], xz[H,D], yz[W,D]  (src/utils/triplane_util.py:20-25)
+struct Geo {
+    int h[3], w[3];
+    static Geo from_hwd(int H, int W, int D) { return Geo{{H, H, W}, {W, D, D}}; }
+    Geo half() const { return Geo{{h[0] / 2, h[1] / 2, h[2] / 2}, {w[0] / 2, w[1] / 2, w[2] / 2}}; }
+    Geo twice() const { return Geo{{h[0] * 2, h[1] * 2, h[2] * 2}, {w[0] * 2, w[1] * 2, w[2] * 2}}; }
+    bool operator==(const Geo& o) const {
+        for (int i = 0; i < 3; ++i) if (h[i] != o.h[i] || w[i] != o.w[i]) return false;
+        return true;
+    }
+    size_t pixels() const { return size_t(h[0]) * w[0] + size_t(h[1]) * w[1] + size_t(h[2]) * w[2]; }
+};
+
+// A triplane activation in the library's layout: per plane NHWC fp32 [B][h][w][C].
+struct Tri {
+    float* p[3] = {nullptr, nullptr, nullptr};
+    int C = 0;
+    Geo g{};
+};
+
+// ------------------------------------------------------------------ MFMA conv (s3d_conv.hip)
+// One implicit-GEMM convolution problem: M = B*h*w pixels, N = cout, K = taps*cin.
+struct ConvJob {
+    const float* in;      // [B][h][w][cin] NHWC
+    const float* wgt;     // packed [taps][cout][cin]
+    const float* bias;    // [cout] or null
+    const float* bbias;   // [B][bbias_stride] per-sample bias (h + emb path) or null
+    const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
+    const float* rcol;    // [B][w][4][cout] rank-1 rollout term indexed by pixel column, variant by row; or null
+    const float* res;     // [B][h][w][cout] residual or null
+    float* out;           // [B][h][w][cout]
+    int h, w;
+    int bbias_stride;
+    int tiles_x, tiles_per_img, n_tiles_n;   // filled by the launcher
+    int block_begin;                          // first block id of this job
+};
+constexpr int kMaxConvJobs = 8;
+struct ConvArgs {
+    ConvJob job[kMaxConvJobs];
+    int njobs;
+    int B, cin, cout;
+};
+enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3 };
+// Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
+// Debug/triangulation path: a plain one-thread-per-output direct convolution (no MFMA, no LDS).
+// Selected with S3D_CONV_IMPL=naive; never the default.
+int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st);
+bool conv_use_naive();
+
+// Packed TriplaneConv parameters: offsets (in floats) into a staging image that is uploaded as one buffer.
+struct ConvW {
+    size_t dense[3] = {0, 0, 0};      // [taps][cout][cin_own]
+    size_t bias[3] = {0, 0, 0};
+    size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3][4*cout][C]
+    size_t rcol[3] = {0, 0, 0};       // rank-1 weights for the column-varying mean vector
+    int cin = 0, cout = 0, k = 0;
+    bool rollout = false;
+};
+size_t push(std::vector<float>& stage, const float* src, size_t n);
+void pack_tconv_raw(std::vector<float>& stage, const float* const W[3], const float* const bias[3], int cin, int cout,
+                    int k, bool roll, ConvW& cw);
+
+// ------------------------------------------------------------------ small kernels (s3d_kernels.hip)
+// NCHW <-> NHWC plane repacks used only by the leaf-operator test entry points.
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int h, int w, hipStream_t st);
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w, hipStream_t st);
+
+// in_conv: composed NCHW x [B,Cin,H+D,W+D] -> three NHWC planes through a 1x1 conv (Cin small).
+// wT: [3][Cin][Cout] (transposed), bias [3][Cout]
+int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const float* wT, const float* bias,
+                   int Cout, Tri& out, hipStream_t st);
+
+// GroupNorm statistics, stage 1: per (b, plane, chunk, group) partial {sum, sumsq} in double.
+constexpr int kGnChunks = 32;     // partial slots per (b, plane)
+struct GnPartials { double* p; }; // [B][3][kGnChunks][32 groups][2]
+int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st);
+
+// GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
+struct ActArgs {
+    const float* gamma[3];   // [C]
+    const float* beta[3];
+    const float* film;       // [B][film_stride]: scale at [0,C), shift at [C,2C); or null
+    int film_stride;
+};
+constexpr int kActRows = 8, kActCols = 32;   // tile of the act kernel
+struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a tile's columns), colpart [B][ntr][w][C]
+    float* rowpart[3];
+    float* colpart[3];
+};
+// stats.p == nullptr: identity (no norm, no SiLU) — used by the leaf-operator entry point to get the rollout
+// means of a raw input.
+int launch_gn_act(const Tri& x, int B, GnPartials stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
+                  hipStream_t st);
+// finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
+struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
+int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);
+
+int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st);
+// bilinear (align_corners=False) resize into a channel slice of a wider NHWC tensor
+int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, int ho, int wo, int out_cstride,
+                    int out_coff, hipStream_t st);
+int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, int out_cstride, int out_coff,
+                      hipStream_t st);
+
+// out head: GN + SiLU + 1x1 conv (C -> Cout small) + compose into NCHW [B,Cout,H+D,W+D] with zero corner
+int launch_out_head(const Tri& x, int B, GnPartials stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
+                    const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st);
+
+// small dense layers for the timestep path: y[b][o] = act_out( sum_i f(in[b][i]) * W[o][i] + bias[o] )
+// in_mode 0: plain, 1: SiLU(in), 2: in is t[b] -> sinusoidal embedding of width I (cos | sin)
+int launch_linear(const float* in, int B, int I, const float* W, const float* bias, int O, float* out,
+                  int in_mode, int out_silu, hipStream_t st);
+
+int launch_sampler(const s3d_sampler_args& a, hipStream_t st);
+
+}  // namespace s3d

@@ -1,0 +1,308 @@
+// s3d_conv.hip — the hot kernel: im2col-free NHWC direct convolution on the fp32 matrix cores.
+//
+// Each TriplaneConv of the reference (src/diffusion/unet_triplane.py:21-60) is three independent
+// Conv2d's whose input is [own C | axis-mean A (C) | axis-mean B (C)].  The two mean blocks are constant
+// along one spatial axis, so their contribution is a pair of 1-D convolutions (rank-1 "rollout" terms)
+// that this file evaluates as tiny vector jobs (CONV_1x3_VEC) and then adds in the epilogue of the dense
+// convolution over the plane's own C channels.  See DESIGN.md §3.
+//
+// Dense part = implicit GEMM: M = pixels of a TH x TW tile, N = output channels, K = taps x C.
+//   * the (TH+KH-1) x (TW+KW-1) input halo tile of one 32-channel chunk is staged once in LDS and reused by
+//     all KH*KW taps (a tap is just a different LDS base offset: no im2col buffer anywhere);
+//   * weights are pre-packed [tap][cout][cin] so a stage's B tile is BN rows of 128 contiguous bytes;
+//   * the contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32, same rate as the fp32 vector peak but one
+//     operand VGPR per lane); the K order inside an 8-wide step is permuted (lane half 0 takes k0..3, half 1
+//     k4..7) so both operands are fetched with one ds_read_b128 per 4 MFMAs;
+//   * LDS rows are padded to 36 floats: the 32-lane column read of the B tile is conflict-free, the A tile's
+//     2-D pixel patch costs at most 3x on a read that is issued once per 256+ MFMA cycles (tools/lds_bank_check.py);
+//   * global->LDS staging is register-prefetched one stage ahead and double-buffered: one barrier per stage.
+//   * epilogue: + bias (+ per-sample bias) + rank-1 row/column terms + residual, 128-byte runs per pixel.
+#include "s3d_common.h"
+
+namespace s3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 32;          // channels per K chunk
+constexpr int LDP = KC + 4;     // padded LDS row (floats)
+
+template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_>
+struct ConvCfg {
+    static constexpr int TH = TH_, TW = TW_, KH = KH_, KW = KW_, WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
+    static constexpr int BM = TH * TW, BN = WN * NTW * 32;
+    static constexpr int HH = TH + KH - 1, HW = TW + KW - 1;
+    static constexpr int A_ELEMS = HH * HW * LDP, B_ELEMS = BN * LDP;
+    static constexpr int A_ITEMS = HH * HW * (KC / 4), B_ITEMS = BN * (KC / 4);
+    static constexpr int NA = (A_ITEMS + 255) / 256, NB = (B_ITEMS + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(BM == WM * MTW * 32, "pixel tile must match the wave grid");
+    static_assert(32 % TW == 0 || TW % 32 == 0, "an MFMA row block must cover whole tile rows");
+};
+
+__device__ __forceinline__ int edge_variant(int idx, int n) {
+    // which taps of the summed-out axis fall inside the image: 0 interior, 1 first, 2 last, 3 only element
+    return n == 1 ? 3 : (idx == 0 ? 1 : (idx == n - 1 ? 2 : 0));
+}
+
+template <class CFG>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
+    constexpr int TW = CFG::TW, KH = CFG::KH, KW = CFG::KW, MTW = CFG::MTW, NTW = CFG::NTW;
+    constexpr int HW = CFG::HW, TAPS = KH * KW;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (CFG::A_ELEMS + CFG::B_ELEMS)];
+    float* const Abase = smem;
+    float* const Bbase = smem + 2 * CFG::A_ELEMS;
+
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int ty0 = (local / J.tiles_x) * CFG::TH, tx0 = (local % J.tiles_x) * TW;
+    const int n0 = ntile * CFG::BN;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / CFG::WN, wn = wid % CFG::WN;
+
+    int offA[MTW], offB[NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int p = (wm * MTW + mt) * 32 + (lane & 31);
+        offA[mt] = ((p / TW) * HW + (p % TW)) * LDP + (lane >> 5) * 4;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) offB[nt] = ((wn * NTW + nt) * 32 + (lane & 31)) * LDP + (lane >> 5) * 4;
+
+    // ---- global -> register staging descriptors (fixed per thread)
+    const float* aSrc[CFG::NA]; int aDst[CFG::NA]; bool aOk[CFG::NA];
+#pragma unroll
+    for (int it = 0; it < CFG::NA; ++it) {
+        const int idx = it * 256 + tid;
+        const int pix = idx >> 3, q = idx & 7;
+        const int gy = ty0 + pix / HW - KH / 2, gx = tx0 + pix % HW - KW / 2;
+        aOk[it] = idx < CFG::A_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        aDst[it] = idx < CFG::A_ITEMS ? pix * LDP + q * 4 : -1;
+        aSrc[it] = J.in + ((size_t(b) * h + (aOk[it] ? gy : 0)) * w + (aOk[it] ? gx : 0)) * cin + q * 4;
+    }
+    const float* bSrc[CFG::NB]; int bDst[CFG::NB]; bool bOk[CFG::NB];
+#pragma unroll
+    for (int it = 0; it < CFG::NB; ++it) {
+        const int idx = it * 256 + tid;
+        const int n = idx >> 3, q = idx & 7;
+        bOk[it] = idx < CFG::B_ITEMS && n0 + n < cout;
+        bDst[it] = idx < CFG::B_ITEMS ? n * LDP + q * 4 : -1;
+        bSrc[it] = J.wgt + size_t(bOk[it] ? n0 + n : 0) * cin + q * 4;
+    }
+    const size_t tapStride = size_t(cout) * cin;
+
+    f32x16 acc[MTW][NTW];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int nchunks = cin / KC;
+    const int nstages = nchunks * TAPS;
+    float4 ra[CFG::NA], rb[CFG::NB];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // prologue: stage 0 (chunk 0, tap 0)
+#pragma unroll
+    for (int it = 0; it < CFG::NA; ++it) ra[it] = aOk[it] ? *reinterpret_cast<const float4*>(aSrc[it]) : zero4;
+#pragma unroll
+    for (int it = 0; it < CFG::NB; ++it) rb[it] = bOk[it] ? *reinterpret_cast<const float4*>(bSrc[it]) : zero4;
+#pragma unroll
+    for (int it = 0; it < CFG::NA; ++it) if (aDst[it] >= 0) *reinterpret_cast<float4*>(Abase + aDst[it]) = ra[it];
+#pragma unroll
+    for (int it = 0; it < CFG::NB; ++it) if (bDst[it] >= 0) *reinterpret_cast<float4*>(Bbase + bDst[it]) = rb[it];
+    __syncthreads();
+
+    int chunk = 0, tap = 0;
+    for (int s = 0; s < nstages; ++s) {
+        // ---- prefetch stage s+1 into registers
+        int nchunk = chunk, ntap = tap + 1;
+        if (ntap == TAPS) { ntap = 0; ++nchunk; }
+        const bool more = s + 1 < nstages;
+        const bool newA = more && ntap == 0;
+        if (more) {
+#pragma unroll
+            for (int it = 0; it < CFG::NB; ++it)
+                rb[it] = bOk[it] ? *reinterpret_cast<const float4*>(bSrc[it] + ntap * tapStride + nchunk * KC) : zero4;
+            if (newA) {
+#pragma unroll
+                for (int it = 0; it < CFG::NA; ++it)
+                    ra[it] = aOk[it] ? *reinterpret_cast<const float4*>(aSrc[it] + nchunk * KC) : zero4;
+            }
+        }
+        // ---- compute stage s from LDS
+        {
+            const float* As = Abase + (chunk & 1) * CFG::A_ELEMS + ((tap / KW) * HW + (tap % KW)) * LDP;
+            const float* Bs = Bbase + (s & 1) * CFG::B_ELEMS;
+#pragma unroll
+            for (int k8 = 0; k8 < KC / 8; ++k8) {
+                float4 a4[MTW], b4[NTW];
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt) a4[mt] = *reinterpret_cast<const float4*>(As + offA[mt] + k8 * 8);
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) b4[nt] = *reinterpret_cast<const float4*>(Bs + offB[nt] + k8 * 8);
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].x, b4[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].y, b4[nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].z, b4[nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].w, b4[nt].w, acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- registers -> the other LDS buffers (last read one barrier ago), then one barrier
+        if (more) {
+            float* Bd = Bbase + ((s + 1) & 1) * CFG::B_ELEMS;
+#pragma unroll
+            for (int it = 0; it < CFG::NB; ++it) if (bDst[it] >= 0) *reinterpret_cast<float4*>(Bd + bDst[it]) = rb[it];
+            if (newA) {
+                float* Ad = Abase + (nchunk & 1) * CFG::A_ELEMS;
+#pragma unroll
+                for (int it = 0; it < CFG::NA; ++it) if (aDst[it] >= 0) *reinterpret_cast<float4*>(Ad + aDst[it]) = ra[it];
+            }
+        }
+        __syncthreads();
+        chunk = nchunk; tap = ntap;
+    }
+
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = n0 + (wn * NTW + nt) * 32 + (lane & 31);
+        if (co >= cout) continue;
+        const float bv = J.bias ? J.bias[co] : 0.f;
+        const float bb = J.bbias ? J.bbias[size_t(b) * J.bbias_stride + co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int y = ty0 + p / TW, x = tx0 + p % TW;
+                if (y >= h || x >= w) continue;
+                float v = acc[mt][nt][r] + bv;
+                if (J.bbias) v += bb;
+                if (J.rcol) v += J.rcol[((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co];
+                if (J.rrow) v += J.rrow[((size_t(b) * h + y) * 4 + edge_variant(x, w)) * cout + co];
+                const size_t o = ((size_t(b) * h + y) * w + x) * cout + co;
+                if (J.res) v += J.res[o];
+                J.out[o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ naive direct convolution (debug only)
+__global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
+    for (int j = 0; j < args.njobs; ++j) {
+        const ConvJob& J = args.job[j];
+        const long long n = (long long)args.B * J.h * J.w * args.cout;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int co = int(i % args.cout);
+            long long r = i / args.cout;
+            const int x = int(r % J.w); r /= J.w;
+            const int y = int(r % J.h);
+            const int b = int(r / J.h);
+            float acc = 0.f;
+            for (int kh = 0; kh < KH; ++kh)
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int gy = y + kh - KH / 2, gx = x + kw - KW / 2;
+                    if (gy < 0 || gy >= J.h || gx < 0 || gx >= J.w) continue;
+                    const float* xi = J.in + ((size_t(b) * J.h + gy) * J.w + gx) * args.cin;
+                    const float* wr = J.wgt + (size_t(kh * KW + kw) * args.cout + co) * args.cin;
+                    for (int c = 0; c < args.cin; ++c) acc = fmaf(xi[c], wr[c], acc);
+                }
+            float v = acc + (J.bias ? J.bias[co] : 0.f);
+            if (J.bbias) v += J.bbias[size_t(b) * J.bbias_stride + co];
+            if (J.rcol) v += J.rcol[((size_t(b) * J.w + x) * 4 + edge_variant(y, J.h)) * args.cout + co];
+            if (J.rrow) v += J.rrow[((size_t(b) * J.h + y) * 4 + edge_variant(x, J.w)) * args.cout + co];
+            if (J.res) v += J.res[i];
+            J.out[i] = v;
+        }
+    }
+}
+
+bool conv_use_naive() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("S3D_CONV_IMPL");
+        v = (e && strcmp(e, "naive") == 0) ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static void kind_taps(ConvKind kind, int& KH, int& KW) {
+    switch (kind) {
+        case CONV_3x3: KH = 3; KW = 3; break;
+        case CONV_1x1: KH = 1; KW = 1; break;
+        case CONV_1x3_VEC: KH = 1; KW = 3; break;
+        default: KH = 5; KW = 5; break;
+    }
+}
+
+int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st) {
+    int KH, KW;
+    kind_taps(kind, KH, KW);
+    hipLaunchKernelGGL(k_conv_naive, dim3(2048), dim3(256), 0, st, a, KH, KW);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+template <class CFG>
+static int launch_cfg(ConvArgs& a, hipStream_t st) {
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        J.tiles_x = (J.w + CFG::TW - 1) / CFG::TW;
+        J.tiles_per_img = J.tiles_x * ((J.h + CFG::TH - 1) / CFG::TH);
+        J.n_tiles_n = (a.cout + CFG::BN - 1) / CFG::BN;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(k_conv_mfma<CFG>, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int TH, int TW>
+static long long count_tiles(const ConvArgs& a) {
+    long long t = 0;
+    for (int j = 0; j < a.njobs; ++j) t += (long long)((a.job[j].w + TW - 1) / TW) * ((a.job[j].h + TH - 1) / TH);
+    return t * a.B;
+}
+
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
+    S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
+    if (conv_use_naive()) return launch_conv_naive(kind, a, st);
+    // Tile choice: the 128-pixel tile halves the halo and B-tile traffic per flop, but at batch 1 the
+    // half-resolution layers only have a few hundred tiles: fall back to 64-pixel tiles when the big
+    // tile would leave CUs idle (256 CUs, 2 resident blocks each).
+    const long long n64 = (a.cout + 63) / 64;
+    switch (kind) {
+        case CONV_3x3:
+            if (count_tiles<8, 16>(a) * n64 >= 512) return launch_cfg<ConvCfg<8, 16, 3, 3, 4, 1, 1, 2>>(a, st);
+            return launch_cfg<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>>(a, st);
+        case CONV_1x1:
+            if (count_tiles<8, 16>(a) * n64 >= 512) return launch_cfg<ConvCfg<8, 16, 1, 1, 4, 1, 1, 2>>(a, st);
+            return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
+        case CONV_1x3_VEC:
+            return launch_cfg<ConvCfg<1, 32, 1, 3, 1, 4, 1, 1>>(a, st);
+        case CONV_5x5:
+            return launch_cfg<ConvCfg<8, 8, 5, 5, 2, 2, 1, 1>>(a, st);
+    }
+    set_error("conv: unknown kind %d", int(kind));
+    return S3D_ERR_INVALID;
+}
+
+}  // namespace s3d

@@ -1,0 +1,612 @@
+// s3d_kernels.hip — the memory-bound kernels of the triplane UNet step (everything except the
+// MFMA convolutions): layout changes, GroupNorm statistics, GN-apply+FiLM+SiLU with rollout means,
+// resampling, the output head, the timestep MLP and the sampler update.
+//
+// Layout: every activation plane is NHWC fp32 [B][h][w][C]; a thread always owns one float4 of
+// channels so that a wave reads/writes whole 128-byte (or longer) contiguous runs per pixel.
+// All reductions are two-stage with a fixed summation order (no float atomics): results are
+// bit-repeatable run to run.
+#include "s3d_common.h"
+
+namespace s3d {
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------ layout repacks (tests only)
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int B, int C, int hw) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t n = size_t(B) * C * hw;
+    if (i >= n) return;
+    int c = int(i % C);
+    size_t r = i / C;
+    int pix = int(r % hw);
+    int b = int(r / hw);
+    out[i] = in[(size_t(b) * C + c) * hw + pix];
+}
+__global__ void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int B, int C, int hw) {
+    size_t i = size_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    size_t n = size_t(B) * C * hw;
+    if (i >= n) return;
+    int pix = int(i % hw);
+    size_t r = i / hw;
+    int c = int(r % C);
+    int b = int(r / C);
+    out[i] = in[(size_t(b) * hw + pix) * C + c];
+}
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int h, int w, hipStream_t st) {
+    size_t n = size_t(B) * C * h * w;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, C, h * w);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w, hipStream_t st) {
+    size_t n = size_t(B) * C * h * w;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_nhwc_to_nchw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, C, h * w);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ in_conv
+// decompose_featmaps (src/utils/triplane_util.py:20-25) + TriplaneConv(in, ch, 1x1, no rollout)
+// (src/diffusion/unet_triplane.py:378, 482).  One thread = one pixel x 4 output channels.
+struct InConvArgs {
+    const float* x; const float* wT; const float* bias;
+    float* out[3];
+    int B, Cin, Cout, H, W, D;
+    int h[3], w[3];
+    long long pix_begin[4];   // prefix of per-plane pixel counts (per sample)
+};
+__global__ void k_in_conv(InConvArgs a) {
+    const int cq = a.Cout >> 2;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per_b = a.pix_begin[3] * cq;
+    if (i >= per_b * a.B) return;
+    const int b = int(i / per_b);
+    long long r = i % per_b;
+    const int q = int(r % cq);
+    long long pix = r / cq;
+    int p = pix >= a.pix_begin[2] ? 2 : (pix >= a.pix_begin[1] ? 1 : 0);
+    pix -= a.pix_begin[p];
+    const int y = int(pix / a.w[p]), xx = int(pix % a.w[p]);
+    const int Hc = a.H + a.D, Wc = a.W + a.D;
+    int sy, sx;
+    if (p == 0) { sy = y; sx = xx; }
+    else if (p == 1) { sy = y; sx = a.W + xx; }
+    else { sy = a.H + xx; sx = y; }                 // yz[w][d] = composed[H + d][w]
+    const float* src = a.x + (size_t(b) * a.Cin * Hc + sy) * Wc + sx;
+    const float4* wq = reinterpret_cast<const float4*>(a.wT + size_t(p) * a.Cin * a.Cout) + q;
+    float4 acc = reinterpret_cast<const float4*>(a.bias + size_t(p) * a.Cout)[q];
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        const float v = src[size_t(ci) * Hc * Wc];
+        const float4 wv = wq[size_t(ci) * cq];
+        acc.x = fmaf(v, wv.x, acc.x); acc.y = fmaf(v, wv.y, acc.y);
+        acc.z = fmaf(v, wv.z, acc.z); acc.w = fmaf(v, wv.w, acc.w);
+    }
+    reinterpret_cast<float4*>(a.out[p] + ((size_t(b) * a.h[p] + y) * a.w[p] + xx) * a.Cout)[q] = acc;
+}
+int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const float* wT, const float* bias,
+                   int Cout, Tri& out, hipStream_t st) {
+    InConvArgs a;
+    a.x = x; a.wT = wT; a.bias = bias; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
+    a.pix_begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.out[p] = out.p[p]; a.h[p] = out.g.h[p]; a.w[p] = out.g.w[p];
+        a.pix_begin[p + 1] = a.pix_begin[p] + (long long)a.h[p] * a.w[p];
+    }
+    long long n = a.pix_begin[3] * (Cout / 4) * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_in_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ GroupNorm statistics
+// GroupNorm32(32, C): per (sample, group) mean and biased variance over (C/32)*h*w (src/diffusion/nn.py:17-19,
+// 93-100).  Stage 1 here: each block reduces one pixel chunk of one plane to {sum, sumsq} per group, in double.
+// Stage 2 (gn_finalize, in the consumers) adds the kGnChunks partials in index order.
+struct GnPartArgs {
+    const float* x[3];
+    int h[3], w[3];
+    int C, cq, pl;
+    double* part;   // [B][3][kGnChunks][32][2]
+};
+__global__ void k_gn_partials(GnPartArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sm = reinterpret_cast<double*>(smem_raw);        // [pl][C][2]
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int npix = a.h[p] * a.w[p];
+    const int per = (npix + kGnChunks - 1) / kGnChunks;
+    const int p0 = chunk * per, p1 = min(npix, p0 + per);
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float4* src = reinterpret_cast<const float4*>(a.x[p] + size_t(b) * npix * a.C) + q;
+    for (int pix = p0 + l; pix < p1; pix += a.pl) {
+        const float4 v = src[size_t(pix) * a.cq];
+        s[0] += v.x; ss[0] += double(v.x) * v.x;
+        s[1] += v.y; ss[1] += double(v.y) * v.y;
+        s[2] += v.z; ss[2] += double(v.z) * v.z;
+        s[3] += v.w; ss[3] += double(v.w) * v.w;
+    }
+    for (int k = 0; k < 4; ++k) {
+        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 0] = s[k];
+        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 1] = ss[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x, cg = a.C / 32;
+        double S = 0, SS = 0;
+        for (int ll = 0; ll < a.pl; ++ll)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                S += sm[(size_t(ll) * a.C + c) * 2 + 0];
+                SS += sm[(size_t(ll) * a.C + c) * 2 + 1];
+            }
+        double* o = a.part + (((size_t(b) * 3 + p) * kGnChunks + chunk) * 32 + g) * 2;
+        o[0] = S; o[1] = SS;
+    }
+}
+static void thread_shape(int C, int& cq, int& pl) {
+    cq = C / 4;
+    pl = cq >= 256 ? 1 : 256 / cq;
+}
+int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st) {
+    GnPartArgs a;
+    for (int p = 0; p < 3; ++p) { a.x[p] = x.p[p]; a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p]; }
+    a.C = x.C; thread_shape(x.C, a.cq, a.pl); a.part = out.p;
+    S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d must be a multiple of 32 and <= 4096", x.C);
+    size_t shm = size_t(a.pl) * a.C * 2 * sizeof(double);
+    hipLaunchKernelGGL(k_gn_partials, dim3(kGnChunks, 3, B), dim3(a.cq * a.pl), shm, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// mean / rstd of group g for (b, plane p): fixed-order sum of the chunk partials, in double.
+__device__ __forceinline__ void gn_finalize(const double* part, int b, int p, int g, double n, float eps,
+                                            float& mean, float& rstd) {
+    const double* src = part + ((size_t(b) * 3 + p) * kGnChunks * 32 + g) * 2;
+    double S = 0, SS = 0;
+    for (int c = 0; c < kGnChunks; ++c) { S += src[size_t(c) * 64]; SS += src[size_t(c) * 64 + 1]; }
+    const double m = S / n;
+    double var = SS / n - m * m;
+    if (var < 0) var = 0;
+    mean = float(m);
+    rstd = float(1.0 / sqrt(var + double(eps)));
+}
+
+// ------------------------------------------------------------------ GN-apply (+FiLM) + SiLU (+ rollout partial means)
+// TriplaneNorm + TriplaneSiLU (src/diffusion/unet_triplane.py:63-95), with the FiLM modulation
+// h*(1+scale)+shift of TriplaneResBlock._forward (:285-297) applied between them, and the axis sums the
+// next TriplaneConv's rollout needs (:37-46) accumulated on the way out.
+// y = x*(rstd*gamma) + (beta - mean*rstd*gamma) is the form ATen's CPU group_norm kernel evaluates.
+struct GnActArgs {
+    const float* x[3]; float* y[3];
+    const float* gamma[3]; const float* beta[3];
+    float* rowpart[3]; float* colpart[3];
+    const double* part;
+    const float* film; int film_stride;
+    int h[3], w[3];
+    int C, cq, pl, with_means;
+};
+__global__ void k_gn_act(GnActArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);           // [64] stats, then [pl][kActRows][C] row sums
+    const int p = blockIdx.y, b = blockIdx.z;
+    const int h = a.h[p], w = a.w[p];
+    const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
+    if (int(blockIdx.x) >= ntc * ntr) return;
+    const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+    const bool ident = a.part == nullptr;
+    if (threadIdx.x < 32 && !ident) {
+        float m, r;
+        gn_finalize(a.part, b, p, threadIdx.x, double(a.C / 32) * h * w, 1e-5f, m, r);
+        sm[threadIdx.x] = m; sm[32 + threadIdx.x] = r;
+    }
+    __syncthreads();
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    const int cg = a.C / 32;
+    float A[4], Bc[4], sc[4], sh[4];
+    const bool film = a.film != nullptr;
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k, g = c / cg;
+        const float scale = ident ? 1.0f : sm[32 + g] * a.gamma[p][c];
+        A[k] = scale;
+        Bc[k] = ident ? 0.0f : a.beta[p][c] - scale * sm[g];
+        sc[k] = film ? 1.0f + a.film[size_t(b) * a.film_stride + c] : 1.0f;
+        sh[k] = film ? a.film[size_t(b) * a.film_stride + a.C + c] : 0.0f;
+    }
+    __syncthreads();                                            // stats region of sm is reused below
+    const int i0 = tr * kActRows, j0 = tc * kActCols;
+    const int i1 = min(h, i0 + kActRows), j1 = min(w, j0 + kActCols);
+    const float4* xs = reinterpret_cast<const float4*>(a.x[p] + size_t(b) * h * w * a.C) + q;
+    float4* ys = reinterpret_cast<float4*>(a.y[p] + size_t(b) * h * w * a.C) + q;
+    float4 rowacc[kActRows];
+#pragma unroll
+    for (int r = 0; r < kActRows; ++r) rowacc[r] = make_float4(0, 0, 0, 0);
+    for (int j = j0 + l; j < j1; j += a.pl) {
+        float4 colacc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < kActRows; ++r) {
+            const int i = i0 + r;
+            if (i < i1) {
+                const size_t off = (size_t(i) * w + j) * a.cq;
+                const float4 v = xs[off];
+                float4 o;
+                o.x = fmaf(v.x, A[0], Bc[0]); o.y = fmaf(v.y, A[1], Bc[1]);
+                o.z = fmaf(v.z, A[2], Bc[2]); o.w = fmaf(v.w, A[3], Bc[3]);
+                if (film) {
+                    o.x = o.x * sc[0] + sh[0]; o.y = o.y * sc[1] + sh[1];
+                    o.z = o.z * sc[2] + sh[2]; o.w = o.w * sc[3] + sh[3];
+                }
+                if (!ident) { o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w); }
+                ys[off] = o;
+                colacc.x += o.x; colacc.y += o.y; colacc.z += o.z; colacc.w += o.w;
+                rowacc[r].x += o.x; rowacc[r].y += o.y; rowacc[r].z += o.z; rowacc[r].w += o.w;
+            }
+        }
+        if (a.with_means)
+            reinterpret_cast<float4*>(a.colpart[p] + ((size_t(b) * ntr + tr) * w + j) * a.C)[q] = colacc;
+    }
+    if (!a.with_means) return;
+    float4* smr = reinterpret_cast<float4*>(sm);               // [pl][kActRows][cq]
+#pragma unroll
+    for (int r = 0; r < kActRows; ++r) smr[(size_t(l) * kActRows + r) * a.cq + q] = rowacc[r];
+    __syncthreads();
+    const int nthr = a.cq * a.pl;
+    for (int it = threadIdx.x; it < kActRows * a.cq; it += nthr) {
+        const int r = it / a.cq, qq = it % a.cq;
+        const int i = i0 + r;
+        if (i >= i1) continue;
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int ll = 0; ll < a.pl; ++ll) {
+            const float4 v = smr[(size_t(ll) * kActRows + r) * a.cq + qq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(a.rowpart[p] + ((size_t(b) * ntc + tc) * h + i) * a.C)[qq] = s;
+    }
+}
+int launch_gn_act(const Tri& x, int B, GnPartials stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
+                  hipStream_t st) {
+    GnActArgs a;
+    int maxtiles = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = x.p[p]; a.y[p] = y.p[p]; a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p];
+        a.gamma[p] = aa.gamma[p]; a.beta[p] = aa.beta[p];
+        a.rowpart[p] = mp ? mp->rowpart[p] : nullptr;
+        a.colpart[p] = mp ? mp->colpart[p] : nullptr;
+        maxtiles = std::max(maxtiles, cdiv(a.h[p], kActRows) * cdiv(a.w[p], kActCols));
+    }
+    a.part = stats.p; a.film = aa.film; a.film_stride = aa.film_stride;
+    a.C = x.C; thread_shape(x.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
+    S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
+    if (!maxtiles || !B) return 0;
+    size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
+    hipLaunchKernelGGL(k_gn_act, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// th.mean over one axis of the activated planes (src/diffusion/unet_triplane.py:38-46): add the tile partials
+// in index order and divide by the axis length.
+struct MeanFinArgs {
+    const float* rowpart[3]; const float* colpart[3];
+    float* rowmean[3]; float* colmean[3];
+    int h[3], w[3];
+    int C, cq, B;
+    long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
+};
+__global__ void k_means_finalize(MeanFinArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.begin[6] * a.B) return;
+    const int b = int(i / a.begin[6]);
+    long long r = i % a.begin[6];
+    int v = 0;
+    while (r >= a.begin[v + 1]) ++v;
+    r -= a.begin[v];
+    const int p = v >> 1, is_col = v & 1;
+    const int pos = int(r / a.cq), q = int(r % a.cq);
+    const int h = a.h[p], w = a.w[p];
+    float4 s = make_float4(0, 0, 0, 0);
+    if (!is_col) {
+        const int ntc = (w + kActCols - 1) / kActCols;
+        for (int t = 0; t < ntc; ++t) {
+            const float4 u = reinterpret_cast<const float4*>(a.rowpart[p] + ((size_t(b) * ntc + t) * h + pos) * a.C)[q];
+            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+        }
+        const float inv = 1.0f / float(w);
+        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+        reinterpret_cast<float4*>(a.rowmean[p] + (size_t(b) * h + pos) * a.C)[q] = s;
+    } else {
+        const int ntr = (h + kActRows - 1) / kActRows;
+        for (int t = 0; t < ntr; ++t) {
+            const float4 u = reinterpret_cast<const float4*>(a.colpart[p] + ((size_t(b) * ntr + t) * w + pos) * a.C)[q];
+            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+        }
+        const float inv = 1.0f / float(h);
+        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+        reinterpret_cast<float4*>(a.colmean[p] + (size_t(b) * w + pos) * a.C)[q] = s;
+    }
+}
+int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st) {
+    MeanFinArgs a;
+    a.C = C; a.cq = C / 4; a.B = B; a.begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.rowpart[p] = mp.rowpart[p]; a.colpart[p] = mp.colpart[p];
+        a.rowmean[p] = mv.rowmean[p]; a.colmean[p] = mv.colmean[p];
+        a.h[p] = g.h[p]; a.w[p] = g.w[p];
+        a.begin[2 * p + 1] = a.begin[2 * p] + (long long)g.h[p] * a.cq;
+        a.begin[2 * p + 2] = a.begin[2 * p + 1] + (long long)g.w[p] * a.cq;
+    }
+    long long n = a.begin[6] * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_means_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ resampling
+// F.avg_pool2d(k=2, s=2)  (src/diffusion/unet_triplane.py:137-139): floor(h/2) x floor(w/2)
+struct PoolArgs { const float* x[3]; float* y[3]; int h[3], w[3]; int cq, B; long long begin[4]; };
+__global__ void k_avgpool(PoolArgs a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.begin[3] * a.B) return;
+    const int b = int(i / a.begin[3]);
+    long long r = i % a.begin[3];
+    int p = r >= a.begin[2] ? 2 : (r >= a.begin[1] ? 1 : 0);
+    r -= a.begin[p];
+    const int q = int(r % a.cq);
+    const int ho = a.h[p] / 2, wo = a.w[p] / 2;
+    const int xo = int((r / a.cq) % wo), yo = int(r / a.cq / wo);
+    const float4* src = reinterpret_cast<const float4*>(a.x[p]) + ((size_t(b) * a.h[p] + 2 * yo) * a.w[p] + 2 * xo) * a.cq + q;
+    const float4 v00 = src[0], v01 = src[a.cq], v10 = src[size_t(a.w[p]) * a.cq], v11 = src[size_t(a.w[p] + 1) * a.cq];
+    float4 o;
+    o.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f; o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
+    o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f; o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
+    reinterpret_cast<float4*>(a.y[p])[((size_t(b) * ho + yo) * wo + xo) * a.cq + q] = o;
+    (void)ho;
+}
+int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st) {
+    PoolArgs a;
+    a.cq = x.C / 4; a.B = B; a.begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = x.p[p]; a.y[p] = y.p[p]; a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p];
+        a.begin[p + 1] = a.begin[p] + (long long)(a.h[p] / 2) * (a.w[p] / 2) * a.cq;
+    }
+    long long n = a.begin[3] * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// F.interpolate(mode='bilinear', align_corners=False), scale_factor=2 (:116-118) or size=... (:494-499):
+// src = (in/out)*(dst+0.5)-0.5 clamped at 0; neighbour index clamped to in-1.
+__global__ void k_bilinear(const float* __restrict__ in, float* __restrict__ out, int B, int cq, int hi, int wi,
+                           int ho, int wo, int out_cq, int out_q0) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)B * ho * wo * cq;
+    if (i >= n) return;
+    const int q = int(i % cq);
+    long long r = i / cq;
+    const int xo = int(r % wo); r /= wo;
+    const int yo = int(r % ho);
+    const int b = int(r / ho);
+    const float sh = float(hi) / float(ho), sw = float(wi) / float(wo);
+    float fy = sh * (float(yo) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = sw * (float(xo) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+    int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+    const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+    const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+    const float4* src = reinterpret_cast<const float4*>(in) + size_t(b) * hi * wi * cq + q;
+    const float4 a = src[(size_t(y0) * wi + x0) * cq], bq = src[(size_t(y0) * wi + x1) * cq];
+    const float4 c = src[(size_t(y1) * wi + x0) * cq], d = src[(size_t(y1) * wi + x1) * cq];
+    float4 o;
+    o.x = ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * c.x + lx1 * d.x);
+    o.y = ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * c.y + lx1 * d.y);
+    o.z = ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * c.z + lx1 * d.z);
+    o.w = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * c.w + lx1 * d.w);
+    reinterpret_cast<float4*>(out)[((size_t(b) * ho + yo) * wo + xo) * out_cq + out_q0 + q] = o;
+}
+int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, int ho, int wo, int out_cstride,
+                    int out_coff, hipStream_t st) {
+    long long n = (long long)B * ho * wo * (C / 4);
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_bilinear, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, B, C / 4, hi, wi, ho,
+                       wo, out_cstride / 4, out_coff / 4);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+__global__ void k_copy_slice(const float* __restrict__ in, float* __restrict__ out, long long npix, int cq, int out_cq,
+                             int out_q0) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * cq) return;
+    const int q = int(i % cq);
+    const long long pix = i / cq;
+    reinterpret_cast<float4*>(out)[pix * out_cq + out_q0 + q] = reinterpret_cast<const float4*>(in)[i];
+}
+int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, int out_cstride, int out_coff,
+                      hipStream_t st) {
+    long long npix = (long long)B * h * w;
+    long long n = npix * (C / 4);
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_copy_slice, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, out, npix, C / 4,
+                       out_cstride / 4, out_coff / 4);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ output head
+// out = TriplaneNorm -> TriplaneSiLU -> TriplaneConv(ch, out_channels, 1x1) then compose_featmaps
+// (src/diffusion/unet_triplane.py:441-445, 507-508 ; src/utils/triplane_util.py:7-17).
+// blockIdx.y: plane 0..2, 3 = the DxD corner that compose fills with zeros.
+struct OutHeadArgs {
+    const float* x[3]; const float* gamma[3]; const float* beta[3];
+    const double* part; const float* w; const float* bias; float* out;
+    int h[3], wd[3];
+    int C, Cout, H, W, D;
+};
+constexpr int kOutPix = 16;
+__global__ void k_out_head(OutHeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);           // [64] stats + A[C] + Bc[C]
+    const int p = blockIdx.y, b = blockIdx.z;
+    const int Hc = a.H + a.D, Wc = a.W + a.D;
+    if (p == 3) {                                              // zero corner
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)a.Cout * a.D * a.D;
+             i += (long long)gridDim.x * blockDim.x) {
+            const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
+            a.out[((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx] = 0.f;
+        }
+        return;
+    }
+    const int h = a.h[p], w = a.wd[p], npix = h * w;
+    if (int(blockIdx.x) * kOutPix >= npix) return;
+    if (threadIdx.x < 32) {
+        float m, r;
+        gn_finalize(a.part, b, p, threadIdx.x, double(a.C / 32) * npix, 1e-5f, m, r);
+        sm[threadIdx.x] = m; sm[32 + threadIdx.x] = r;
+    }
+    __syncthreads();
+    float* A = sm + 64; float* Bc = A + a.C;
+    const int cg = a.C / 32;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        const float scale = sm[32 + c / cg] * a.gamma[p][c];
+        A[c] = scale; Bc[c] = a.beta[p][c] - scale * sm[c / cg];
+    }
+    __syncthreads();
+    const int lp = threadIdx.x / 16, cs = threadIdx.x % 16;
+    const int pix = blockIdx.x * kOutPix + lp;
+    if (pix >= npix) return;
+    const int y = pix / w, xx = pix % w;
+    const float4* xs = reinterpret_cast<const float4*>(a.x[p] + (size_t(b) * npix + pix) * a.C);
+    for (int co = cs; co < a.Cout; co += 16) {
+        const float4* wr = reinterpret_cast<const float4*>(a.w + (size_t(p) * a.Cout + co) * a.C);
+        float acc = a.bias[p * a.Cout + co];
+        for (int c4 = 0; c4 < a.C / 4; ++c4) {
+            const float4 v = xs[c4], wv = wr[c4];
+            const float4 A4 = reinterpret_cast<const float4*>(A)[c4], B4 = reinterpret_cast<const float4*>(Bc)[c4];
+            acc = fmaf(silu_f(fmaf(v.x, A4.x, B4.x)), wv.x, acc);
+            acc = fmaf(silu_f(fmaf(v.y, A4.y, B4.y)), wv.y, acc);
+            acc = fmaf(silu_f(fmaf(v.z, A4.z, B4.z)), wv.z, acc);
+            acc = fmaf(silu_f(fmaf(v.w, A4.w, B4.w)), wv.w, acc);
+        }
+        int sy, sx;
+        if (p == 0) { sy = y; sx = xx; } else if (p == 1) { sy = y; sx = a.W + xx; } else { sy = a.H + xx; sx = y; }
+        a.out[((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx] = acc;
+    }
+}
+int launch_out_head(const Tri& x, int B, GnPartials stats, const ActArgs& aa, const float* w, const float* bias,
+                    int Cout, int H, int W, int D, float* out, hipStream_t st) {
+    OutHeadArgs a;
+    int maxpix = D * D ? 1 : 0;
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = x.p[p]; a.gamma[p] = aa.gamma[p]; a.beta[p] = aa.beta[p];
+        a.h[p] = x.g.h[p]; a.wd[p] = x.g.w[p];
+        maxpix = std::max(maxpix, a.h[p] * a.wd[p]);
+    }
+    a.part = stats.p; a.w = w; a.bias = bias; a.out = out; a.C = x.C; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
+    if (!maxpix || !B) return 0;
+    size_t shm = (64 + 2 * size_t(x.C)) * sizeof(float);
+    hipLaunchKernelGGL(k_out_head, dim3(cdiv(maxpix, kOutPix), 4, B), dim3(256), shm, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ timestep path
+// timestep_embedding (src/diffusion/nn.py:103-121) -> time_embed (unet_triplane.py:371-375, 477) ->
+// per-block emb_layers SiLU+Linear (:232-238, 281).  One wave per output feature.
+__global__ void k_linear(const float* __restrict__ in, int I, const float* __restrict__ W, const float* __restrict__ bias,
+                         int O, float* __restrict__ out, int B, int in_mode, int out_silu) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * O) return;
+    const int b = wave / O, o = wave % O;
+    const float* wr = W + size_t(o) * I;
+    float acc = 0.f;
+    if (in_mode == 2) {
+        const float t = in[b];
+        const int half = I / 2;
+        for (int i = lane; i < I; i += 64) {
+            float v;
+            if (i < 2 * half) {
+                const int k = i < half ? i : i - half;
+                const float f = expf(-logf(10000.f) * float(k) / float(half));
+                const float arg = t * f;
+                v = i < half ? cosf(arg) : sinf(arg);
+            } else v = 0.f;                                  // odd dim: trailing zero column (nn.py:119-120)
+            acc = fmaf(v, wr[i], acc);
+        }
+    } else {
+        const float* xr = in + size_t(b) * I;
+        for (int i = lane; i < I; i += 64) {
+            float v = xr[i];
+            if (in_mode == 1) v = silu_f(v);
+            acc = fmaf(v, wr[i], acc);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        float r = acc + (bias ? bias[o] : 0.f);
+        out[size_t(b) * O + o] = out_silu ? silu_f(r) : r;
+    }
+}
+int launch_linear(const float* in, int B, int I, const float* W, const float* bias, int O, float* out, int in_mode,
+                  int out_silu, hipStream_t st) {
+    long long waves = (long long)B * O;
+    if (!waves) return 0;
+    hipLaunchKernelGGL(k_linear, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, in, I, W, bias, O, out, B, in_mode,
+                       out_silu);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ sampler update
+// p_mean_variance (START_X | EPSILON, FIXED_* variance, clip) + p_sample / ddim_sample in one pass.
+// src/diffusion/gaussian_diffusion.py:233-327, 346-350, 396-440, 538-600.  Coefficients are the fp32
+// casts of the float64 tables, gathered per sample by t (as _extract_into_tensor does, :934-947).
+__global__ void k_sampler(s3d_sampler_args a) {
+    const long long n = a.batch * a.per_sample;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = int(i / a.per_sample);
+        const int t = int(a.t[b]);
+        const float sr = a.tables[S3D_TAB_SQRT_RECIP * a.T + t], srm1 = a.tables[S3D_TAB_SQRT_RECIPM1 * a.T + t];
+        const float xt = a.x[i];
+        float x0 = a.model_out[i];
+        if (a.mean_type == S3D_MEAN_EPSILON) x0 = sr * xt - srm1 * x0;
+        if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        const float nz = t != 0 ? 1.f : 0.f;
+        if (a.mode == S3D_STEP_DDIM) {
+            if (a.y0 && a.mask) {
+                const float m = a.mask[i], mixed = m * a.y0[i] + (1.f - m) * x0;
+                x0 = a.is_mask_t0 ? mixed : mixed * nz + x0 * (1.f - nz);
+            }
+            const float eps = (sr * xt - x0) / srm1;
+            const float ab = a.tables[S3D_TAB_ACP * a.T + t], abp = a.tables[S3D_TAB_ACP_PREV * a.T + t];
+            const float sigma = a.eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+            const float mean_pred = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * eps;
+            const float nv = a.noise ? a.noise[i] : 0.f;
+            a.sample[i] = mean_pred + nz * sigma * nv;
+            a.pred_xstart[i] = x0;
+        } else {
+            const float mean = a.tables[S3D_TAB_COEF1 * a.T + t] * x0 + a.tables[S3D_TAB_COEF2 * a.T + t] * xt;
+            if (a.mean) a.mean[i] = mean;
+            a.pred_xstart[i] = x0;
+            if (a.mode == S3D_STEP_DDPM) {
+                const float lv = a.tables[S3D_TAB_LOGVAR * a.T + t];
+                a.sample[i] = mean + nz * expf(0.5f * lv) * a.noise[i];
+            }
+        }
+    }
+}
+int launch_sampler(const s3d_sampler_args& a, hipStream_t st) {
+    const long long n = a.batch * a.per_sample;
+    if (n <= 0) return 0;
+    unsigned blocks = (unsigned)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_sampler, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace s3d

@@ -1,0 +1,487 @@
+// s3d_unet.hip — host side of the denoiser: parameter registry, weight repacking and the kernel
+// sequence of TriplaneUNetModelSmall.forward (src/diffusion/unet_triplane.py:465-510).
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+#include "s3d_common.h"
+
+namespace s3d {
+
+static const char* kPlane[3] = {"xy", "xz", "yz"};
+
+struct ParamSpec {
+    std::string name;
+    std::vector<int64_t> shape;
+    size_t numel() const { size_t n = 1; for (auto d : shape) n *= size_t(d); return n; }
+};
+
+struct NormW { size_t gamma[3], beta[3]; };
+struct ResBlockW {
+    std::string prefix;
+    int C, Cout;
+    NormW n1, n2;
+    ConvW c1, c2, skip;
+    bool has_skip;
+    int film_off;                      // offset of this block's emb_layers output in the concatenated FiLM row
+};
+
+}  // namespace s3d
+
+using namespace s3d;
+
+struct s3d_unet {
+    s3d_unet_cfg cfg;
+    std::vector<ParamSpec> specs;
+    std::map<std::string, std::vector<float>> host;     // as handed to set_param (PyTorch layouts)
+    bool packed = false;
+
+    // packed parameters, one device allocation, offsets in floats
+    DevBuf wbuf;
+    std::vector<float> stage;                            // host staging of the packed image
+    size_t te0_w, te0_b, te2_w, te2_b, film_w, film_b;
+    int film_total = 0;
+    size_t in_wT, in_b, out_w, out_b;
+    NormW out_norm;
+    std::vector<ResBlockW> in_blocks, out_blocks;
+
+    Arena arena;
+
+    const float* dev(size_t off) const { return static_cast<const float*>(wbuf.p) + off; }
+};
+
+namespace s3d {
+
+static void add_lin(std::vector<ParamSpec>& s, const std::string& p, int o, int i) {
+    s.push_back({p + ".weight", {o, i}});
+    s.push_back({p + ".bias", {o}});
+}
+static void add_tconv(std::vector<ParamSpec>& s, const std::string& p, int cin, int cout, int k, bool roll) {
+    for (int i = 0; i < 3; ++i) {
+        s.push_back({p + ".conv_" + kPlane[i] + ".weight", {cout, roll ? 3 * cin : cin, k, k}});
+        s.push_back({p + ".conv_" + kPlane[i] + ".bias", {cout}});
+    }
+}
+static void add_tnorm(std::vector<ParamSpec>& s, const std::string& p, int c) {
+    for (int i = 0; i < 3; ++i) {
+        s.push_back({p + ".norm_" + kPlane[i] + ".weight", {c}});
+        s.push_back({p + ".norm_" + kPlane[i] + ".bias", {c}});
+    }
+}
+static void add_resblock(std::vector<ParamSpec>& s, const std::string& p, int c, int cout, int ted, bool ssn, bool roll) {
+    add_tnorm(s, p + ".in_layers.0", c);
+    add_tconv(s, p + ".in_layers.2", c, cout, 3, roll);
+    add_lin(s, p + ".emb_layers.1", ssn ? 2 * cout : cout, ted);
+    add_tnorm(s, p + ".out_layers.0", cout);
+    add_tconv(s, p + ".out_layers.2", cout, cout, 3, roll);
+    if (c != cout) add_tconv(s, p + ".skip_connection", c, cout, 1, false);
+}
+
+// Mirrors TriplaneUNetModelSmall.__init__ (src/diffusion/unet_triplane.py:346-449).
+static int build_specs(s3d_unet* m) {
+    const s3d_unet_cfg& c = m->cfg;
+    const int mc = c.model_channels, ted = 4 * mc;
+    const bool ssn = c.use_scale_shift_norm != 0, roll = c.is_rollout != 0;
+    auto& s = m->specs;
+    add_lin(s, "time_embed.0", ted, mc);
+    add_lin(s, "time_embed.2", ted, ted);
+    int ch = c.channel_mult[0] * mc;
+    add_tconv(s, "in_conv.0", c.in_channels, ch, 1, false);
+    std::vector<int> chans{ch};
+    int film = 0;
+    for (int level = 0; level < c.n_levels; ++level) {
+        const int cout = c.channel_mult[level] * mc;
+        ResBlockW rb;
+        rb.prefix = "input_blocks." + std::to_string(level) + "." + std::to_string(level == 0 ? 0 : 1);
+        rb.C = ch; rb.Cout = cout; rb.has_skip = ch != cout; rb.film_off = film;
+        film += ssn ? 2 * cout : cout;
+        add_resblock(s, rb.prefix, ch, cout, ted, ssn, roll);
+        m->in_blocks.push_back(rb);
+        ch = cout;
+        chans.push_back(ch);
+    }
+    for (int oi = 0; oi < c.n_levels; ++oi) {
+        const int level = c.n_levels - 1 - oi;
+        int ich = chans.back(); chans.pop_back();
+        if (oi == 0) ich = 0;
+        const int cout = c.channel_mult[level] * mc;
+        ResBlockW rb;
+        rb.prefix = "output_blocks." + std::to_string(oi) + ".0";
+        rb.C = ch + ich; rb.Cout = cout; rb.has_skip = rb.C != cout; rb.film_off = film;
+        film += ssn ? 2 * cout : cout;
+        add_resblock(s, rb.prefix, rb.C, cout, ted, ssn, roll);
+        m->out_blocks.push_back(rb);
+        ch = cout;
+    }
+    m->film_total = film;
+    add_tnorm(s, "out.0", ch);
+    add_tconv(s, "out.2", c.channel_mult[0] * mc, c.out_channels, 1, false);
+    return 0;
+}
+
+// ------------------------------------------------------------------ packing
+size_t push(std::vector<float>& st, const float* src, size_t n) {
+    size_t off = (st.size() + 63) & ~size_t(63);      // 256-byte aligned starts
+    st.resize(off + n);
+    if (src) memcpy(st.data() + off, src, n * sizeof(float));
+    return off;
+}
+static const std::vector<float>& H(const s3d_unet* m, const std::string& name) { return m->host.at(name); }
+
+// taps of the summed-out axis that stay inside the image, by edge variant (see edge_variant in s3d_conv.hip)
+static const int kVarTaps[4][3] = {{1, 1, 1}, {0, 1, 1}, {1, 1, 0}, {0, 1, 0}};
+
+// Pack one TriplaneConv.  Rollout channel blocks (src/diffusion/unet_triplane.py:37-46):
+//   plane xy: A = mean_d(yz) varies along columns (w), B = mean_d(xz) varies along rows (h)
+//   plane xz: A = mean_w(xy) varies along rows (h),    B = mean_w(yz) varies along columns (d)
+//   plane yz: A = mean_h(xy) varies along rows (w),    B = mean_h(xz) varies along columns (d)
+void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const float* const bp[3], int cin, int cout,
+                    int k, bool roll, ConvW& cw) {
+    cw.cin = cin; cw.cout = cout; cw.k = k; cw.rollout = roll;
+    const int taps = k * k, ctot = roll ? 3 * cin : cin;
+    for (int p = 0; p < 3; ++p) {
+        const float* W = Wp[p];                                   // [cout][ctot][k][k]
+        cw.bias[p] = push(stage, bp[p], cout);
+        cw.dense[p] = push(stage, nullptr, size_t(taps) * cout * cin);
+        float* d = stage.data() + cw.dense[p];
+        for (int t = 0; t < taps; ++t)
+            for (int co = 0; co < cout; ++co)
+                for (int c = 0; c < cin; ++c) d[(size_t(t) * cout + co) * cin + c] = W[(size_t(co) * ctot + c) * taps + t];
+        if (!roll) continue;
+        const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
+        for (int slot = 1; slot <= 2; ++slot) {
+            const bool col_varying = (slot == 1) ? a_is_col : !a_is_col;
+            size_t off = push(stage, nullptr, size_t(3) * 4 * cout * cin);
+            float* r = stage.data() + off;
+            for (int t = 0; t < 3; ++t)                      // tap along the vector's own axis
+                for (int var = 0; var < 4; ++var)
+                    for (int co = 0; co < cout; ++co)
+                        for (int c = 0; c < cin; ++c) {
+                            double s = 0;
+                            for (int o = 0; o < 3; ++o) {       // the summed-out axis
+                                if (!kVarTaps[var][o]) continue;
+                                const int kh = col_varying ? o : t, kw = col_varying ? t : o;
+                                s += W[(size_t(co) * ctot + slot * cin + c) * 9 + kh * 3 + kw];
+                            }
+                            r[(size_t(t) * 4 * cout + var * cout + co) * cin + c] = float(s);
+                        }
+            if (col_varying) cw.rcol[p] = off; else cw.rrow[p] = off;
+        }
+    }
+}
+static void pack_tconv(s3d_unet* m, const std::string& prefix, int cin, int cout, int k, bool roll, ConvW& cw) {
+    const float* W[3]; const float* bv[3];
+    for (int p = 0; p < 3; ++p) {
+        W[p] = H(m, prefix + ".conv_" + kPlane[p] + ".weight").data();
+        bv[p] = H(m, prefix + ".conv_" + kPlane[p] + ".bias").data();
+    }
+    pack_tconv_raw(m->stage, W, bv, cin, cout, k, roll, cw);
+}
+static void pack_norm(s3d_unet* m, const std::string& prefix, int c, NormW& nw) {
+    for (int p = 0; p < 3; ++p) {
+        nw.gamma[p] = push(m->stage, H(m, prefix + ".norm_" + kPlane[p] + ".weight").data(), c);
+        nw.beta[p] = push(m->stage, H(m, prefix + ".norm_" + kPlane[p] + ".bias").data(), c);
+    }
+}
+
+static int pack_all(s3d_unet* m) {
+    for (const auto& sp : m->specs)
+        S3D_CHECK(m->host.count(sp.name), S3D_ERR_MISSING, "parameter '%s' was never set (load_state_dict incomplete)", sp.name.c_str());
+    const s3d_unet_cfg& c = m->cfg;
+    const int mc = c.model_channels, ted = 4 * mc;
+    const bool ssn = c.use_scale_shift_norm != 0, roll = c.is_rollout != 0;
+    m->stage.clear();
+    m->te0_w = push(m->stage, H(m, "time_embed.0.weight").data(), size_t(ted) * mc);
+    m->te0_b = push(m->stage, H(m, "time_embed.0.bias").data(), ted);
+    m->te2_w = push(m->stage, H(m, "time_embed.2.weight").data(), size_t(ted) * ted);
+    m->te2_b = push(m->stage, H(m, "time_embed.2.bias").data(), ted);
+    // all emb_layers.1 stacked into one [film_total][4mc] matrix -> one launch per forward
+    m->film_w = push(m->stage, nullptr, size_t(m->film_total) * ted);
+    m->film_b = push(m->stage, nullptr, m->film_total);
+    auto pack_block = [&](ResBlockW& rb) {
+        const int eo = ssn ? 2 * rb.Cout : rb.Cout;
+        memcpy(m->stage.data() + m->film_w + size_t(rb.film_off) * ted, H(m, rb.prefix + ".emb_layers.1.weight").data(),
+               size_t(eo) * ted * sizeof(float));
+        memcpy(m->stage.data() + m->film_b + rb.film_off, H(m, rb.prefix + ".emb_layers.1.bias").data(), eo * sizeof(float));
+        pack_norm(m, rb.prefix + ".in_layers.0", rb.C, rb.n1);
+        pack_tconv(m, rb.prefix + ".in_layers.2", rb.C, rb.Cout, 3, roll, rb.c1);
+        pack_norm(m, rb.prefix + ".out_layers.0", rb.Cout, rb.n2);
+        pack_tconv(m, rb.prefix + ".out_layers.2", rb.Cout, rb.Cout, 3, roll, rb.c2);
+        if (rb.has_skip) pack_tconv(m, rb.prefix + ".skip_connection", rb.C, rb.Cout, 1, false, rb.skip);
+    };
+    for (auto& rb : m->in_blocks) pack_block(rb);
+    for (auto& rb : m->out_blocks) pack_block(rb);
+    // in_conv: transposed [3][Cin][Cout]
+    {
+        const int ci = c.in_channels, co = c.channel_mult[0] * mc;
+        m->in_wT = push(m->stage, nullptr, size_t(3) * ci * co);
+        m->in_b = push(m->stage, nullptr, size_t(3) * co);
+        for (int p = 0; p < 3; ++p) {
+            const auto& W = H(m, std::string("in_conv.0.conv_") + kPlane[p] + ".weight");
+            const auto& bv = H(m, std::string("in_conv.0.conv_") + kPlane[p] + ".bias");
+            for (int i = 0; i < ci; ++i)
+                for (int o = 0; o < co; ++o) m->stage[m->in_wT + (size_t(p) * ci + i) * co + o] = W[size_t(o) * ci + i];
+            memcpy(m->stage.data() + m->in_b + size_t(p) * co, bv.data(), co * sizeof(float));
+        }
+    }
+    {
+        const int ci = c.channel_mult[0] * mc, co = c.out_channels;
+        pack_norm(m, "out.0", ci, m->out_norm);
+        m->out_w = push(m->stage, nullptr, size_t(3) * co * ci);
+        m->out_b = push(m->stage, nullptr, size_t(3) * co);
+        for (int p = 0; p < 3; ++p) {
+            memcpy(m->stage.data() + m->out_w + size_t(p) * co * ci, H(m, std::string("out.2.conv_") + kPlane[p] + ".weight").data(),
+                   size_t(co) * ci * sizeof(float));
+            memcpy(m->stage.data() + m->out_b + size_t(p) * co, H(m, std::string("out.2.conv_") + kPlane[p] + ".bias").data(),
+                   co * sizeof(float));
+        }
+    }
+    S3D_TRY(upload(m->wbuf, m->stage.data(), m->stage.size() * sizeof(float)));
+    m->stage.clear(); m->stage.shrink_to_fit();
+    m->packed = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------ forward
+struct Fwd {
+    s3d_unet* m;
+    int B;
+    hipStream_t st;
+    const float* film;      // [B][film_total]
+    Arena& ar() { return m->arena; }
+
+    Tri alloc_tri(int C, const Geo& g) {
+        Tri t; t.C = C; t.g = g;
+        for (int p = 0; p < 3; ++p) t.p[p] = ar().alloc<float>(size_t(B) * g.h[p] * g.w[p] * C);
+        return t;
+    }
+    GnPartials alloc_stats() { return GnPartials{ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64)}; }
+
+    // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and
+    // the rank-1 tables its epilogue needs.  Returns activated tensor; fills rrow/rcol table pointers.
+    int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
+                 const float* rcol[3]) {
+        const bool measuring = ar().measuring;
+        GnPartials stats = alloc_stats();
+        y = alloc_tri(x.C, x.g);
+        ActArgs aa;
+        for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(nw.gamma[p]); aa.beta[p] = m->dev(nw.beta[p]); }
+        aa.film = film_ptr; aa.film_stride = m->film_total;
+        const bool roll = cw && cw->rollout;
+        MeanPartials mp; MeanVecs mv;
+        float* tab_row[3]; float* tab_col[3];
+        for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
+        if (roll) {
+            for (int p = 0; p < 3; ++p) {
+                const int h = x.g.h[p], w = x.g.w[p];
+                const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
+                mp.rowpart[p] = ar().alloc<float>(size_t(B) * ntc * h * x.C);
+                mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * x.C);
+                mv.rowmean[p] = ar().alloc<float>(size_t(B) * h * x.C);
+                mv.colmean[p] = ar().alloc<float>(size_t(B) * w * x.C);
+                tab_row[p] = ar().alloc<float>(size_t(B) * h * 4 * cw->cout);
+                tab_col[p] = ar().alloc<float>(size_t(B) * w * 4 * cw->cout);
+                rrow[p] = tab_row[p]; rcol[p] = tab_col[p];
+            }
+        }
+        if (measuring) return 0;
+        S3D_TRY(launch_gn_partials(x, B, stats, st));
+        S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st));
+        if (!roll) return 0;
+        S3D_TRY(launch_means_finalize(x.g, x.C, B, mp, mv, st));
+        // rank-1 rollout terms: six 1-D convolutions of the mean vectors, all in one launch
+        ConvArgs ca; memset(&ca, 0, sizeof ca);
+        ca.B = B; ca.cin = x.C; ca.cout = 4 * cw->cout; ca.njobs = 6;
+        // row-varying / column-varying vector of each plane
+        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
+        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
+        for (int p = 0; p < 3; ++p) {
+            ConvJob& jr = ca.job[2 * p];
+            jr.in = rowvec[p]; jr.wgt = m->dev(cw->rrow[p]); jr.out = tab_row[p]; jr.h = 1; jr.w = x.g.h[p];
+            ConvJob& jc = ca.job[2 * p + 1];
+            jc.in = colvec[p]; jc.wgt = m->dev(cw->rcol[p]); jc.out = tab_col[p]; jc.h = 1; jc.w = x.g.w[p];
+        }
+        S3D_TRY(launch_conv(CONV_1x3_VEC, ca, st));
+        return 0;
+    }
+
+    int conv(const Tri& y, const ConvW& cw, const float* bbias, const float* const rrow[3], const float* const rcol[3],
+             const Tri* res, Tri& out) {
+        out = alloc_tri(cw.cout, y.g);
+        if (ar().measuring) return 0;
+        ConvArgs ca; memset(&ca, 0, sizeof ca);
+        ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
+        for (int p = 0; p < 3; ++p) {
+            ConvJob& J = ca.job[p];
+            J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
+            J.bbias = bbias; J.bbias_stride = m->film_total;
+            J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
+            J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
+        }
+        return launch_conv(cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st);
+    }
+
+    // TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311)
+    int resblock(const ResBlockW& rb, const Tri& x, Tri& out) {
+        const bool ssn = m->cfg.use_scale_shift_norm != 0;
+        const float* film_ptr = film ? film + rb.film_off : nullptr;
+        Tri y1, h1, y2;
+        const float *rr[3], *rc[3];
+        S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc));
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1));     // (!ssn: h = h + emb_out, :298-303)
+        S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc));
+        Tri skip;
+        const Tri* res = &x;
+        if (rb.has_skip) { S3D_TRY(conv(x, rb.skip, nullptr, nullptr, nullptr, nullptr, skip)); res = &skip; }
+        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out));
+        return 0;
+    }
+};
+
+static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st) {
+    const s3d_unet_cfg& c = m->cfg;
+    const int mc = c.model_channels, ted = 4 * mc;
+    Fwd f{m, B, st, nullptr};
+    Arena& ar = m->arena;
+    const bool meas = ar.measuring;
+    ar.reset();
+
+    // emb = time_embed(timestep_embedding(t)) ; all blocks' emb_layers in one stacked linear
+    float* e1 = ar.alloc<float>(size_t(B) * ted);
+    float* emb = ar.alloc<float>(size_t(B) * ted);
+    float* film = ar.alloc<float>(size_t(B) * m->film_total);
+    f.film = film;
+    if (!meas) {
+        S3D_TRY(launch_linear(t, B, mc, m->dev(m->te0_w), m->dev(m->te0_b), ted, e1, 2, 1, st));
+        S3D_TRY(launch_linear(e1, B, ted, m->dev(m->te2_w), m->dev(m->te2_b), ted, emb, 0, 0, st));
+        S3D_TRY(launch_linear(emb, B, ted, m->dev(m->film_w), m->dev(m->film_b), m->film_total, film, 1, 0, st));
+    }
+
+    Geo g0 = Geo::from_hwd(H, W, D);
+    Tri h = f.alloc_tri(c.channel_mult[0] * mc, g0);
+    if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st));
+
+    std::vector<Tri> hs;
+    for (int level = 0; level < c.n_levels; ++level) {
+        if (level != 0) {                                           // TriplaneDownsample2x (:127-145)
+            Tri d = f.alloc_tri(h.C, h.g.half());
+            for (int p = 0; p < 3; ++p)
+                S3D_CHECK(d.g.h[p] > 0 && d.g.w[p] > 0, S3D_ERR_INVALID, "plane too small to downsample (level %d)", level);
+            if (!meas) S3D_TRY(launch_avgpool(h, B, d, st));
+            h = d;
+        }
+        Tri o;
+        S3D_TRY(f.resblock(m->in_blocks[level], h, o));
+        h = o;
+        hs.push_back(o);
+    }
+    for (int oi = 0; oi < c.n_levels; ++oi) {
+        const int level = c.n_levels - 1 - oi;
+        Tri inp;
+        if (oi == 0) { inp = hs.back(); hs.pop_back(); }
+        else {
+            // previous block's output `h` -> TriplaneUpsample2x (:106-124) -> resize to the skip's size when it
+            // differs (:494-499) -> concat [h, skip] (:501-503), written straight into the concat buffer
+            Tri sk = hs.back(); hs.pop_back();
+            inp = f.alloc_tri(h.C + sk.C, sk.g);
+            const Geo up = h.g.twice();
+            for (int p = 0; p < 3; ++p) {
+                const bool same = up.h[p] == sk.g.h[p] && up.w[p] == sk.g.w[p];
+                if (same) {
+                    if (!meas) S3D_TRY(launch_bilinear(h.p[p], B, h.C, h.g.h[p], h.g.w[p], inp.p[p], up.h[p], up.w[p], inp.C, 0, st));
+                } else {
+                    S3D_CHECK(c.is_rollout, S3D_ERR_UNSUPPORTED,
+                              "TriplaneUNetModelSmallRaw has no skip-size resize: plane sizes must be divisible by 2^levels");
+                    float* tmp = ar.alloc<float>(size_t(B) * up.h[p] * up.w[p] * h.C);
+                    if (!meas) {
+                        S3D_TRY(launch_bilinear(h.p[p], B, h.C, h.g.h[p], h.g.w[p], tmp, up.h[p], up.w[p], h.C, 0, st));
+                        S3D_TRY(launch_bilinear(tmp, B, h.C, up.h[p], up.w[p], inp.p[p], sk.g.h[p], sk.g.w[p], inp.C, 0, st));
+                    }
+                }
+                if (!meas) S3D_TRY(launch_copy_slice(sk.p[p], B, sk.C, sk.g.h[p], sk.g.w[p], inp.p[p], inp.C, h.C, st));
+            }
+        }
+        Tri o;
+        S3D_TRY(f.resblock(m->out_blocks[oi], inp, o));
+        h = o;
+        (void)level;
+    }
+    // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
+    GnPartials stats = f.alloc_stats();
+    if (!meas) {
+        S3D_TRY(launch_gn_partials(h, B, stats, st));
+        ActArgs aa;
+        for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
+        aa.film = nullptr; aa.film_stride = 0;
+        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st));
+    }
+    return 0;
+}
+
+}  // namespace s3d
+
+extern "C" {
+
+int s3d_unet_create(const s3d_unet_cfg* cfg, s3d_unet** out) {
+    S3D_CHECK(cfg && out, S3D_ERR_INVALID, "unet_create: null argument");
+    S3D_CHECK(cfg->num_res_blocks == 1, S3D_ERR_UNSUPPORTED,
+              "num_res_blocks=%d: the reference constructor only succeeds for 1 (unet_triplane.py:383-419)", cfg->num_res_blocks);
+    S3D_CHECK(cfg->n_levels >= 1 && cfg->n_levels <= 8, S3D_ERR_INVALID, "channel_mult must have 1..8 entries");
+    S3D_CHECK(cfg->model_channels > 0 && cfg->model_channels % 32 == 0, S3D_ERR_INVALID,
+              "model_channels=%d must be a positive multiple of 32 (GroupNorm32(32, C))", cfg->model_channels);
+    S3D_CHECK(cfg->in_channels > 0 && cfg->out_channels > 0, S3D_ERR_INVALID, "in/out channels must be positive");
+    for (int i = 0; i < cfg->n_levels; ++i) S3D_CHECK(cfg->channel_mult[i] >= 1, S3D_ERR_INVALID, "channel_mult entries must be >= 1");
+    std::unique_ptr<s3d_unet> m(new s3d_unet());
+    m->cfg = *cfg;
+    S3D_TRY(build_specs(m.get()));
+    *out = m.release();
+    return 0;
+}
+
+void s3d_unet_destroy(s3d_unet* m) { delete m; }
+
+int s3d_unet_num_params(const s3d_unet* m) { return m ? int(m->specs.size()) : S3D_ERR_INVALID; }
+
+int s3d_unet_param_info(const s3d_unet* m, int i, const char** name, int64_t shape[4], int* ndim) {
+    S3D_CHECK(m && i >= 0 && i < int(m->specs.size()), S3D_ERR_INVALID, "param_info: index %d out of range", i);
+    const ParamSpec& sp = m->specs[i];
+    if (name) *name = sp.name.c_str();
+    if (ndim) *ndim = int(sp.shape.size());
+    if (shape) for (size_t k = 0; k < sp.shape.size(); ++k) shape[k] = sp.shape[k];
+    return 0;
+}
+
+int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data, const int64_t* shape, int ndim) {
+    S3D_CHECK(m && name && data && shape, S3D_ERR_INVALID, "set_param: null argument");
+    for (const auto& sp : m->specs) {
+        if (sp.name != name) continue;
+        bool ok = int(sp.shape.size()) == ndim;
+        for (int k = 0; ok && k < ndim; ++k) ok = sp.shape[k] == shape[k];
+        S3D_CHECK(ok, S3D_ERR_INVALID, "size mismatch for %s", name);
+        m->host[sp.name].assign(data, data + sp.numel());
+        m->packed = false;
+        return 0;
+    }
+    set_error("unexpected key '%s' in state_dict", name);
+    return S3D_ERR_INVALID;
+}
+
+int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream) {
+    S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "unet_forward: null argument");
+    S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "unet_forward: B,H,W,D must be >= 1");
+    if (!m->packed) S3D_TRY(pack_all(m));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows)
+    m->arena.measuring = true;
+    m->arena.high = 0;
+    int rc = run_forward(m, x, t, B, H, W, D, out, st);
+    m->arena.measuring = false;
+    if (rc) return rc;
+    if (m->arena.high > m->arena.buf.cap) {
+        S3D_HIP(hipStreamSynchronize(st));
+        S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+    }
+    return run_forward(m, x, t, B, H, W, D, out, st);
+}
+
+}  // extern "C"

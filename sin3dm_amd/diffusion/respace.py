@@ -1,0 +1,94 @@
+"""Timestep respacing (reference: src/diffusion/respace.py)."""
+from __future__ import annotations
+
+import numpy as np
+import torch as th
+
+from .gaussian_diffusion import GaussianDiffusion
+
+
+def space_timesteps(num_timesteps, section_counts):
+    """Which original steps to keep (reference: src/diffusion/respace.py:7-60).
+
+    `section_counts`: "ddimN" (fixed integer stride giving exactly N steps), a comma-separated string or a
+    list of per-section counts; each equally sized section is covered by evenly spaced, rounded indices
+    that include its first and last step.
+    """
+    if isinstance(section_counts, str):
+        if section_counts.startswith("ddim"):
+            want = int(section_counts[4:])
+            for stride in range(1, num_timesteps):
+                steps = range(0, num_timesteps, stride)
+                if len(steps) == want:
+                    return set(steps)
+            raise ValueError(f"cannot create exactly {num_timesteps} steps with an integer stride")
+        section_counts = [int(x) for x in section_counts.split(",")]
+    n_sec = len(section_counts)
+    base, extra = divmod(num_timesteps, n_sec)
+    kept, start = [], 0
+    for i, count in enumerate(section_counts):
+        size = base + (1 if i < extra else 0)
+        if size < count:
+            raise ValueError(f"cannot divide section of {size} steps into {count}")
+        stride = 1 if count <= 1 else (size - 1) / (count - 1)
+        pos = 0.0
+        for _ in range(count):
+            kept.append(start + round(pos))
+            pos += stride
+        start += size
+    return set(kept)
+
+
+class SpacedDiffusion(GaussianDiffusion):
+    """A diffusion process over a subset of the base steps (reference: src/diffusion/respace.py:63-113).
+
+    New betas are 1 - abar_i / abar_(previous kept) so the kept marginals are unchanged; the model still
+    sees ORIGINAL step indices through `_WrappedModel`.
+    """
+
+    def __init__(self, use_timesteps, **kwargs):
+        self.use_timesteps = set(use_timesteps)
+        self.original_num_steps = len(kwargs["betas"])
+        base = GaussianDiffusion(**kwargs)
+        self.timestep_map = [i for i in range(self.original_num_steps) if i in self.use_timesteps]
+        last, new_betas = 1.0, []
+        for i in self.timestep_map:
+            new_betas.append(1 - base.alphas_cumprod[i] / last)
+            last = base.alphas_cumprod[i]
+        kwargs["betas"] = np.array(new_betas)
+        super().__init__(**kwargs)
+
+    def _wrap_model(self, model):
+        if isinstance(model, _WrappedModel):
+            return model
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+
+    def _step(self, mode, model, *args, **kwargs):
+        return super()._step(mode, self._wrap_model(model), *args, **kwargs)
+
+    def _scale_timesteps(self, t):
+        return t          # scaling happens inside the wrapped model
+
+
+class _WrappedModel:
+    """Maps respaced indices back to original ones before calling the denoiser (:116-128)."""
+
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+        self.model = model
+        self.timestep_map = timestep_map
+        self.rescale_timesteps = rescale_timesteps
+        self.original_num_steps = original_num_steps
+        self._maps = {}
+
+    def parameters(self):
+        return self.model.parameters()
+
+    def __call__(self, x, ts, **kwargs):
+        key = (str(ts.device), ts.dtype)
+        m = self._maps.get(key)
+        if m is None:
+            m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        new_ts = m[ts]
+        if self.rescale_timesteps:
+            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+        return self.model(x, new_ts, **kwargs)

@@ -1,0 +1,153 @@
+"""TriplaneUNetModelSmall / TriplaneUNetModelSmallRaw with the reference's constructor, parameter names
+and forward signature (src/diffusion/unet_triplane.py:315-510, 513-702) — executed by libsin3dm_hip.so.
+
+The module owns ordinary nn.Parameters under the reference's state_dict names, so `load_state_dict`,
+`.to(dev)`, `.eval()`, `.parameters()` and checkpoints written by the reference all work.  Their values are
+mirrored into the HIP handle (repacked to the kernels' layouts) whenever they change.  Inference only:
+the forward is not differentiable (sampling runs under no_grad in the reference, gaussian_diffusion.py:525).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch as th
+import torch.nn as nn
+
+from .. import _lib
+from ..testing import unet_param_shapes
+
+
+class _Node(nn.Module):
+    """Anonymous container used to rebuild the reference's dotted parameter names."""
+
+
+def _register(root, dotted, tensor):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+class _TriplaneUNetBase(nn.Module):
+    _ROLLOUT = True
+
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks=1, dropout=0,
+                 channel_mult=(1, 2), use_checkpoint=False, use_fp16=False, use_scale_shift_norm=False):
+        super().__init__()
+        if isinstance(channel_mult, str):
+            channel_mult = tuple(int(c) for c in channel_mult.split(","))
+        if use_fp16:
+            # the reference's fp16 path cannot run either: in_conv stays fp32 while x is cast to fp16
+            # (unet_triplane.py:479, fp16_util only converts input_blocks/output_blocks)
+            raise NotImplementedError("use_fp16 is not runnable in the reference and is not implemented here")
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.dropout = dropout              # the reference has its Dropout commented out (:242)
+        self.channel_mult = tuple(channel_mult)
+        self.use_checkpoint = use_checkpoint
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.dtype = th.float32
+
+        shapes = unet_param_shapes(in_channels, model_channels, out_channels, num_res_blocks, self.channel_mult,
+                                   use_scale_shift_norm, self._ROLLOUT)
+        self._param_names = list(shapes)
+        gen = th.Generator().manual_seed(0)
+        for name, shape in shapes.items():
+            _register(self, name, self._init_tensor(name, shape, gen))
+
+        self._handle = None
+        self._synced = None
+
+    @staticmethod
+    def _init_tensor(name, shape, gen):
+        """Default initialisation in the spirit of the reference's modules: uniform(+-1/sqrt(fan_in)) for
+        conv/linear, ones/zeros for norms, zeros for the zero_module'd convs (out_layers.2, out.2)."""
+        leaf = name.rsplit(".", 1)[-1]
+        if ".norm_" in name:
+            return th.ones(shape) if leaf == "weight" else th.zeros(shape)
+        if ".out_layers.2." in name or name.startswith("out.2."):
+            return th.zeros(shape)
+        fan_in = 1
+        wshape = shape if leaf == "weight" else None
+        if wshape is not None:
+            for d in wshape[1:]:
+                fan_in *= d
+            bound = (1.0 / fan_in) ** 0.5
+        else:
+            bound = 0.05
+        return (th.rand(shape, generator=gen) * 2 - 1) * bound
+
+    # ------------------------------------------------------------------ HIP handle
+    def _cfg(self):
+        cm = list(self.channel_mult) + [0] * (8 - len(self.channel_mult))
+        return _lib.UNetCfg(self.in_channels, self.model_channels, self.out_channels, self.num_res_blocks,
+                            len(self.channel_mult), (C.c_int32 * 8)(*cm), int(bool(self.use_scale_shift_norm)),
+                            int(self._ROLLOUT))
+
+    def _ensure_handle(self):
+        lib = _lib.load()
+        if self._handle is None:
+            h = C.c_void_p()
+            cfg = self._cfg()
+            _lib.check(lib.s3d_unet_create(C.byref(cfg), C.byref(h)))
+            self._handle = h
+        params = dict(self.named_parameters())
+        stamp = tuple((p.data_ptr(), p._version) for p in params.values())
+        if stamp != self._synced:
+            for name in self._param_names:
+                host = params[name].detach().to("cpu", th.float32).contiguous()
+                shape = (C.c_int64 * host.dim())(*host.shape)
+                _lib.check(lib.s3d_unet_set_param(self._handle, name.encode(), C.c_void_p(host.data_ptr()), shape,
+                                                  host.dim()))
+            self._synced = stamp
+        return lib
+
+    def __del__(self):
+        h, self._handle = getattr(self, "_handle", None), None
+        if h is not None:
+            try:
+                _lib.load().s3d_unet_destroy(h)
+            except Exception:
+                pass
+
+    def convert_to_fp16(self):
+        raise NotImplementedError("fp16 is not runnable in the reference (see __init__)")
+
+    def convert_to_fp32(self):
+        pass
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, timesteps, H=None, W=None, D=None, y=None):
+        """x: [N, C, H+D, W+D] composed triplane, timesteps: [N]; returns a tensor of x's shape
+        (reference: unet_triplane.py:465-510)."""
+        assert H is not None and W is not None and D is not None
+        _lib.require_gpu(x)
+        h = x if y is None else th.cat([x, y], dim=1)
+        h = h.contiguous().float()
+        B, Cin, Hc, Wc = h.shape
+        assert Cin == self.in_channels, f"expected {self.in_channels} input channels, got {Cin}"
+        assert Hc == H + D and Wc == W + D, f"composed map {tuple(h.shape[-2:])} != (H+D, W+D) = {(H + D, W + D)}"
+        assert timesteps.shape == (B,)
+        lib = self._ensure_handle()
+        t = timesteps.to(device=h.device, dtype=th.float32).contiguous()
+        out = th.empty((B, self.out_channels, Hc, Wc), device=h.device, dtype=th.float32)
+        with th.cuda.device(h.device):
+            _lib.check(lib.s3d_unet_forward(self._handle, _lib.ptr(h), _lib.ptr(t), B, int(H), int(W), int(D),
+                                            _lib.ptr(out), _lib.stream_ptr()))
+        assert out.shape == x.shape or y is not None
+        return out
+
+
+class TriplaneUNetModelSmall(_TriplaneUNetBase):
+    """Triplane UNet with rollout convolutions (reference: unet_triplane.py:315-510)."""
+    _ROLLOUT = True
+
+
+class TriplaneUNetModelSmallRaw(_TriplaneUNetBase):
+    """Same topology without rollout and without the skip-size resize (reference: :513-702)."""
+    _ROLLOUT = False

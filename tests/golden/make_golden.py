@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference (PyTorch-CPU).
+
+Runs only in the build container, where /root/reference exists; the reference never travels to
+the GPU box.  What is committed is data only: inputs + the reference's outputs.
+Weights are NOT stored: they are regenerated bit-identically from sin3dm_amd.testing
+(numpy PCG64 keyed by parameter name), and this script asserts that the name->shape manifest it
+uses equals the reference modules' own state_dict.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import contextlib
+import io
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF_SRC = os.environ.get("SIN3DM_REFERENCE", "/root/reference") + "/src"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF_SRC)
+
+from sin3dm_amd import testing as T  # noqa: E402
+
+torch.set_num_threads(1)           # 1-thread oneDNN: the most reproducible reference arithmetic
+torch.set_grad_enabled(False)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def rnd(shape, seed):
+    return torch.from_numpy(T.synthetic_noise(shape, seed))
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}.npz: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays")
+
+
+def planes(B, C, H, W, D, seed):
+    return (rnd((B, C, H, W), seed), rnd((B, C, H, D), seed + 1), rnd((B, C, W, D), seed + 2))
+
+
+def load_synth(module, shapes, seed, prefix=""):
+    sd = T.synthetic_state_dict(shapes, seed)
+    ref_sd = module.state_dict()
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)} if prefix else sd
+    assert set(sub) == set(ref_sd), (sorted(set(sub) ^ set(ref_sd))[:8])
+    for k in sub:
+        assert tuple(sub[k].shape) == tuple(ref_sd[k].shape), k
+    module.load_state_dict(sub)
+    module.eval()
+    return sd
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_schedules():
+    from diffusion.script_util import create_gaussian_diffusion
+    out = {}
+    for tag, resp in (("full", ""), ("r100", "100"), ("r10", "10"), ("ddim50", "ddim50"), ("r20", "20")):
+        d = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True,
+                                      timestep_respacing=resp)
+        for f in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                  "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                  "posterior_mean_coef1", "posterior_mean_coef2", "sqrt_alphas_cumprod",
+                  "sqrt_one_minus_alphas_cumprod"):
+            out[f"{tag}.{f}"] = getattr(d, f)
+        out[f"{tag}.timestep_map"] = np.asarray(d.timestep_map, dtype=np.int64)
+    save("schedules", **out)
+
+
+def gen_temb():
+    from diffusion.nn import timestep_embedding
+    out = {}
+    t = torch.tensor([0, 1, 500, 999], dtype=torch.int64)
+    out["t"] = t
+    for mc in (32, 64):
+        out[f"emb{mc}"] = timestep_embedding(t, mc)
+    save("temb", **out)
+
+
+def gen_leaves():
+    import diffusion.unet_triplane as U
+    out = {}
+    for tag, (B, C, H, W, D) in (("a", (2, 32, 10, 14, 6)), ("b", (1, 64, 9, 13, 7))):
+        fm = planes(B, C, H, W, D, 100)
+        out[f"{tag}.in_xy"], out[f"{tag}.in_xz"], out[f"{tag}.in_yz"] = fm
+        # TriplaneNorm + SiLU  (unet_triplane.py:63-95)
+        m = torch.nn.Sequential(U.TriplaneNorm(C), U.TriplaneSiLU())
+        shapes = {f"0.norm_{p}.{l}": (C,) for p in T.PLANES for l in ("weight", "bias")}
+        load_synth(m, shapes, 1)
+        for p, y in zip(T.PLANES, m(fm)):
+            out[f"{tag}.normsilu_{p}"] = y
+        # TriplaneConv 3x3 rollout / 3x3 plain / 1x1 (unet_triplane.py:21-60)
+        for name, k, roll, cout in (("conv3r", 3, True, 48), ("conv3", 3, False, 48), ("conv1", 1, False, 40)):
+            m = U.TriplaneConv(C, cout, k, padding=k // 2, is_rollout=roll)
+            shapes = {}
+            for p in T.PLANES:
+                shapes[f"conv_{p}.weight"] = (cout, C * 3 if roll else C, k, k)
+                shapes[f"conv_{p}.bias"] = (cout,)
+            load_synth(m, shapes, 2)
+            for p, y in zip(T.PLANES, m(fm)):
+                out[f"{tag}.{name}_{p}"] = y
+        for p, y in zip(T.PLANES, U.TriplaneDownsample2x()(fm)):
+            out[f"{tag}.down_{p}"] = y
+        for p, y in zip(T.PLANES, U.TriplaneUpsample2x()(fm)):
+            out[f"{tag}.up_{p}"] = y
+        # size-targeted bilinear resize (unet_triplane.py:494-499): to (2H+1, 2W+1) etc.
+        tgt = {"xy": (2 * H + 1, 2 * W + 1), "xz": (2 * H + 1, 2 * D + 1), "yz": (2 * W + 1, 2 * D + 1)}
+        for p, x in zip(T.PLANES, fm):
+            out[f"{tag}.resize_{p}"] = torch.nn.functional.interpolate(x, size=tgt[p], mode="bilinear",
+                                                                     align_corners=False)
+    save("leaves", **out)
+
+
+def gen_resblock():
+    import diffusion.unet_triplane as U
+    out = {}
+    B, H, W, D = 2, 10, 14, 6
+    for tag, (C, Cout, ssn) in (("same", (32, 32, True)), ("skip", (32, 64, True)), ("add", (32, 32, False))):
+        m = U.TriplaneResBlock(C, 128, 0, out_channels=Cout, use_scale_shift_norm=ssn)
+        full = T.unet_param_shapes(model_channels=32, use_scale_shift_norm=ssn)
+        # borrow the names of an equivalent block
+        shapes = {}
+        for k, v in m.state_dict().items():
+            shapes[k] = tuple(v.shape)
+        load_synth(m, shapes, 3)
+        fm = planes(B, C, H, W, D, 200)
+        emb = rnd((B, 128), 210)
+        out[f"{tag}.in_xy"], out[f"{tag}.in_xz"], out[f"{tag}.in_yz"] = fm
+        out[f"{tag}.emb"] = emb
+        for p, y in zip(T.PLANES, m(fm, emb)):
+            out[f"{tag}.out_{p}"] = y
+    save("resblock", **out)
+
+
+def make_unet(mc, raw=False, ssn=True, channel_mult="1,2"):
+    from diffusion.script_util import create_model_and_diffusion_from_args
+    args = SimpleNamespace(learn_sigma=False, steps=1000, noise_schedule="linear", timestep_respacing="",
+                           use_kl=False, predict_xstart=True, rescale_timesteps=False,
+                           rescale_learned_sigmas=False, in_channels=12, model_channels=mc, out_channels=12,
+                           num_res_blocks=1, dropout=0, channel_mult=channel_mult, use_checkpoint=False,
+                           use_fp16=False, use_scale_shift_norm=ssn,
+                           diff_net_type="unet_raw" if raw else "unet_small")
+    model, _ = quiet(create_model_and_diffusion_from_args, args)
+    shapes = T.unet_param_shapes(model_channels=mc, rollout=not raw, use_scale_shift_norm=ssn,
+                                 channel_mult=channel_mult)
+    load_synth(model, shapes, 0)
+    return model
+
+
+def make_diffusion(resp):
+    from diffusion.script_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True,
+                                     timestep_respacing=resp)
+
+
+def gen_unet():
+    out = {}
+    cases = (("mc32_a", 32, False, (2, 10, 14, 6), True, "1,2"),
+             ("mc32_odd", 32, False, (2, 9, 13, 7), True, "1,2"),
+             ("mc64_b", 64, False, (1, 12, 8, 10), True, "1,2"),
+             ("mc32_raw", 32, True, (2, 10, 14, 6), True, "1,2"),
+             ("mc32_add", 32, False, (1, 10, 14, 6), False, "1,2"),
+             ("mc32_3lev", 32, False, (1, 12, 16, 8), True, "1,2,2"))
+    for tag, mc, raw, (B, H, W, D), ssn, cm in cases:
+        model = make_unet(mc, raw, ssn, cm)
+        x = rnd((B, 12, H + D, W + D), 300)
+        t = torch.tensor([999, 17][:B], dtype=torch.int64)
+        y = model(x, t, H=H, W=W, D=D)
+        out[f"{tag}.x"], out[f"{tag}.t"], out[f"{tag}.y"] = x, t, y
+        out[f"{tag}.hwd"] = np.asarray([H, W, D])
+    save("unet_fwd", **out)
+
+    # name -> shape manifest for mc in {32, 64, 128} straight from the reference modules
+    man = {}
+    for mc in (32, 64, 128):
+        from diffusion.unet_triplane import TriplaneUNetModelSmall
+        m = quiet(TriplaneUNetModelSmall, 12, mc, 12, use_scale_shift_norm=True)
+        for k, v in m.state_dict().items():
+            man[f"mc{mc}/{k}"] = np.asarray(v.shape, dtype=np.int64)
+        mine = T.unet_param_shapes(model_channels=mc)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == dict(mine)
+    save("unet_manifest", **man)
+
+
+def gen_sampler():
+    out = {}
+    model = make_unet(32)
+    H, W, D = 10, 14, 6
+    kw = dict(H=H, W=W, D=D)
+    B = 2
+    shape = (B, 12, H + D, W + D)
+    # single steps with stored noise: patch randn_like so the reference consumes OUR eps
+    import diffusion.gaussian_diffusion as gd
+    for resp_tag, resp in (("full", ""), ("r20", "20")):
+        diff = make_diffusion(resp)
+        Tn = diff.num_timesteps
+        for ti in (Tn - 1, 1, 0):
+            x = rnd(shape, 400 + ti)
+            eps = rnd(shape, 500 + ti)
+            t = torch.tensor([ti] * B)
+            orig = gd.th.randn_like
+            gd.th.randn_like = lambda z: eps.clone()
+            try:
+                o1 = diff.p_sample(model, x, t, model_kwargs=kw)
+                o2 = diff.ddim_sample(model, x, t, model_kwargs=kw)
+                o3 = diff.ddim_sample(model, x, t, model_kwargs=kw, eta=0.7)
+            finally:
+                gd.th.randn_like = orig
+            pre = f"{resp_tag}.t{ti}"
+            out[pre + ".x"], out[pre + ".eps"] = x, eps
+            out[pre + ".p_sample"], out[pre + ".p_xstart"] = o1["sample"], o1["pred_xstart"]
+            out[pre + ".ddim_sample"], out[pre + ".ddim_xstart"] = o2["sample"], o2["pred_xstart"]
+            out[pre + ".ddim_eta_sample"] = o3["sample"]
+    out["hwd"] = np.asarray([H, W, D])
+    save("sampler_steps", **out)
+
+    # trajectories: store x_T and every eps explicitly (RNG streams are not portable across torch versions)
+    tr = {}
+    for tag, resp, ddim in (("ddim10", "10", True), ("ddpm20", "20", False)):
+        diff = make_diffusion(resp)
+        Tn = diff.num_timesteps
+        xT = rnd(shape, 600)
+        epss = [rnd(shape, 700 + i) for i in range(Tn)]
+        it = iter(epss)
+        orig = gd.th.randn_like
+        gd.th.randn_like = lambda z: next(it).clone()
+        try:
+            fn = diff.ddim_sample_loop_progressive if ddim else diff.p_sample_loop_progressive
+            inter = []
+            for k, o in enumerate(fn(model, shape, noise=xT.clone(), model_kwargs=kw)):
+                if k % 5 == 4 or k == Tn - 1:
+                    inter.append(o["sample"].clone())
+                final = o["sample"]
+        finally:
+            gd.th.randn_like = orig
+        tr[f"{tag}.xT"] = xT
+        tr[f"{tag}.eps"] = torch.stack(epss)
+        tr[f"{tag}.inter"] = torch.stack(inter)
+        tr[f"{tag}.final"] = final
+        corner = final[..., H:, W:]
+        assert float(corner.abs().max()) == 0.0, "DxD corner must end at exactly 0"
+    tr["hwd"] = np.asarray([H, W, D])
+    save("trajectories", **tr)
+
+
+def gen_decoder():
+    from encoding.networks import AutoEncoderGroupSkip
+    from encoding.blocks import TriplaneGroupResnetBlock
+    out = {}
+    for tag, (up, hid, H, W, D) in (("small", (16, 32, 10, 14, 6)), ("wide", (64, 256, 9, 8, 11))):
+        net = AutoEncoderGroupSkip(4, 8, up, hid, 4)
+        shapes = T.ae_param_shapes(4, 8, up, hid, 4)
+        sd = T.synthetic_state_dict(shapes, 5)
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and all(k.startswith(("geo_encoder", "tex_encoder", "aabb")) for k in missing), missing
+        net.eval()
+        fm = [0.8 * torch.tanh(x) for x in planes(1, 12, H, W, D, 800)]
+        aabb = torch.tensor([-0.7, -1.0, -0.45, 0.7, 1.0, 0.45])
+        g = np.random.Generator(np.random.PCG64(900))
+        pts = torch.from_numpy(g.uniform(-1.15, 1.15, size=(257, 3)).astype(np.float32)) * aabb[3:]
+        y = net.decode(pts, fm, aabb=aabb)
+        y_default = net.decode(pts[:33], fm)            # module buffer aabb = [-1,-1,-1,1,1,1]
+        out[f"{tag}.xy"], out[f"{tag}.xz"], out[f"{tag}.yz"] = fm
+        out[f"{tag}.aabb"], out[f"{tag}.pts"], out[f"{tag}.out"] = aabb, pts, y
+        out[f"{tag}.out_default_aabb"] = y_default
+        geo = net.geo_convs([f[:, :4] for f in fm])
+        tex = net.tex_convs([f[:, 4:] for f in fm])
+        for p, a, b in zip(T.PLANES, geo, tex):
+            out[f"{tag}.geo_{p}"], out[f"{tag}.tex_{p}"] = a, b
+        out[f"{tag}.cfg"] = np.asarray([up, hid, H, W, D])
+    save("decoder", **out)
+
+
+def gen_compose():
+    from utils.triplane_util import compose_featmaps, decompose_featmaps
+    fm = planes(2, 3, 5, 7, 4, 950)
+    comp, (H, W, D) = compose_featmaps(*fm)
+    back = decompose_featmaps(comp, (H, W, D))
+    for a, b in zip(fm, back):
+        assert torch.equal(a, b)
+    save("compose", xy=fm[0], xz=fm[1], yz=fm[2], composed=comp, hwd=np.asarray([H, W, D]))
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
+                     ("decoder", gen_decoder), ("compose", gen_compose)):
+        if not only or name in only:
+            fn()

@@ -1,0 +1,160 @@
+"""Pins the C oracle (oracle/sin3dm_oracle.c) against golden vectors captured from the reference.
+
+CPU-only.  Tolerance: 2e-5 relative (max|a-b|/max|b|) per op — fp32 with a different summation
+order than oneDNN; the north_star gate for the HIP path is 1e-3.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr
+from sin3dm_amd import testing as T
+
+TOL = 2e-5
+
+
+def test_schedule_tables(oracle):
+    g = golden("schedules")
+    from sin3dm_amd.diffusion.respace import space_timesteps
+    for tag, resp in (("full", None), ("r100", "100"), ("r10", "10"), ("ddim50", "ddim50"), ("r20", "20")):
+        keep = None if resp is None else space_timesteps(1000, resp)
+        tab, tmap = oracle.schedule_tables(keep)
+        assert np.array_equal(tmap, g[f"{tag}.timestep_map"])
+        for i, row in enumerate(oracle.TABLE_ROWS):
+            np.testing.assert_allclose(tab[i], g[f"{tag}.{row}"], rtol=1e-12, atol=1e-15, err_msg=f"{tag}.{row}")
+
+
+def test_timestep_embedding(oracle):
+    g = golden("temb")
+    for mc in (32, 64):
+        e = oracle.timestep_embedding(g["t"], mc)
+        # cos/sin of arguments up to 999 rad: fp32 argument rounding dominates -> absolute tolerance
+        np.testing.assert_allclose(e, g[f"emb{mc}"], atol=2e-4, rtol=0)
+
+
+@pytest.mark.parametrize("tag,C", [("a", 32), ("b", 64)])
+def test_leaves(oracle, tag, C):
+    g = golden("leaves")
+    fm = [g[f"{tag}.in_{p}"] for p in T.PLANES]
+    shapes = {f"0.norm_{p}.{l}": (C,) for p in T.PLANES for l in ("weight", "bias")}
+    out = oracle.triplane_norm_silu(T.synthetic_state_dict(shapes, 1, as_torch=False), "0", fm)
+    for p, y in zip(T.PLANES, out):
+        assert relerr(y, g[f"{tag}.normsilu_{p}"]) < TOL
+    for name, k, roll, cout in (("conv3r", 3, True, 48), ("conv3", 3, False, 48), ("conv1", 1, False, 40)):
+        shapes = {}
+        for p in T.PLANES:
+            shapes[f"conv_{p}.weight"] = (cout, C * 3 if roll else C, k, k)
+            shapes[f"conv_{p}.bias"] = (cout,)
+        sd = {"c." + k_: T.synthetic_tensor(k_, v, 2) for k_, v in shapes.items()}
+        out = oracle.triplane_conv(sd, "c", fm, cout, k, roll)
+        for p, y in zip(T.PLANES, out):
+            assert relerr(y, g[f"{tag}.{name}_{p}"]) < TOL, (name, p)
+    for p, x in zip(T.PLANES, fm):
+        assert relerr(oracle.avgpool2(x), g[f"{tag}.down_{p}"]) < 1e-6
+        h, w = x.shape[-2:]
+        assert relerr(oracle.bilinear(x, 2 * h, 2 * w), g[f"{tag}.up_{p}"]) < 1e-6
+        assert relerr(oracle.bilinear(x, 2 * h + 1, 2 * w + 1), g[f"{tag}.resize_{p}"]) < 2e-6
+
+
+@pytest.mark.parametrize("tag,C,Cout,ssn", [("same", 32, 32, True), ("skip", 32, 64, True), ("add", 32, 32, False)])
+def test_resblock(oracle, tag, C, Cout, ssn):
+    g = golden("resblock")
+    full = T.unet_param_shapes(model_channels=32, use_scale_shift_norm=ssn)
+    # the generator named the block's tensors by its own state_dict keys
+    pre = "input_blocks.0.0." if C == Cout else "input_blocks.1.1."
+    shapes = {k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}
+    sd = {"b." + k: T.synthetic_tensor(k, v, 3) for k, v in shapes.items()}
+    fm = [g[f"{tag}.in_{p}"] for p in T.PLANES]
+    out = oracle.triplane_resblock(sd, "b", fm, g[f"{tag}.emb"], Cout, ssn)
+    for p, y in zip(T.PLANES, out):
+        assert relerr(y, g[f"{tag}.out_{p}"]) < TOL
+
+
+UNET_CASES = [("mc32_a", 32, False, True, (1, 2)), ("mc32_odd", 32, False, True, (1, 2)),
+              ("mc64_b", 64, False, True, (1, 2)), ("mc32_raw", 32, True, True, (1, 2)),
+              ("mc32_add", 32, False, False, (1, 2)), ("mc32_3lev", 32, False, True, (1, 2, 2))]
+
+
+@pytest.mark.parametrize("tag,mc,raw,ssn,cm", UNET_CASES)
+def test_unet_forward(oracle, tag, mc, raw, ssn, cm):
+    g = golden("unet_fwd")
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc, rollout=not raw, use_scale_shift_norm=ssn,
+                                                    channel_mult=cm), 0, as_torch=False)
+    H, W, D = (int(v) for v in g[f"{tag}.hwd"])
+    y = oracle.unet_forward(sd, g[f"{tag}.x"], g[f"{tag}.t"], H, W, D, mc, cm, ssn, not raw)
+    assert relerr(y, g[f"{tag}.y"]) < 5e-5
+    assert np.all(y[..., H:, W:] == 0)
+
+
+def test_manifest_matches_reference():
+    g = golden("unet_manifest")
+    for mc in (32, 64, 128):
+        mine = T.unet_param_shapes(model_channels=mc)
+        ref = {k.split("/", 1)[1]: tuple(int(i) for i in g[k]) for k in g.files if k.startswith(f"mc{mc}/")}
+        assert ref == dict(mine)
+
+
+def test_sampler_updates(oracle):
+    """p_sample / ddim_sample element-wise updates, given the oracle's own UNet output."""
+    g = golden("sampler_steps")
+    from sin3dm_amd.diffusion.respace import space_timesteps
+    H, W, D = (int(v) for v in g["hwd"])
+    sd = oracle.Params(T.synthetic_state_dict(T.unet_param_shapes(model_channels=32), 0, as_torch=False))
+    for tag, resp in (("full", None), ("r20", "20")):
+        tab, tmap = oracle.schedule_tables(None if resp is None else space_timesteps(1000, resp))
+        Tn = tab.shape[1]
+        for ti in (Tn - 1, 1, 0):
+            pre = f"{tag}.t{ti}"
+            x, eps = g[pre + ".x"], g[pre + ".eps"]
+            mo = oracle.unet_forward(sd, x, [tmap[ti]] * x.shape[0], H, W, D, 32)
+            s, p = oracle.p_sample_update(mo, x, eps, tab, ti)
+            assert relerr(s, g[pre + ".p_sample"]) < 5e-5 and relerr(p, g[pre + ".p_xstart"]) < 5e-5
+            s, p = oracle.ddim_update(mo, x, eps, tab, ti)
+            assert relerr(s, g[pre + ".ddim_sample"]) < 5e-5 and relerr(p, g[pre + ".ddim_xstart"]) < 5e-5
+            s, _ = oracle.ddim_update(mo, x, eps, tab, ti, eta=0.7)
+            assert relerr(s, g[pre + ".ddim_eta_sample"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag,resp,ddim", [("ddim10", "10", True), ("ddpm20", "20", False)])
+def test_trajectories(oracle, tag, resp, ddim):
+    g = golden("trajectories")
+    from sin3dm_amd.diffusion.respace import space_timesteps
+    H, W, D = (int(v) for v in g["hwd"])
+    sd = oracle.Params(T.synthetic_state_dict(T.unet_param_shapes(model_channels=32), 0, as_torch=False))
+    tab, tmap = oracle.schedule_tables(space_timesteps(1000, resp))
+    Tn = tab.shape[1]
+    x = g[f"{tag}.xT"].copy()
+    inter = []
+    for k, ti in enumerate(range(Tn - 1, -1, -1)):
+        mo = oracle.unet_forward(sd, x, [tmap[ti]] * x.shape[0], H, W, D, 32)
+        upd = oracle.ddim_update if ddim else oracle.p_sample_update
+        x, _ = upd(mo, x, g[f"{tag}.eps"][k], tab, ti)
+        if k % 5 == 4 or k == Tn - 1:
+            inter.append(x.copy())
+    assert relerr(x, g[f"{tag}.final"]) < 2e-4
+    assert relerr(np.stack(inter), g[f"{tag}.inter"]) < 2e-4
+    assert np.all(x[..., H:, W:] == 0)
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_decoder(oracle, tag):
+    g = golden("decoder")
+    up, hid, H, W, D = (int(v) for v in g[f"{tag}.cfg"])
+    sd = oracle.Params(T.synthetic_state_dict(T.ae_param_shapes(4, 8, up, hid, 4), 5, as_torch=False))
+    fm = [g[f"{tag}.{p}"] for p in T.PLANES]
+    geo = oracle.ae_plane_block(sd, "geo_convs", [f[:, :4] for f in fm], up)
+    tex = oracle.ae_plane_block(sd, "tex_convs", [f[:, 4:] for f in fm], up)
+    for p, a, b in zip(T.PLANES, geo, tex):
+        assert relerr(a, g[f"{tag}.geo_{p}"]) < TOL and relerr(b, g[f"{tag}.tex_{p}"]) < TOL
+    out = oracle.ae_decode(sd, g[f"{tag}.pts"], *fm, g[f"{tag}.aabb"], 4, 8, up, hid, 4)
+    assert relerr(out, g[f"{tag}.out"]) < 5e-5
+    out = oracle.ae_decode(sd, g[f"{tag}.pts"][:33], *fm, np.array([-1, -1, -1, 1, 1, 1], np.float32), 4, 8, up, hid, 4)
+    assert relerr(out, g[f"{tag}.out_default_aabb"]) < 5e-5
+
+
+def test_compose(oracle):
+    g = golden("compose")
+    H, W, D = (int(v) for v in g["hwd"])
+    comp = oracle.compose(g["xy"], g["xz"], g["yz"])
+    assert np.array_equal(comp, g["composed"])
+    for a, b in zip(oracle.decompose(comp, H, W, D), (g["xy"], g["xz"], g["yz"])):
+        assert np.array_equal(a, b)
