@@ -76,6 +76,19 @@ S3D_API int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data,
 S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D,
                      float* out, void* stream);
 
+/* Live kernel timing for bench.py's roofline line: HIP events are recorded on `stream` around every
+ * MFMA convolution launch of each `every`-th forward (0 = off).  s3d_unet_profile_read waits for the
+ * recorded events, ADDS their durations to `out` (caller zero-initialises) and recycles them.
+ * flops = executed algorithmic flops of the launches, 2*taps*cin*cout*pixels. */
+typedef struct {
+    double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */
+    double flops[3];
+    int64_t launches[3];
+    int64_t forwards;      /* forwards that were instrumented */
+} s3d_profile;
+S3D_API int s3d_unet_profile(s3d_unet* m, int every);
+S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
+
 /* ------------------------------------------------------------------------------------------
  * Sampler update: GaussianDiffusion.p_mean_variance + p_sample / ddim_sample
  *   src/diffusion/gaussian_diffusion.py:233-327, 396-440, 538-600

@@ -1,0 +1,106 @@
+"""PyTorch-CPU functional port of the Sin3DM denoising step.  TEST / BASELINE INFRASTRUCTURE ONLY.
+
+A second CPU restatement next to oracle/sin3dm_oracle.c: it runs the reference's algorithm through the very
+ATen/oneDNN CPU ops the reference itself dispatches to (F.conv2d, F.group_norm, F.avg_pool2d,
+F.interpolate), assembled functionally from a plain state_dict.  bench.py times it as the `cpu_baseline`
+("port": the reference cannot travel to the GPU box) because it is the fastest honest CPU path we have —
+4-5x faster than the plain-C oracle.  Pinned against the golden vectors in tests/test_oracle_golden.py.
+Nothing under sin3dm_amd/ imports this file.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+PLANES = ("xy", "xz", "yz")
+
+
+def timestep_embedding(t, dim):
+    """src/diffusion/nn.py:103-121"""
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def silu(x):
+    return x * torch.sigmoid(x)
+
+
+def tconv(sd, prefix, fm, pad, rollout):
+    """TriplaneConv.forward, src/diffusion/unet_triplane.py:31-60"""
+    xy, xz, yz = fm
+    if rollout:
+        xy_in = torch.cat([xy, yz.mean(-1, keepdim=True).transpose(-1, -2).expand_as(xy),
+                           xz.mean(-1, keepdim=True).expand_as(xy)], 1)
+        xz_in = torch.cat([xz, xy.mean(-1, keepdim=True).expand_as(xz), yz.mean(-2, keepdim=True).expand_as(xz)], 1)
+        yz_in = torch.cat([yz, xy.mean(-2, keepdim=True).transpose(-1, -2).expand_as(yz),
+                           xz.mean(-2, keepdim=True).expand_as(yz)], 1)
+        fm = (xy_in, xz_in, yz_in)
+    return tuple(F.conv2d(x, sd[f"{prefix}.conv_{p}.weight"], sd[f"{prefix}.conv_{p}.bias"], padding=pad)
+                 for p, x in zip(PLANES, fm))
+
+
+def tnorm(sd, prefix, fm):
+    """TriplaneNorm = GroupNorm32(32, C) per plane, src/diffusion/unet_triplane.py:63-84"""
+    return tuple(F.group_norm(x, 32, sd[f"{prefix}.norm_{p}.weight"], sd[f"{prefix}.norm_{p}.bias"], 1e-5)
+                 for p, x in zip(PLANES, fm))
+
+
+def resblock(sd, prefix, fm, emb, ssn, rollout):
+    """TriplaneResBlock._forward, src/diffusion/unet_triplane.py:269-311"""
+    h = tconv(sd, prefix + ".in_layers.2", tuple(silu(x) for x in tnorm(sd, prefix + ".in_layers.0", fm)), 1, rollout)
+    e = F.linear(silu(emb), sd[prefix + ".emb_layers.1.weight"], sd[prefix + ".emb_layers.1.bias"])[..., None, None]
+    if ssn:
+        scale, shift = torch.chunk(e, 2, dim=1)
+        h = tuple(x * (1 + scale) + shift for x in tnorm(sd, prefix + ".out_layers.0", h))
+    else:
+        h = tnorm(sd, prefix + ".out_layers.0", tuple(x + e for x in h))
+    h = tconv(sd, prefix + ".out_layers.2", tuple(silu(x) for x in h), 1, rollout)
+    skip = tconv(sd, prefix + ".skip_connection", fm, 0, False) if prefix + ".skip_connection.conv_xy.weight" in sd else fm
+    return tuple(a + b for a, b in zip(h, skip))
+
+
+def unet_forward(sd, x, t, H, W, D, model_channels, channel_mult=(1, 2), use_scale_shift_norm=True, rollout=True):
+    """TriplaneUNetModelSmall.forward, src/diffusion/unet_triplane.py:465-510"""
+    emb = timestep_embedding(t, model_channels)
+    emb = F.linear(silu(F.linear(emb, sd["time_embed.0.weight"], sd["time_embed.0.bias"])),
+                   sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    fm = (x[..., :H, :W], x[..., :H, W:], x[..., H:, :W].transpose(-1, -2))
+    h = tconv(sd, "in_conv.0", fm, 0, False)
+    hs = []
+    for level in range(len(channel_mult)):
+        if level:
+            h = tuple(F.avg_pool2d(a, 2, 2) for a in h)
+        h = resblock(sd, f"input_blocks.{level}.{0 if level == 0 else 1}", h, emb, use_scale_shift_norm, rollout)
+        hs.append(h)
+    for oi in range(len(channel_mult)):
+        level = len(channel_mult) - 1 - oi
+        if oi == 0:
+            h = hs.pop()
+        else:
+            sk = hs.pop()
+            h = tuple(a if a.shape[2:] == s.shape[2:] else F.interpolate(a, size=s.shape[2:], mode="bilinear", align_corners=False)
+                      for a, s in zip(h, sk))
+            h = tuple(torch.cat([a, s], 1) for a, s in zip(h, sk))
+        h = resblock(sd, f"output_blocks.{oi}.0", h, emb, use_scale_shift_norm, rollout)
+        if level > 0:
+            h = tuple(F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=False) for a in h)
+    xy, xz, yz = tconv(sd, "out.2", tuple(silu(a) for a in tnorm(sd, "out.0", h)), 0, False)
+    out = x.new_zeros(x.shape[0], xy.shape[1], H + D, W + D)
+    out[..., :H, :W], out[..., :H, W:], out[..., H:, :W] = xy, xz, yz.transpose(-1, -2)
+    return out
+
+
+def p_sample_update(model_out, x, eps, tab, t):
+    """p_mean_variance (START_X, FIXED_LARGE, clip) + p_sample, src/diffusion/gaussian_diffusion.py:233-327, 396-440.
+    tab: the float64 [8,T] table of oracle.schedule_tables()."""
+    x0 = model_out.clamp(-1, 1)
+    mean = float(tab[6][t]) * x0 + float(tab[7][t]) * x
+    var = tab[5][1] if t == 0 else tab[0][t]
+    return mean + (0.0 if t == 0 else 1.0) * math.exp(0.5 * math.log(var)) * eps, x0

@@ -35,6 +35,11 @@ class SamplerArgs(C.Structure):
                 ("sample", C.c_void_p), ("pred_xstart", C.c_void_p), ("mean", C.c_void_p)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 3), ("flops", C.c_double * 3), ("launches", C.c_int64 * 3),
+                ("forwards", C.c_int64)]
+
+
 class DecoderCfg(C.Structure):
     _fields_ = [("geo_feat_channels", C.c_int32), ("tex_feat_channels", C.c_int32), ("feat_channel_up", C.c_int32),
                 ("mlp_hidden_channels", C.c_int32), ("mlp_hidden_layers", C.c_int32), ("tex_channels", C.c_int32)]
@@ -52,6 +57,8 @@ SIGNATURES = {
     "s3d_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64p, C.c_int]),
     "s3d_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
+    "s3d_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "s3d_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "s3d_sampler_step": (C.c_int, [C.POINTER(SamplerArgs), C.c_void_p]),
     "s3d_op_triplane_conv": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),

@@ -39,6 +39,10 @@ struct ConvCfg {
     static_assert(32 % TW == 0 || TW % 32 == 0, "an MFMA row block must cover whole tile rows");
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* gf4ptr;      // global address space: global_load, not flat
+__device__ __forceinline__ gf4ptr to_global4(const float* p) { return (gf4ptr)(uintptr_t)p; }
+
 __device__ __forceinline__ int edge_variant(int idx, int n) {
     // which taps of the summed-out axis fall inside the image: 0 interior, 1 first, 2 last, 3 only element
     return n == 1 ? 3 : (idx == 0 ? 1 : (idx == n - 1 ? 2 : 0));
@@ -75,27 +79,28 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) offB[nt] = ((wn * NTW + nt) * 32 + (lane & 31)) * LDP + (lane >> 5) * 4;
 
-    // ---- global -> register staging descriptors (fixed per thread)
-    const float* aSrc[CFG::NA]; int aDst[CFG::NA]; bool aOk[CFG::NA];
+    // ---- global -> register staging descriptors (fixed per thread).  Out-of-image / out-of-range items keep a
+    // valid (clamped) address and are zeroed after the load, so the pipeline below has no divergent control flow.
+    gf4ptr aSrc[CFG::NA]; int aDst[CFG::NA]; bool aOk[CFG::NA];
 #pragma unroll
     for (int it = 0; it < CFG::NA; ++it) {
-        const int idx = it * 256 + tid;
+        const int idx = min(it * 256 + tid, CFG::A_ITEMS - 1);      // tail threads duplicate the last item
         const int pix = idx >> 3, q = idx & 7;
         const int gy = ty0 + pix / HW - KH / 2, gx = tx0 + pix % HW - KW / 2;
-        aOk[it] = idx < CFG::A_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        aDst[it] = idx < CFG::A_ITEMS ? pix * LDP + q * 4 : -1;
-        aSrc[it] = J.in + ((size_t(b) * h + (aOk[it] ? gy : 0)) * w + (aOk[it] ? gx : 0)) * cin + q * 4;
+        aOk[it] = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        aDst[it] = pix * LDP + q * 4;
+        aSrc[it] = to_global4(J.in + ((size_t(b) * h + (aOk[it] ? gy : 0)) * w + (aOk[it] ? gx : 0)) * cin + q * 4);
     }
-    const float* bSrc[CFG::NB]; int bDst[CFG::NB]; bool bOk[CFG::NB];
+    gf4ptr bSrc[CFG::NB]; int bDst[CFG::NB]; bool bOk[CFG::NB];
 #pragma unroll
     for (int it = 0; it < CFG::NB; ++it) {
-        const int idx = it * 256 + tid;
+        const int idx = min(it * 256 + tid, CFG::B_ITEMS - 1);
         const int n = idx >> 3, q = idx & 7;
-        bOk[it] = idx < CFG::B_ITEMS && n0 + n < cout;
-        bDst[it] = idx < CFG::B_ITEMS ? n * LDP + q * 4 : -1;
-        bSrc[it] = J.wgt + size_t(bOk[it] ? n0 + n : 0) * cin + q * 4;
+        bOk[it] = n0 + n < cout;
+        bDst[it] = n * LDP + q * 4;
+        bSrc[it] = to_global4(J.wgt + size_t(bOk[it] ? n0 + n : 0) * cin + q * 4);
     }
-    const size_t tapStride = size_t(cout) * cin;
+    const size_t tapStride4 = size_t(cout) * cin / 4;               // in float4 units
 
     f32x16 acc[MTW][NTW];
 #pragma unroll
@@ -106,49 +111,45 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int nchunks = cin / KC;
-    const int nstages = nchunks * TAPS;
-    float4 ra[CFG::NA], rb[CFG::NB];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 ra[CFG::NA], rb[CFG::NB];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    // prologue: stage 0 (chunk 0, tap 0)
+    // prologue: stage 0 (chunk 0, tap 0) -> LDS buffers 0
 #pragma unroll
-    for (int it = 0; it < CFG::NA; ++it) ra[it] = aOk[it] ? *reinterpret_cast<const float4*>(aSrc[it]) : zero4;
+    for (int it = 0; it < CFG::NA; ++it) { ra[it] = aSrc[it][0]; if (!aOk[it]) ra[it] = zero4; }
 #pragma unroll
-    for (int it = 0; it < CFG::NB; ++it) rb[it] = bOk[it] ? *reinterpret_cast<const float4*>(bSrc[it]) : zero4;
+    for (int it = 0; it < CFG::NB; ++it) { rb[it] = bSrc[it][0]; if (!bOk[it]) rb[it] = zero4; }
 #pragma unroll
-    for (int it = 0; it < CFG::NA; ++it) if (aDst[it] >= 0) *reinterpret_cast<float4*>(Abase + aDst[it]) = ra[it];
+    for (int it = 0; it < CFG::NA; ++it) *reinterpret_cast<f32x4*>(Abase + aDst[it]) = ra[it];
 #pragma unroll
-    for (int it = 0; it < CFG::NB; ++it) if (bDst[it] >= 0) *reinterpret_cast<float4*>(Bbase + bDst[it]) = rb[it];
+    for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bbase + bDst[it]) = rb[it];
     __syncthreads();
 
-    int chunk = 0, tap = 0;
-    for (int s = 0; s < nstages; ++s) {
-        // ---- prefetch stage s+1 into registers
-        int nchunk = chunk, ntap = tap + 1;
-        if (ntap == TAPS) { ntap = 0; ++nchunk; }
-        const bool more = s + 1 < nstages;
-        const bool newA = more && ntap == 0;
-        if (more) {
+    // Pipeline: chunk-outer, taps fully unrolled.  The next chunk's A halo tile is fetched at the top of a chunk and
+    // parked in registers for all TAPS stages; each stage fetches the next stage's B tile before its MFMA block and
+    // writes it to the other LDS buffer after it.  The final stage re-fetches a clamped (valid) tile that nobody reads.
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int nch = min(chunk + 1, nchunks - 1);
 #pragma unroll
-            for (int it = 0; it < CFG::NB; ++it)
-                rb[it] = bOk[it] ? *reinterpret_cast<const float4*>(bSrc[it] + ntap * tapStride + nchunk * KC) : zero4;
-            if (newA) {
+        for (int it = 0; it < CFG::NA; ++it) ra[it] = aSrc[it][nch * (KC / 4)];
 #pragma unroll
-                for (int it = 0; it < CFG::NA; ++it)
-                    ra[it] = aOk[it] ? *reinterpret_cast<const float4*>(aSrc[it] + nchunk * KC) : zero4;
-            }
-        }
-        // ---- compute stage s from LDS
-        {
+        for (int tap = 0; tap < TAPS; ++tap) {
+            constexpr int kLast = TAPS - 1;
+            const int ntap = tap == kLast ? 0 : tap + 1;
+            const int bch = tap == kLast ? nch : chunk;
+#pragma unroll
+            for (int it = 0; it < CFG::NB; ++it) rb[it] = bSrc[it][ntap * tapStride4 + bch * (KC / 4)];
+            __builtin_amdgcn_sched_barrier(0);
+            const int stage = chunk * TAPS + tap;
             const float* As = Abase + (chunk & 1) * CFG::A_ELEMS + ((tap / KW) * HW + (tap % KW)) * LDP;
-            const float* Bs = Bbase + (s & 1) * CFG::B_ELEMS;
+            const float* Bs = Bbase + (stage & 1) * CFG::B_ELEMS;
 #pragma unroll
             for (int k8 = 0; k8 < KC / 8; ++k8) {
-                float4 a4[MTW], b4[NTW];
+                f32x4 a4[MTW], b4[NTW];
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) a4[mt] = *reinterpret_cast<const float4*>(As + offA[mt] + k8 * 8);
+                for (int mt = 0; mt < MTW; ++mt) a4[mt] = *reinterpret_cast<const f32x4*>(As + offA[mt] + k8 * 8);
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) b4[nt] = *reinterpret_cast<const float4*>(Bs + offB[nt] + k8 * 8);
+                for (int nt = 0; nt < NTW; ++nt) b4[nt] = *reinterpret_cast<const f32x4*>(Bs + offB[nt] + k8 * 8);
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -159,20 +160,17 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].w, b4[nt].w, acc[mt][nt], 0, 0, 0);
                     }
             }
-        }
-        // ---- registers -> the other LDS buffers (last read one barrier ago), then one barrier
-        if (more) {
-            float* Bd = Bbase + ((s + 1) & 1) * CFG::B_ELEMS;
+            __builtin_amdgcn_sched_barrier(0);
+            float* Bd = Bbase + ((stage + 1) & 1) * CFG::B_ELEMS;
 #pragma unroll
-            for (int it = 0; it < CFG::NB; ++it) if (bDst[it] >= 0) *reinterpret_cast<float4*>(Bd + bDst[it]) = rb[it];
-            if (newA) {
-                float* Ad = Abase + (nchunk & 1) * CFG::A_ELEMS;
+            for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? rb[it] : zero4;
+            if (tap == kLast) {
+                float* Ad = Abase + ((chunk + 1) & 1) * CFG::A_ELEMS;
 #pragma unroll
-                for (int it = 0; it < CFG::NA; ++it) if (aDst[it] >= 0) *reinterpret_cast<float4*>(Ad + aDst[it]) = ra[it];
+                for (int it = 0; it < CFG::NA; ++it) *reinterpret_cast<f32x4*>(Ad + aDst[it]) = aOk[it] ? ra[it] : zero4;
             }
+            __syncthreads();
         }
-        __syncthreads();
-        chunk = nchunk; tap = ntap;
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)

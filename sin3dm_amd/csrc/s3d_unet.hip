@@ -47,6 +47,37 @@ struct s3d_unet {
 
     Arena arena;
 
+    // optional live timing of the convolution launches (s3d_unet_profile)
+    struct ProfRec { int cls; hipEvent_t e0, e1; double flops; };
+    int prof_every = 0;
+    long fwd_count = 0;
+    bool prof_now = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    int64_t prof_forwards = 0;
+    hipEvent_t prof_event() {
+        hipEvent_t e = nullptr;
+        if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    }
+    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
+        if (!prof_now) return launch_conv(kind, ca, st);
+        int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : 25));
+        double pix = 0;
+        for (int j = 0; j < ca.njobs; ++j) pix += double(ca.job[j].h) * ca.job[j].w;
+        ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B};
+        if (r.e0) (void)hipEventRecord(r.e0, st);
+        int rc = launch_conv(kind, ca, st);
+        if (r.e1) (void)hipEventRecord(r.e1, st);
+        prof_recs.push_back(r);
+        return rc;
+    }
+    ~s3d_unet() {
+        for (auto& r : prof_recs) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
+        for (auto e : prof_pool) (void)hipEventDestroy(e);
+    }
+
     const float* dev(size_t off) const { return static_cast<const float*>(wbuf.p) + off; }
 };
 
@@ -301,7 +332,7 @@ struct Fwd {
             ConvJob& jc = ca.job[2 * p + 1];
             jc.in = colvec[p]; jc.wgt = m->dev(cw->rcol[p]); jc.out = tab_col[p]; jc.h = 1; jc.w = x.g.w[p];
         }
-        S3D_TRY(launch_conv(CONV_1x3_VEC, ca, st));
+        S3D_TRY(m->timed_conv(2, CONV_1x3_VEC, ca, st));
         return 0;
     }
 
@@ -318,7 +349,7 @@ struct Fwd {
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
         }
-        return launch_conv(cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st);
+        return m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st);
     }
 
     // TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311)
@@ -481,7 +512,39 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
         S3D_HIP(hipStreamSynchronize(st));
         S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
     }
-    return run_forward(m, x, t, B, H, W, D, out, st);
+    m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
+    ++m->fwd_count;
+    if (m->prof_now) ++m->prof_forwards;
+    rc = run_forward(m, x, t, B, H, W, D, out, st);
+    m->prof_now = false;
+    return rc;
+}
+
+int s3d_unet_profile(s3d_unet* m, int every) {
+    S3D_CHECK(m && every >= 0, S3D_ERR_INVALID, "unet_profile: bad argument");
+    m->prof_every = every;
+    m->fwd_count = 0;
+    return 0;
+}
+
+int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
+    S3D_CHECK(m && out, S3D_ERR_INVALID, "unet_profile_read: null argument");
+    for (auto& r : m->prof_recs) {
+        if (r.e0 && r.e1) {
+            S3D_HIP(hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            S3D_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            out->ms[r.cls] += ms;
+            out->flops[r.cls] += r.flops;
+            out->launches[r.cls] += 1;
+        }
+        if (r.e0) m->prof_pool.push_back(r.e0);
+        if (r.e1) m->prof_pool.push_back(r.e1);
+    }
+    m->prof_recs.clear();
+    out->forwards += m->prof_forwards;
+    m->prof_forwards = 0;
+    return 0;
 }
 
 }  // extern "C"

@@ -115,6 +115,18 @@ class _TriplaneUNetBase(nn.Module):
             except Exception:
                 pass
 
+    # ------------------------------------------------------------------ live kernel timing (bench.py)
+    def profile(self, every):
+        """Record HIP events around the convolution launches of every `every`-th forward (0 = off)."""
+        lib = self._ensure_handle()
+        _lib.check(lib.s3d_unet_profile(self._handle, int(every)))
+
+    def profile_read(self, into=None):
+        """Accumulate the recorded launch durations: dict of lists over (conv3x3, conv1x1, rank1)."""
+        prof = into if into is not None else _lib.Profile()
+        _lib.check(_lib.load().s3d_unet_profile_read(self._handle, C.byref(prof)))
+        return prof
+
     def convert_to_fp16(self):
         raise NotImplementedError("fp16 is not runnable in the reference (see __init__)")
 

@@ -158,3 +158,18 @@ def test_compose(oracle):
     assert np.array_equal(comp, g["composed"])
     for a, b in zip(oracle.decompose(comp, H, W, D), (g["xy"], g["xz"], g["yz"])):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag,mc,raw,ssn,cm", UNET_CASES)
+def test_torch_port_unet_forward(oracle, tag, mc, raw, ssn, cm):
+    """oracle/torch_port.py (bench.py's cpu_baseline engine) against the same golden vectors."""
+    import torch
+    import torch_port as tp
+    g = golden("unet_fwd")
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc, rollout=not raw, use_scale_shift_norm=ssn,
+                                                    channel_mult=cm), 0)
+    H, W, D = (int(v) for v in g[f"{tag}.hwd"])
+    with torch.no_grad():
+        y = tp.unet_forward(sd, torch.from_numpy(g[f"{tag}.x"]), torch.from_numpy(g[f"{tag}.t"]), H, W, D, mc, cm, ssn,
+                            not raw).numpy()
+    assert relerr(y, g[f"{tag}.y"]) < 5e-6
