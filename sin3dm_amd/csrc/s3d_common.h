@@ -90,6 +90,7 @@ struct Tri {
     float* p[3] = {nullptr, nullptr, nullptr};
     int C = 0;
     Geo g{};
+    float* gn = nullptr;      // GroupNorm {mean, rstd} [B][3][32][2] of this tensor when its producer already reduced them
 };
 
 // ------------------------------------------------------------------ MFMA conv (s3d_conv.hip)
@@ -105,6 +106,7 @@ struct ConvJob {
     float* out;           // [B][h][w][cout]
     int h, w;
     int bbias_stride;
+    double* gn_part;      // GroupNorm partial sums of `out` for this plane (see GnPartials) or null
     int tiles_x, tiles_per_img, n_tiles_n;   // filled by the launcher
     int block_begin;                          // first block id of this job
 };
@@ -113,6 +115,7 @@ struct ConvArgs {
     ConvJob job[kMaxConvJobs];
     int njobs;
     int B, cin, cout;
+    int gn_sg, gn_nsub, gn_maxparts;          // GroupNorm partial layout when job[].gn_part is set
 };
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3 };
 // Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.
@@ -145,10 +148,23 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w,
 int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const float* wT, const float* bias,
                    int Cout, Tri& out, hipStream_t st);
 
-// GroupNorm statistics, stage 1: per (b, plane, chunk, group) partial {sum, sumsq} in double.
-constexpr int kGnChunks = 32;     // partial slots per (b, plane)
-struct GnPartials { double* p; }; // [B][3][kGnChunks][32 groups][2]
-int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st);
+// GroupNorm statistics.  Stage 1: producers emit partial {sum, sumsq} in double, indexed
+//   p[(((b*3 + plane) * maxparts + part) * nsub + sub) * 2 + {0,1}],  sub = channel / sg
+// where a "part" is a pixel chunk (launch_gn_partials) or one wave's 32-pixel tile of a convolution epilogue and a
+// "subgroup" is sg consecutive channels of one group.  Stage 2 (launch_gn_finalize) adds the parts in index order
+// and writes {mean, rstd} per (b, plane, group): deterministic, no float atomics.
+constexpr int kGnChunks = 32;     // parts per (b, plane) written by launch_gn_partials
+struct GnPartials { double* p; int maxparts; int nparts[3]; int nsub; };
+struct GnStats { float* mr; };    // [B][3][32 groups][2] = {mean, rstd}
+inline int gn_subgroup(int C) {   // largest power of two dividing C/32, at most 32
+    int cg = C / 32, sg = 1;
+    while (sg < 32 && cg % (sg * 2) == 0) sg *= 2;
+    return sg;
+}
+int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st);   // out: maxparts=kGnChunks, nsub=32
+int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnStats out, hipStream_t st);
+// how many parts per plane a convolution epilogue writes for a given geometry (must match s3d_conv.hip's tiling)
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3]);
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {
@@ -157,14 +173,14 @@ struct ActArgs {
     const float* film;       // [B][film_stride]: scale at [0,C), shift at [C,2C); or null
     int film_stride;
 };
-constexpr int kActRows = 8, kActCols = 32;   // tile of the act kernel
+constexpr int kActRows = 8, kActCols = 16;   // tile of the act kernel
 struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a tile's columns), colpart [B][ntr][w][C]
     float* rowpart[3];
     float* colpart[3];
 };
 // stats.p == nullptr: identity (no norm, no SiLU) — used by the leaf-operator entry point to get the rollout
 // means of a raw input.
-int launch_gn_act(const Tri& x, int B, GnPartials stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
+int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                   hipStream_t st);
 // finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
 struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
@@ -178,7 +194,7 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
                       hipStream_t st);
 
 // out head: GN + SiLU + 1x1 conv (C -> Cout small) + compose into NCHW [B,Cout,H+D,W+D] with zero corner
-int launch_out_head(const Tri& x, int B, GnPartials stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
+int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
                     const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st);
 
 // small dense layers for the timestep path: y[b][o] = act_out( sum_i f(in[b][i]) * W[o][i] + bias[o] )

@@ -23,11 +23,15 @@ namespace s3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef S3D_ABLATE
+#define S3D_ABLATE 0            // tools/conv_ubench.hip only: 1 no prefetch loads, 2 no LDS stores, 4 no barrier, 8 no ds_reads
+#endif
 constexpr int KC = 32;          // channels per K chunk
 constexpr int LDP = KC + 4;     // padded LDS row (floats)
 
-template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_>
+template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1>
 struct ConvCfg {
+    static constexpr int KS = KS_;       // independent partial accumulators over K (breaks the MFMA dependency chain)
     static constexpr int TH = TH_, TW = TW_, KH = KH_, KW = KW_, WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
     static constexpr int BM = TH * TW, BN = WN * NTW * 32;
     static constexpr int HH = TH + KH - 1, HW = TW + KW - 1;
@@ -102,13 +106,16 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
     }
     const size_t tapStride4 = size_t(cout) * cin / 4;               // in float4 units
 
-    f32x16 acc[MTW][NTW];
+    constexpr int KS = CFG::KS;
+    f32x16 acc[KS][MTW][NTW];
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ks][mt][nt][r] = 0.f;
 
     const int nchunks = cin / KC;
     f32x4 ra[CFG::NA], rb[CFG::NB];
@@ -131,14 +138,14 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int nch = min(chunk + 1, nchunks - 1);
 #pragma unroll
-        for (int it = 0; it < CFG::NA; ++it) ra[it] = aSrc[it][nch * (KC / 4)];
+        for (int it = 0; it < CFG::NA; ++it) if (!(S3D_ABLATE & 1)) ra[it] = aSrc[it][nch * (KC / 4)];
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             constexpr int kLast = TAPS - 1;
             const int ntap = tap == kLast ? 0 : tap + 1;
             const int bch = tap == kLast ? nch : chunk;
 #pragma unroll
-            for (int it = 0; it < CFG::NB; ++it) rb[it] = bSrc[it][ntap * tapStride4 + bch * (KC / 4)];
+            for (int it = 0; it < CFG::NB; ++it) if (!(S3D_ABLATE & 1)) rb[it] = bSrc[it][ntap * tapStride4 + bch * (KC / 4)];
             __builtin_amdgcn_sched_barrier(0);
             const int stage = chunk * TAPS + tap;
             const float* As = Abase + (chunk & 1) * CFG::A_ELEMS + ((tap / KW) * HW + (tap % KW)) * LDP;
@@ -147,53 +154,73 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
             for (int k8 = 0; k8 < KC / 8; ++k8) {
                 f32x4 a4[MTW], b4[NTW];
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) a4[mt] = *reinterpret_cast<const f32x4*>(As + offA[mt] + k8 * 8);
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) b4[nt] = *reinterpret_cast<const f32x4*>(Bs + offB[nt] + k8 * 8);
-#pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
+                    a4[mt] = (S3D_ABLATE & 8) ? ra[0] + float(k8) : *reinterpret_cast<const f32x4*>(As + offA[mt] + k8 * 8);
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].x, b4[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].y, b4[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].z, b4[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt].w, b4[nt].w, acc[mt][nt], 0, 0, 0);
-                    }
+                for (int nt = 0; nt < NTW; ++nt)
+                    b4[nt] = (S3D_ABLATE & 8) ? rb[0] + float(k8) : *reinterpret_cast<const f32x4*>(Bs + offB[nt] + k8 * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)                    // consecutive MFMAs go to different accumulators
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int ks = (k8 * 4 + e) % KS;
+                            acc[ks][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt][e], b4[nt][e], acc[ks][mt][nt], 0, 0, 0);
+                        }
             }
             __builtin_amdgcn_sched_barrier(0);
             float* Bd = Bbase + ((stage + 1) & 1) * CFG::B_ELEMS;
 #pragma unroll
-            for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? rb[it] : zero4;
-            if (tap == kLast) {
+            for (int it = 0; it < CFG::NB; ++it) if (!(S3D_ABLATE & 2)) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? rb[it] : zero4;
+            if (tap == kLast && !(S3D_ABLATE & 2)) {
                 float* Ad = Abase + ((chunk + 1) & 1) * CFG::A_ELEMS;
 #pragma unroll
                 for (int it = 0; it < CFG::NA; ++it) *reinterpret_cast<f32x4*>(Ad + aDst[it]) = aOk[it] ? ra[it] : zero4;
             }
-            __syncthreads();
+            if (!(S3D_ABLATE & 4)) __syncthreads();
         }
     }
 
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int tile_idx = local;                       // pixel-tile index inside the image
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0 + (wn * NTW + nt) * 32 + (lane & 31);
-        if (co >= cout) continue;
-        const float bv = J.bias ? J.bias[co] : 0.f;
-        const float bb = J.bbias ? J.bbias[size_t(b) * J.bbias_stride + co] : 0.f;
+        const bool co_ok = co < cout;
+        const float bv = (co_ok && J.bias) ? J.bias[co] : 0.f;
+        const float bb = (co_ok && J.bbias) ? J.bbias[size_t(b) * J.bbias_stride + co] : 0.f;
+        float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int y = ty0 + p / TW, x = tx0 + p % TW;
-                if (y >= h || x >= w) continue;
-                float v = acc[mt][nt][r] + bv;
+                if (y >= h || x >= w || !co_ok) continue;
+                float v = acc[0][mt][nt][r];
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) v += acc[ks][mt][nt][r];
+                v += bv;
                 if (J.bbias) v += bb;
                 if (J.rcol) v += J.rcol[((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co];
                 if (J.rrow) v += J.rrow[((size_t(b) * h + y) * 4 + edge_variant(x, w)) * cout + co];
                 const size_t o = ((size_t(b) * h + y) * w + x) * cout + co;
                 if (J.res) v += J.res[o];
                 J.out[o] = v;
+                gs += v; gss = fmaf(v, v, gss);
+            }
+        }
+        if (J.gn_part) {
+            // this wave's {sum, sumsq} per subgroup of sg consecutive channels: fold the two lane halves (the other
+            // 16 pixel rows), then the sg channels; one part per (pixel tile, wave row) — see GnPartials
+            gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
+            for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
+            if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
+                const int part = tile_idx * CFG::WM + wm;
+                double* dst = J.gn_part + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
+                dst[0] = double(gs); dst[1] = double(gss);
             }
         }
     }
@@ -227,6 +254,14 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
             J.out[i] = v;
         }
     }
+}
+
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3]) {
+    // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
+    (void)kind;
+    using CFG = ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>;
+    for (int p = 0; p < 3; ++p)
+        nparts[p] = ((g.w[p] + CFG::TW - 1) / CFG::TW) * ((g.h[p] + CFG::TH - 1) / CFG::TH) * CFG::WM;
 }
 
 bool conv_use_naive() {
@@ -283,16 +318,13 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
     if (conv_use_naive()) return launch_conv_naive(kind, a, st);
-    // Tile choice: the 128-pixel tile halves the halo and B-tile traffic per flop, but at batch 1 the
-    // half-resolution layers only have a few hundred tiles: fall back to 64-pixel tiles when the big
-    // tile would leave CUs idle (256 CUs, 2 resident blocks each).
-    const long long n64 = (a.cout + 63) / 64;
+    // Tile choice (measured, tools/run_cfgs.sh + tools/conv_ubench.hip): the 64-pixel x 64-cout tile wins at every
+    // size of this network because three blocks stay resident per CU (47 KB LDS each) and their staggered barriers keep
+    // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
-            if (count_tiles<8, 16>(a) * n64 >= 512) return launch_cfg<ConvCfg<8, 16, 3, 3, 4, 1, 1, 2>>(a, st);
             return launch_cfg<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>>(a, st);
         case CONV_1x1:
-            if (count_tiles<8, 16>(a) * n64 >= 512) return launch_cfg<ConvCfg<8, 16, 1, 1, 4, 1, 1, 2>>(a, st);
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
         case CONV_1x3_VEC:
             return launch_cfg<ConvCfg<1, 32, 1, 3, 1, 4, 1, 1>>(a, st);

@@ -163,17 +163,45 @@ int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st) {
     return 0;
 }
 
-// mean / rstd of group g for (b, plane p): fixed-order sum of the chunk partials, in double.
-__device__ __forceinline__ void gn_finalize(const double* part, int b, int p, int g, double n, float eps,
-                                            float& mean, float& rstd) {
-    const double* src = part + ((size_t(b) * 3 + p) * kGnChunks * 32 + g) * 2;
+// Stage 2: {mean, rstd} of every (b, plane, group) from the partials, added in part order, in double.
+struct GnFinArgs {
+    const double* part; float* mr;
+    int maxparts, nparts[3], nsub, subs_per_group;
+    double count[3];      // elements per group = (C/32)*h*w
+};
+__global__ void k_gn_finalize(GnFinArgs a) {
+    __shared__ double sm[8][32][2];
+    const int p = blockIdx.x, b = blockIdx.y;
+    const int g = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const double* base = a.part + (size_t(b) * 3 + p) * a.maxparts * a.nsub * 2;
     double S = 0, SS = 0;
-    for (int c = 0; c < kGnChunks; ++c) { S += src[size_t(c) * 64]; SS += src[size_t(c) * 64 + 1]; }
-    const double m = S / n;
-    double var = SS / n - m * m;
-    if (var < 0) var = 0;
-    mean = float(m);
-    rstd = float(1.0 / sqrt(var + double(eps)));
+    for (int part = slice; part < a.nparts[p]; part += 8) {
+        const double* row = base + (size_t(part) * a.nsub + size_t(g) * a.subs_per_group) * 2;
+        for (int k = 0; k < a.subs_per_group; ++k) { S += row[2 * k]; SS += row[2 * k + 1]; }
+    }
+    sm[slice][g][0] = S; sm[slice][g][1] = SS;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double s = 0, ss = 0;
+        for (int k = 0; k < 8; ++k) { s += sm[k][g][0]; ss += sm[k][g][1]; }
+        const double m = s / a.count[p];
+        double var = ss / a.count[p] - m * m;
+        if (var < 0) var = 0;
+        float* o = a.mr + ((size_t(b) * 3 + p) * 32 + g) * 2;
+        o[0] = float(m);
+        o[1] = float(1.0 / sqrt(var + 1e-5));
+    }
+}
+int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnStats out, hipStream_t st) {
+    GnFinArgs a;
+    a.part = part.p; a.mr = out.mr; a.maxparts = part.maxparts; a.nsub = part.nsub;
+    S3D_CHECK(part.nsub % 32 == 0, S3D_ERR_INVALID, "gn_finalize: nsub=%d", part.nsub);
+    a.subs_per_group = part.nsub / 32;
+    for (int p = 0; p < 3; ++p) { a.nparts[p] = part.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
+    if (!B) return 0;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(3, B), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------ GN-apply (+FiLM) + SiLU (+ rollout partial means)
@@ -185,7 +213,7 @@ struct GnActArgs {
     const float* x[3]; float* y[3];
     const float* gamma[3]; const float* beta[3];
     float* rowpart[3]; float* colpart[3];
-    const double* part;
+    const float* mr;
     const float* film; int film_stride;
     int h[3], w[3];
     int C, cq, pl, with_means;
@@ -198,11 +226,10 @@ __global__ void k_gn_act(GnActArgs a) {
     const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
     if (int(blockIdx.x) >= ntc * ntr) return;
     const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
-    const bool ident = a.part == nullptr;
+    const bool ident = a.mr == nullptr;
     if (threadIdx.x < 32 && !ident) {
-        float m, r;
-        gn_finalize(a.part, b, p, threadIdx.x, double(a.C / 32) * h * w, 1e-5f, m, r);
-        sm[threadIdx.x] = m; sm[32 + threadIdx.x] = r;
+        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
+        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
     }
     __syncthreads();
     const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
@@ -227,12 +254,15 @@ __global__ void k_gn_act(GnActArgs a) {
     for (int r = 0; r < kActRows; ++r) rowacc[r] = make_float4(0, 0, 0, 0);
     for (int j = j0 + l; j < j1; j += a.pl) {
         float4 colacc = make_float4(0, 0, 0, 0);
+        float4 xin[kActRows];
+#pragma unroll
+        for (int r = 0; r < kActRows; ++r) xin[r] = xs[(size_t(min(i0 + r, i1 - 1)) * w + j) * a.cq];   // all loads first
 #pragma unroll
         for (int r = 0; r < kActRows; ++r) {
             const int i = i0 + r;
             if (i < i1) {
                 const size_t off = (size_t(i) * w + j) * a.cq;
-                const float4 v = xs[off];
+                const float4 v = xin[r];
                 float4 o;
                 o.x = fmaf(v.x, A[0], Bc[0]); o.y = fmaf(v.y, A[1], Bc[1]);
                 o.z = fmaf(v.z, A[2], Bc[2]); o.w = fmaf(v.w, A[3], Bc[3]);
@@ -267,7 +297,7 @@ __global__ void k_gn_act(GnActArgs a) {
         reinterpret_cast<float4*>(a.rowpart[p] + ((size_t(b) * ntc + tc) * h + i) * a.C)[qq] = s;
     }
 }
-int launch_gn_act(const Tri& x, int B, GnPartials stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
+int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
                   hipStream_t st) {
     GnActArgs a;
     int maxtiles = 0;
@@ -278,7 +308,7 @@ int launch_gn_act(const Tri& x, int B, GnPartials stats, const ActArgs& aa, Tri&
         a.colpart[p] = mp ? mp->colpart[p] : nullptr;
         maxtiles = std::max(maxtiles, cdiv(a.h[p], kActRows) * cdiv(a.w[p], kActCols));
     }
-    a.part = stats.p; a.film = aa.film; a.film_stride = aa.film_stride;
+    a.mr = stats.mr; a.film = aa.film; a.film_stride = aa.film_stride;
     a.C = x.C; thread_shape(x.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
     if (!maxtiles || !B) return 0;
@@ -444,14 +474,17 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
 // blockIdx.y: plane 0..2, 3 = the DxD corner that compose fills with zeros.
 struct OutHeadArgs {
     const float* x[3]; const float* gamma[3]; const float* beta[3];
-    const double* part; const float* w; const float* bias; float* out;
+    const float* mr; const float* w; const float* bias; float* out;
     int h[3], wd[3];
-    int C, Cout, H, W, D;
+    int C, cq, ppb, Cout, H, W, D;
 };
-constexpr int kOutPix = 16;
+constexpr int kOutCo = 16;     // output channels handled per pass
+// One thread = one pixel x one float4 of channels: the activation is evaluated once per element, each thread
+// forms its 4-channel partial dot products with the Cout weight rows, and the cq partials of a pixel are added in
+// LDS in index order.
 __global__ void k_out_head(OutHeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* sm = reinterpret_cast<float*>(smem_raw);           // [64] stats + A[C] + Bc[C]
+    float* sm = reinterpret_cast<float*>(smem_raw);           // [64] stats, then [ppb][kOutCo][cq] partials
     const int p = blockIdx.y, b = blockIdx.z;
     const int Hc = a.H + a.D, Wc = a.W + a.D;
     if (p == 3) {                                              // zero corner
@@ -463,42 +496,51 @@ __global__ void k_out_head(OutHeadArgs a) {
         return;
     }
     const int h = a.h[p], w = a.wd[p], npix = h * w;
-    if (int(blockIdx.x) * kOutPix >= npix) return;
+    if (int(blockIdx.x) * a.ppb >= npix) return;
     if (threadIdx.x < 32) {
-        float m, r;
-        gn_finalize(a.part, b, p, threadIdx.x, double(a.C / 32) * npix, 1e-5f, m, r);
-        sm[threadIdx.x] = m; sm[32 + threadIdx.x] = r;
+        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
+        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
     }
     __syncthreads();
-    float* A = sm + 64; float* Bc = A + a.C;
+    const int q = threadIdx.x % a.cq, lp = threadIdx.x / a.cq;
+    const int pix = blockIdx.x * a.ppb + lp;
+    const bool live = pix < npix;
     const int cg = a.C / 32;
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
-        const float scale = sm[32 + c / cg] * a.gamma[p][c];
-        A[c] = scale; Bc[c] = a.beta[p][c] - scale * sm[c / cg];
-    }
-    __syncthreads();
-    const int lp = threadIdx.x / 16, cs = threadIdx.x % 16;
-    const int pix = blockIdx.x * kOutPix + lp;
-    if (pix >= npix) return;
-    const int y = pix / w, xx = pix % w;
-    const float4* xs = reinterpret_cast<const float4*>(a.x[p] + (size_t(b) * npix + pix) * a.C);
-    for (int co = cs; co < a.Cout; co += 16) {
-        const float4* wr = reinterpret_cast<const float4*>(a.w + (size_t(p) * a.Cout + co) * a.C);
-        float acc = a.bias[p * a.Cout + co];
-        for (int c4 = 0; c4 < a.C / 4; ++c4) {
-            const float4 v = xs[c4], wv = wr[c4];
-            const float4 A4 = reinterpret_cast<const float4*>(A)[c4], B4 = reinterpret_cast<const float4*>(Bc)[c4];
-            acc = fmaf(silu_f(fmaf(v.x, A4.x, B4.x)), wv.x, acc);
-            acc = fmaf(silu_f(fmaf(v.y, A4.y, B4.y)), wv.y, acc);
-            acc = fmaf(silu_f(fmaf(v.z, A4.z, B4.z)), wv.z, acc);
-            acc = fmaf(silu_f(fmaf(v.w, A4.w, B4.w)), wv.w, acc);
+    float act[4];
+    {
+        const float4 v = live ? reinterpret_cast<const float4*>(a.x[p] + (size_t(b) * npix + pix) * a.C)[q]
+                              : make_float4(0, 0, 0, 0);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * q + k, g = c / cg;
+            const float scale = sm[32 + g] * a.gamma[p][c];
+            act[k] = silu_f(fmaf(vv[k], scale, a.beta[p][c] - scale * sm[g]));
         }
-        int sy, sx;
-        if (p == 0) { sy = y; sx = xx; } else if (p == 1) { sy = y; sx = a.W + xx; } else { sy = a.H + xx; sx = y; }
-        a.out[((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx] = acc;
+    }
+    __syncthreads();                                            // stats region is reused for the partials
+    for (int co0 = 0; co0 < a.Cout; co0 += kOutCo) {
+        const int nco = min(kOutCo, a.Cout - co0);
+        for (int k = 0; k < nco; ++k) {
+            const float4 wv = reinterpret_cast<const float4*>(a.w + (size_t(p) * a.Cout + co0 + k) * a.C)[q];
+            sm[(size_t(lp) * kOutCo + k) * a.cq + q] = act[0] * wv.x + act[1] * wv.y + act[2] * wv.z + act[3] * wv.w;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < a.ppb * nco; it += blockDim.x) {
+            const int k = it / a.ppb, l2 = it % a.ppb;           // consecutive threads -> consecutive pixels
+            const int px = blockIdx.x * a.ppb + l2;
+            if (px >= npix) continue;
+            const float* row = sm + (size_t(l2) * kOutCo + k) * a.cq;
+            float acc = a.bias[p * a.Cout + co0 + k];
+            for (int j = 0; j < a.cq; ++j) acc += row[j];
+            const int y = px / w, xx = px % w;
+            int sy, sx;
+            if (p == 0) { sy = y; sx = xx; } else if (p == 1) { sy = y; sx = a.W + xx; } else { sy = a.H + xx; sx = y; }
+            a.out[((size_t(b) * a.Cout + co0 + k) * Hc + sy) * Wc + sx] = acc;
+        }
+        __syncthreads();
     }
 }
-int launch_out_head(const Tri& x, int B, GnPartials stats, const ActArgs& aa, const float* w, const float* bias,
+int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const float* w, const float* bias,
                     int Cout, int H, int W, int D, float* out, hipStream_t st) {
     OutHeadArgs a;
     int maxpix = D * D ? 1 : 0;
@@ -507,10 +549,12 @@ int launch_out_head(const Tri& x, int B, GnPartials stats, const ActArgs& aa, co
         a.h[p] = x.g.h[p]; a.wd[p] = x.g.w[p];
         maxpix = std::max(maxpix, a.h[p] * a.wd[p]);
     }
-    a.part = stats.p; a.w = w; a.bias = bias; a.out = out; a.C = x.C; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
+    a.mr = stats.mr; a.w = w; a.bias = bias; a.out = out; a.C = x.C; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
+    thread_shape(x.C, a.cq, a.ppb);
+    S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "out head: C=%d unsupported", x.C);
     if (!maxpix || !B) return 0;
-    size_t shm = (64 + 2 * size_t(x.C)) * sizeof(float);
-    hipLaunchKernelGGL(k_out_head, dim3(cdiv(maxpix, kOutPix), 4, B), dim3(256), shm, st, a);
+    size_t shm = std::max(size_t(64), size_t(a.ppb) * kOutCo * a.cq) * sizeof(float);
+    hipLaunchKernelGGL(k_out_head, dim3(cdiv(maxpix, a.ppb), 4, B), dim3(a.cq * a.ppb), shm, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }

@@ -78,7 +78,7 @@ int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, i
             S3D_TRY(sc.alloc(&tab_col[p], size_t(B) * w * 4 * Cout));
         }
         ActArgs aa; memset(&aa, 0, sizeof aa);
-        S3D_TRY(launch_gn_act(x, B, GnPartials{nullptr}, aa, y, &mp, st));       // identity copy + axis sums
+        S3D_TRY(launch_gn_act(x, B, GnStats{nullptr}, aa, y, &mp, st));          // identity copy + axis sums
         S3D_TRY(launch_means_finalize(g, C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = C; ca.cout = 4 * Cout; ca.njobs = 6;
@@ -114,8 +114,12 @@ int s3d_op_triplane_norm_silu(const float* const in[3], float* const out[3], int
     Tri x, y;
     S3D_TRY(tri_from_nchw(sc, in, B, C, g, x, st));
     S3D_TRY(tri_alloc(sc, B, C, g, y));
-    GnPartials stats;
-    S3D_TRY(sc.alloc(&stats.p, size_t(B) * 3 * kGnChunks * 64));
+    GnPartials part;
+    S3D_TRY(sc.alloc(&part.p, size_t(B) * 3 * kGnChunks * 64));
+    part.maxparts = kGnChunks; part.nsub = 32;
+    for (int p = 0; p < 3; ++p) part.nparts[p] = kGnChunks;
+    GnStats stats;
+    S3D_TRY(sc.alloc(&stats.mr, size_t(B) * 3 * 64));
     ActArgs aa; memset(&aa, 0, sizeof aa);
     for (int p = 0; p < 3; ++p) {
         float *gd, *bd;
@@ -124,7 +128,8 @@ int s3d_op_triplane_norm_silu(const float* const in[3], float* const out[3], int
         S3D_HIP(hipMemcpyAsync(bd, beta[p], C * sizeof(float), hipMemcpyHostToDevice, st));
         aa.gamma[p] = gd; aa.beta[p] = bd;
     }
-    S3D_TRY(launch_gn_partials(x, B, stats, st));
+    S3D_TRY(launch_gn_partials(x, B, part, st));
+    S3D_TRY(launch_gn_finalize(part, g, C, B, stats, st));
     S3D_TRY(launch_gn_act(x, B, stats, aa, y, nullptr, st));
     S3D_TRY(tri_to_nchw(y, B, out, st));
     S3D_HIP(hipStreamSynchronize(st));

@@ -286,14 +286,26 @@ struct Fwd {
         for (int p = 0; p < 3; ++p) t.p[p] = ar().alloc<float>(size_t(B) * g.h[p] * g.w[p] * C);
         return t;
     }
-    GnPartials alloc_stats() { return GnPartials{ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64)}; }
+    // GroupNorm {mean, rstd} of x: taken from its producer's epilogue when available, otherwise one read pass.
+    int stats_of(const Tri& x, GnStats& out) {
+        if (x.gn) { out.mr = x.gn; return 0; }
+        GnPartials part;
+        part.p = ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64);
+        part.maxparts = kGnChunks; part.nsub = 32;
+        for (int p = 0; p < 3; ++p) part.nparts[p] = kGnChunks;
+        out.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+        if (ar().measuring) return 0;
+        S3D_TRY(launch_gn_partials(x, B, part, st));
+        return launch_gn_finalize(part, x.g, x.C, B, out, st);
+    }
 
     // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and
     // the rank-1 tables its epilogue needs.  Returns activated tensor; fills rrow/rcol table pointers.
     int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
                  const float* rcol[3]) {
         const bool measuring = ar().measuring;
-        GnPartials stats = alloc_stats();
+        GnStats stats;
+        S3D_TRY(stats_of(x, stats));
         y = alloc_tri(x.C, x.g);
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(nw.gamma[p]); aa.beta[p] = m->dev(nw.beta[p]); }
@@ -316,7 +328,6 @@ struct Fwd {
             }
         }
         if (measuring) return 0;
-        S3D_TRY(launch_gn_partials(x, B, stats, st));
         S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st));
         if (!roll) return 0;
         S3D_TRY(launch_means_finalize(x.g, x.C, B, mp, mv, st));
@@ -336,35 +347,50 @@ struct Fwd {
         return 0;
     }
 
+    // want_stats: also reduce the GroupNorm statistics of the output in the epilogue (3x3 MFMA path only)
     int conv(const Tri& y, const ConvW& cw, const float* bbias, const float* const rrow[3], const float* const rcol[3],
-             const Tri* res, Tri& out) {
+             const Tri* res, Tri& out, bool want_stats = false) {
         out = alloc_tri(cw.cout, y.g);
+        want_stats = want_stats && cw.k == 3 && !conv_use_naive();
+        GnPartials part; GnStats gs{nullptr};
+        if (want_stats) {
+            conv_gn_parts(CONV_3x3, y.g, part.nparts);
+            part.maxparts = std::max(part.nparts[0], std::max(part.nparts[1], part.nparts[2]));
+            part.nsub = cw.cout / gn_subgroup(cw.cout);
+            part.p = ar().alloc<double>(size_t(B) * 3 * part.maxparts * part.nsub * 2);
+            gs.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+            out.gn = gs.mr;
+        }
         if (ar().measuring) return 0;
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
+        if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
         for (int p = 0; p < 3; ++p) {
             ConvJob& J = ca.job[p];
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
             J.bbias = bbias; J.bbias_stride = m->film_total;
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
+            J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
         }
-        return m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st);
+        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
+        if (want_stats) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
+        return 0;
     }
 
     // TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311)
-    int resblock(const ResBlockW& rb, const Tri& x, Tri& out) {
+    int resblock(const ResBlockW& rb, const Tri& x, Tri& out, bool out_feeds_norm) {
         const bool ssn = m->cfg.use_scale_shift_norm != 0;
         const float* film_ptr = film ? film + rb.film_off : nullptr;
         Tri y1, h1, y2;
         const float *rr[3], *rc[3];
         S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc));
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1));     // (!ssn: h = h + emb_out, :298-303)
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, true));   // (!ssn: h = h + emb_out, :298-303)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc));
         Tri skip;
         const Tri* res = &x;
         if (rb.has_skip) { S3D_TRY(conv(x, rb.skip, nullptr, nullptr, nullptr, nullptr, skip)); res = &skip; }
-        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out));
+        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_feeds_norm));
         return 0;
     }
 };
@@ -402,7 +428,7 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
             h = d;
         }
         Tri o;
-        S3D_TRY(f.resblock(m->in_blocks[level], h, o));
+        S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1));   // the deepest output goes straight into a norm
         h = o;
         hs.push_back(o);
     }
@@ -433,14 +459,14 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
             }
         }
         Tri o;
-        S3D_TRY(f.resblock(m->out_blocks[oi], inp, o));
+        S3D_TRY(f.resblock(m->out_blocks[oi], inp, o, oi == c.n_levels - 1));       // ... and so does the last one (out head)
         h = o;
         (void)level;
     }
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
-    GnPartials stats = f.alloc_stats();
+    GnStats stats;
+    S3D_TRY(f.stats_of(h, stats));
     if (!meas) {
-        S3D_TRY(launch_gn_partials(h, B, stats, st));
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
         aa.film = nullptr; aa.film_stride = 0;
