@@ -56,6 +56,19 @@ def f_dense_per_step(mc, H, W, D, mult=(1, 2)):
     return f
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box
+    shows 256 logical CPUs but grants 16 CPUs of time; oversubscribing oneDNN 16x makes it ~40x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(steps_budget_s=20.0):
     """oracle/torch_port.py (the reference's algorithm on the reference's own CPU engine, oneDNN) timed on this
     box's host cores for a bounded number of full-size steps; samples/s = 1 / (1000 * s_per_step)."""
@@ -63,7 +76,7 @@ def cpu_baseline(steps_budget_s=20.0):
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch_port as tp
     from sin3dm_amd import testing as T
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     H, W, D = HWD
     sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0)

@@ -183,43 +183,88 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
         }
     }
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Structured for memory-level parallelism: per 32-channel column block, first issue every rank-1 / residual
+    // load of the lane's 16 pixels (predicated, clamped addresses, no per-element branches), then add and store.
     const int tile_idx = local;                       // pixel-tile index inside the image
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    const size_t img = size_t(b) * h;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0 + (wn * NTW + nt) * 32 + (lane & 31);
         const bool co_ok = co < cout;
-        const float bv = (co_ok && J.bias) ? J.bias[co] : 0.f;
-        const float bb = (co_ok && J.bbias) ? J.bbias[size_t(b) * J.bbias_stride + co] : 0.f;
-        float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
+        const int coc = co_ok ? co : 0;
+        float base = p_bias ? p_bias[coc] : 0.f;
+        if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
+        float addv[MTW][16];
+        bool ok[MTW][16];
+        size_t oidx[MTW][16];
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int y = ty0 + p / TW, x = tx0 + p % TW;
-                if (y >= h || x >= w || !co_ok) continue;
+                ok[mt][r] = y < h && x < w && co_ok;
+                oidx[mt][r] = ok[mt][r] ? ((img + y) * w + x) * cout + co : 0;
+                addv[mt][r] = base;
+            }
+        if (p_rcol) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int y = ty0 + p / TW, x = tx0 + p % TW;
+                    const float t = p_rcol[ok[mt][r] ? ((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co : 0];
+                    addv[mt][r] += ok[mt][r] ? t : 0.f;
+                }
+        }
+        if (p_rrow) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int y = ty0 + p / TW, x = tx0 + p % TW;
+                    const float t = p_rrow[ok[mt][r] ? ((img + y) * 4 + edge_variant(x, w)) * cout + co : 0];
+                    addv[mt][r] += ok[mt][r] ? t : 0.f;
+                }
+        }
+        if (p_res) {
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) addv[mt][r] += p_res[oidx[mt][r]];      // index 0 when !ok: finite, unused
+        }
+        float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
                 float v = acc[0][mt][nt][r];
 #pragma unroll
                 for (int ks = 1; ks < KS; ++ks) v += acc[ks][mt][nt][r];
-                v += bv;
-                if (J.bbias) v += bb;
-                if (J.rcol) v += J.rcol[((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co];
-                if (J.rrow) v += J.rrow[((size_t(b) * h + y) * 4 + edge_variant(x, w)) * cout + co];
-                const size_t o = ((size_t(b) * h + y) * w + x) * cout + co;
-                if (J.res) v += J.res[o];
-                J.out[o] = v;
-                gs += v; gss = fmaf(v, v, gss);
+                v += addv[mt][r];
+                if (ok[mt][r]) {
+                    p_out[oidx[mt][r]] = v;
+                    gs += v; gss = fmaf(v, v, gss);
+                }
             }
-        }
-        if (J.gn_part) {
+        if (p_gn) {
             // this wave's {sum, sumsq} per subgroup of sg consecutive channels: fold the two lane halves (the other
             // 16 pixel rows), then the sg channels; one part per (pixel tile, wave row) — see GnPartials
             gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
             for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
             if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
                 const int part = tile_idx * CFG::WM + wm;
-                double* dst = J.gn_part + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
+                double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
                 dst[0] = double(gs); dst[1] = double(gss);
             }
         }

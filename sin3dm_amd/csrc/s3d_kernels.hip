@@ -170,12 +170,12 @@ struct GnFinArgs {
     double count[3];      // elements per group = (C/32)*h*w
 };
 __global__ void k_gn_finalize(GnFinArgs a) {
-    __shared__ double sm[8][32][2];
+    __shared__ double sm[32][32][2];
     const int p = blockIdx.x, b = blockIdx.y;
-    const int g = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int g = threadIdx.x & 31, slice = threadIdx.x >> 5;          // 32 slices x 32 groups
     const double* base = a.part + (size_t(b) * 3 + p) * a.maxparts * a.nsub * 2;
     double S = 0, SS = 0;
-    for (int part = slice; part < a.nparts[p]; part += 8) {
+    for (int part = slice; part < a.nparts[p]; part += 32) {
         const double* row = base + (size_t(part) * a.nsub + size_t(g) * a.subs_per_group) * 2;
         for (int k = 0; k < a.subs_per_group; ++k) { S += row[2 * k]; SS += row[2 * k + 1]; }
     }
@@ -183,7 +183,7 @@ __global__ void k_gn_finalize(GnFinArgs a) {
     __syncthreads();
     if (threadIdx.x < 32) {
         double s = 0, ss = 0;
-        for (int k = 0; k < 8; ++k) { s += sm[k][g][0]; ss += sm[k][g][1]; }
+        for (int k = 0; k < 32; ++k) { s += sm[k][g][0]; ss += sm[k][g][1]; }
         const double m = s / a.count[p];
         double var = ss / a.count[p] - m * m;
         if (var < 0) var = 0;
@@ -199,7 +199,7 @@ int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnSta
     a.subs_per_group = part.nsub / 32;
     for (int p = 0; p < 3; ++p) { a.nparts[p] = part.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
     if (!B) return 0;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(3, B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(3, B), dim3(1024), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
