@@ -108,7 +108,7 @@ class _TriplaneUNetBase(nn.Module):
         return lib
 
     def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
+        h = self.__dict__.pop("_handle", None)      # not via nn.Module.__setattr__: it may run at interpreter exit
         if h is not None:
             try:
                 _lib.load().s3d_unet_destroy(h)

@@ -189,3 +189,46 @@ def test_sample_loop_api_device_noise():
     for s in (a, b):
         assert tuple(s.shape) == shape and torch.isfinite(s).all()
         assert float(s[..., H:, W:].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ decoder vs the reference
+def make_decoder(up, hid):
+    from sin3dm_amd.encoding.networks import AutoEncoderGroupSkip
+    net = AutoEncoderGroupSkip(4, 8, up, hid, 4)
+    missing, unexpected = net.load_state_dict(T.synthetic_state_dict(T.ae_param_shapes(4, 8, up, hid, 4), 5), strict=False)
+    assert not unexpected and all(k.startswith(("geo_encoder", "tex_encoder", "aabb")) for k in missing)
+    return net.to(dev()).eval()
+
+
+@pytest.mark.parametrize("tag", ["small", "wide"])
+def test_decoder_golden(tag):
+    g = golden("decoder")
+    up, hid, H, W, D = (int(v) for v in g[f"{tag}.cfg"])
+    net = make_decoder(up, hid)
+    fm = [cu(g[f"{tag}.{p}"]) for p in T.PLANES]
+    out = net.decode(cu(g[f"{tag}.pts"]), fm, aabb=torch.from_numpy(g[f"{tag}.aabb"]))
+    assert relerr(out.cpu().numpy(), g[f"{tag}.out"]) < TOL_FWD
+    out = net.decode(cu(g[f"{tag}.pts"][:33]), fm)                      # module buffer aabb
+    assert relerr(out.cpu().numpy(), g[f"{tag}.out_default_aabb"]) < TOL_FWD
+
+
+def test_decoder_grid_vs_oracle(oracle):
+    """decode_grid over a non-cubic aabb: grid coordinates restated from src/encoding/utils3d.py:13-25,
+    values checked against the oracle's decode on those points; full-width decoder (up 64, hidden 256)."""
+    up, hid, (H, W, D), reso = 64, 256, (20, 12, 16), 24
+    net = make_decoder(up, hid)
+    fm = [0.8 * np.tanh(T.synthetic_noise(s, 40 + i)) for i, s in enumerate(((1, 12, H, W), (1, 12, H, D), (1, 12, W, D)))]
+    aabb = torch.tensor([-1.0, -0.6, -0.8, 1.0, 0.6, 0.8])
+    grid = net.decode_grid([cu(f) for f in fm], reso, aabb=aabb).cpu().numpy()
+    size = aabb[3:] - aabb[:3]
+    res = (reso * size / size.max()).long()
+    assert grid.shape == (int(res[0]), int(res[1]), int(res[2]), 4) == (24, 14, 19, 4)
+    axes = [torch.linspace(0.5, float(r) - 0.5, int(r)) / r * size[i] + aabb[i] for i, r in enumerate(res)]
+    pts = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=-1).reshape(-1, 3).numpy()
+    sd = oracle.Params(T.synthetic_state_dict(T.ae_param_shapes(4, 8, up, hid, 4), 5, as_torch=False))
+    want = oracle.ae_decode(sd, pts, *fm, aabb.numpy(), 4, 8, up, hid, 4)
+    want[:, 1:] = np.clip(want[:, 1:], 0, 1)
+    assert relerr(grid.reshape(-1, 4), want) < TOL_FWD
+    pts_out = net.decode(cu(pts), [cu(f) for f in fm], aabb=aabb, clamp_color=True).cpu().numpy()
+    # the in-kernel grid coordinates may differ from torch's CPU linspace/div by one ulp
+    assert relerr(pts_out, grid.reshape(-1, 4)) < 1e-5, "grid mode and point mode must agree"

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE config 5 side): AutoEncoderGroupSkip.decode over a cell-centred grid.
+Prints one JSON line: points/s, achieved TFLOP/s on the 1.182 MFLOP/point of the two MLPs."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from sin3dm_amd import testing as T
+from sin3dm_amd.encoding.networks import AutoEncoderGroupSkip
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reso", type=int, default=256)
+ap.add_argument("--hwd", type=int, nargs=3, default=(128, 128, 128))
+ap.add_argument("--aabb-scale", type=float, nargs=3, default=(1, 1, 1))
+ap.add_argument("--iters", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+net = AutoEncoderGroupSkip(4, 8, 64, 256, 4)
+net.load_state_dict(T.synthetic_state_dict(T.ae_param_shapes(), 5), strict=False)
+net.to(dev).eval()
+H, W, D = a.hwd
+fm = [torch.from_numpy(0.8 * np.tanh(T.synthetic_noise(s, 40 + i))).to(dev) for i, s in enumerate(((1, 12, H, W), (1, 12, H, D), (1, 12, W, D)))]
+aabb = torch.tensor([-s for s in a.aabb_scale] + list(a.aabb_scale), dtype=torch.float32)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+net.prepare(fm); torch.cuda.synchronize(); t_prep = time.perf_counter() - t0
+out = net.decode_grid(fm, a.reso, aabb=aabb); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    out = net.decode_grid(fm, a.reso, aabb=aabb)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.iters
+n = out.shape[0] * out.shape[1] * out.shape[2]
+flop_pt = 2.0 * 2 * (64 * 256 + 3 * 256 * 256 + 320 * 256) + 2.0 * 256 * 4
+print(json.dumps({"metric": "decode_grid points/s", "value": n / dt, "grid": list(out.shape[:3]), "seconds": dt,
+                  "prepare_first_call_s": t_prep, "tflops": n * flop_pt / dt / 1e12, "frac_of_157.3": n * flop_pt / dt / 157.3e12,
+                  "finite": bool(torch.isfinite(out).all())}))
