@@ -301,6 +301,137 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
     }
 }
 
+// ------------------------------------------------------------------ rank-1 rollout tables (skinny GEMMs)
+// out[b][pos][n] = sum_{tap, c} W[tap][n][c] * v[b][pos + tap - 1][c]   (zero outside [0, L)), n = variant*cout + co.
+// M = L is only ~128 rows, so the work is split along K instead: a block owns 128 positions x 32 columns and its four
+// waves each contract a quarter of K = 3*C, operands fetched straight from L2 into MFMA registers (no staging, no
+// barriers in the loop; one weight fragment feeds four row tiles).  The four partial accumulators are then added
+// through LDS in wave order.
+// One block = 32 positions x 32 columns.  K = 3 taps x C is walked in stages of (tap, <=128-channel chunk): whole
+// 512-byte rows of the vector (with its +-1 halo, loaded once per chunk) and of the weights are staged in LDS with
+// coalesced loads, register-prefetched one stage ahead; inside a stage the four waves each contract a quarter of the
+// chunk, and their partial accumulators are added through LDS in wave order at the end.
+constexpr int kR1Chunk = 128, kR1Ld = kR1Chunk + 4;
+__global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
+    __shared__ __attribute__((aligned(16))) float sA[34 * kR1Ld];
+    __shared__ __attribute__((aligned(16))) float sB[2][32 * kR1Ld];
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img, mtile = local % J.tiles_per_img;
+    const int L = J.w, cin = args.cin, cout4 = args.cout;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, half = lane >> 5;
+    const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
+    constexpr int q4 = kR1Chunk / 4;                        // float4 slots per staged row
+    const float* vb = J.in + size_t(b) * L * cin;
+    const size_t tapStride = size_t(cout4) * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // staging items: A has 34 rows (positions mtile*32-1 .. +32), B 32 rows (columns ntile*32 ..); <= 5 + 4 float4 each
+    constexpr int NA = (34 * (kR1Chunk / 4) + 255) / 256, NB = (32 * (kR1Chunk / 4) + 255) / 256;
+    f32x4 ra[NA], rb[NB];
+    auto loadA = [&](int chunk) {
+        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            const int pos = mtile * 32 - 1 + row;
+            const bool ok = row < 34 && pos >= 0 && pos < L && q < wq;
+            ra[it] = to_global4(vb + size_t(ok ? pos : 0) * cin + c0 + (ok ? q : 0) * 4)[0];
+            if (!ok) ra[it] = zero4;
+        }
+    };
+    auto loadB = [&](int tap, int chunk) {
+        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            const int n = ntile * 32 + row;
+            const bool ok = row < 32 && n < cout4 && q < wq;
+            rb[it] = to_global4(J.wgt + tap * tapStride + size_t(ok ? n : 0) * cin + c0 + (ok ? q : 0) * 4)[0];
+            if (!ok) rb[it] = zero4;
+        }
+    };
+    auto storeA = [&]() {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            if (row < 34) *reinterpret_cast<f32x4*>(sA + row * kR1Ld + q * 4) = ra[it];
+        }
+    };
+    auto storeB = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            if (row < 32) *reinterpret_cast<f32x4*>(sB[buf] + row * kR1Ld + q * 4) = rb[it];
+        }
+    };
+
+    const int nstages = nchunks * 3;                       // stage s -> chunk = s / 3, tap = s % 3
+    loadA(0); loadB(0, 0);
+    storeA(); storeB(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / 3, tap = s - chunk * 3;
+        const int ns = s + 1 < nstages ? s + 1 : s;
+        const int nchunk = ns / 3, ntap = ns - nchunk * 3;
+        loadB(ntap, nchunk);
+        const bool newA = nchunk != chunk;
+        if (newA) loadA(nchunk);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's quarter of the chunk: k8 steps [wid*cw/32, (wid+1)*cw/32)
+        const float* Ar = sA + (i + tap) * kR1Ld + half * 4;
+        const float* Br = sB[s & 1] + i * kR1Ld + half * 4;
+        const int k8n = min(cin - chunk * kR1Chunk, kR1Chunk) / 32;
+        for (int k8 = 0; k8 < k8n; ++k8) {
+            const int c = (wid * k8n + k8) * 8;
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ar + c);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(Br + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (newA) __syncthreads();                          // everyone is done reading the old A tile
+        storeB((s + 1) & 1);
+        if (newA) storeA();
+        __syncthreads();
+    }
+    // add the four waves' partials (reuse sB as [4][16][64] floats = 16 KB)
+    float* red = &sB[0][0];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    for (int it = tid; it < 1024; it += 256) {
+        const int r = it >> 6, l = it & 63;
+        const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
+        if (row < L && col < cout4) J.out[(size_t(b) * L + row) * cout4 + col] = v;
+    }
+}
+
+int launch_rank1(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % KC == 0, S3D_ERR_INVALID, "rank1: bad arguments");
+    if (conv_use_naive()) return launch_conv_naive(CONV_1x3_VEC, a, st);
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        J.tiles_x = J.tiles_per_img = (J.w + 31) / 32;
+        J.n_tiles_n = (a.cout + 31) / 32;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(k_rank1, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3]) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
@@ -372,7 +503,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
         case CONV_1x1:
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
         case CONV_1x3_VEC:
-            return launch_cfg<ConvCfg<1, 32, 1, 3, 1, 4, 1, 1>>(a, st);
+            return launch_rank1(a, st);
         case CONV_5x5:
             return launch_cfg<ConvCfg<8, 8, 5, 5, 2, 2, 1, 1>>(a, st);
     }

@@ -1,0 +1,68 @@
+"""Multi-GPU sharding of the sampling path: independent samples striped over ranks, no data-path collective.
+
+The reference is single-process (its DDP/dist code is commented out: src/diffusion/train_util.py:8-9,
+src/utils/dist_util.py:29-42).  Samples are independent (src/sample.py:33-47 loops over batches; GroupNorm
+statistics and rollout means are per sample), so N GPUs = N processes that each take a stripe of the sample
+indices.  Seeds are a function of the SAMPLE index, never of the rank or world size, so the set of results is
+identical for any N.  One process per GPU, launched with `python -m torch.distributed.run`; the backend is
+"nccl" (= RCCL over xGMI) on GPUs and "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None, device=None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    rank, local, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, local, world
+
+
+def shard_indices(n_samples, rank, world):
+    """Sample indices of this rank: i with i % world == rank (round-robin keeps per-rank counts within one)."""
+    return list(range(rank, n_samples, world))
+
+
+def sample_seed(base_seed, sample_index):
+    """Per-sample generator seed (1000 + sample index)."""
+    return int(base_seed) + int(sample_index)
+
+
+def batches(indices, batch_size):
+    for i in range(0, len(indices), batch_size):
+        yield indices[i:i + batch_size]
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a python float (used for the wall time of a timed region)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_objects(obj):
+    """All ranks' python objects on every rank (file paths of the written samples; host side only)."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out

@@ -1,0 +1,90 @@
+"""Sampling CLI with the reference's flags and on-disk layout (src/sample.py):
+
+    python -m sin3dm_amd.sample --tag EXP --n_samples N [--use_ddim True --timestep_respacing 100] [--resize a b c] [--vox]
+    python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.sample --tag EXP --n_samples 64 ...
+
+Reads EXP/encoding/{args.json,feat.npz}, EXP/diffusion/{args.json,ema_<rate>_<iters>.pt} and the AE checkpoint
+EXP/encoding/model/ckpt_final.pth written by the reference's train.py; writes EXP/<output>/NNN/feat.npz (and
+r<reso>_voxel.npz with --vox).  Multi-GPU: sample indices are striped over the ranks (sin3dm_amd/parallel.py).
+Mesh/texture export (PyMCubes, xatlas, nvdiffrast) is out of scope: without --vox the decode
+stage stops after writing feat.npz.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import parallel
+from .utils import dist_util
+from .utils.parser_util import (diffusion_model_path, encoding_feat_path, encoding_log_dir, sample_args)
+
+
+def sample_diffusion(args, rank=0, world=1, base_seed=1000):
+    """Reference: src/sample.py:6-48, with per-sample seeds and rank striping."""
+    from .diffusion.script_util import create_model_and_diffusion_from_args
+    from .utils.triplane_util import decompose_featmaps, load_triplane_data, save_triplane_data
+
+    dev = dist_util.dev()
+    src_data, sizes = load_triplane_data(encoding_feat_path(args.tag), device=dev)
+    model, diffusion = create_model_and_diffusion_from_args(args)
+    model.load_state_dict(dist_util.load_state_dict(diffusion_model_path(args.tag, args.ema_rate, args.diff_n_iters),
+                                                    map_location="cpu"))
+    model.to(dev).eval()
+    sample_fn = diffusion.ddim_sample_loop if args.use_ddim else diffusion.p_sample_loop
+
+    result_dir = os.path.join(args.tag, args.output)
+    os.makedirs(result_dir, exist_ok=True)
+    C = src_data.shape[0]
+    H, W, D = (int(s * r) for s, r in zip(sizes, args.resize))
+    if rank == 0:
+        print("H, W, D:", H, W, D)
+
+    paths = []
+    mine = parallel.shard_indices(args.n_samples, rank, world)
+    for idx in parallel.batches(mine, args.diff_batch_size):
+        # x_T per sample from its own seed, so the outputs do not depend on the number of GPUs
+        noise = torch.stack([torch.randn(C, H + D, W + D, device=dev,
+                                         generator=torch.Generator(device=dev).manual_seed(parallel.sample_seed(base_seed, i)))
+                             for i in idx])
+        samples = sample_fn(model, list(noise.shape), noise=noise, progress=rank == 0,
+                            model_kwargs={"H": H, "W": W, "D": D})
+        xy, xz, yz = (t.detach().cpu().numpy() for t in decompose_featmaps(samples, (H, W, D)))
+        for j, i in enumerate(idx):
+            path = os.path.join(result_dir, f"{i:03d}", "feat.npz")
+            save_triplane_data(path, xy[j], xz[j], yz[j])
+            paths.append(path)
+    return paths
+
+
+def decode(args, paths):
+    """Reference: src/sample.py:51-78 (voxel branch; mesh export is out of scope)."""
+    from .encoding.model import ShapeAutoEncoder
+    from .utils.triplane_util import load_triplane_data
+
+    if not args.vox:
+        print("decode: mesh/texture export needs PyMCubes/xatlas/nvdiffrast (out of scope); pass --vox for voxels")
+        return
+    ae = ShapeAutoEncoder(encoding_log_dir(args.tag), args, device=dist_util.dev())
+    ae.load_ckpt("final")
+    for path in paths:
+        fm = [f.unsqueeze(0) for f in load_triplane_data(path, device=dist_util.dev(), compose=False)]
+        ae.decode_voxel(os.path.dirname(path), fm, args.reso)
+
+
+def main(argv=None):
+    args = sample_args(argv)
+    rank, local, world = parallel.env_rank_world()
+    dist_util.setup_dist(local if world > 1 else args.gpu_id)
+    parallel.init(device=dist_util.dev())
+    paths = sample_diffusion(args, rank, world)
+    decode(args, paths)
+    all_paths = sorted(p for ps in parallel.gather_objects(paths) for p in ps)
+    if rank == 0:
+        print(f"wrote {len(all_paths)} samples under {os.path.join(args.tag, args.output)}")
+    parallel.barrier()
+    return all_paths
+
+
+if __name__ == "__main__":
+    main()

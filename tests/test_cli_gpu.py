@@ -1,0 +1,54 @@
+"""GPU: the sample.py pipeline end to end on an experiment directory laid out like the reference's
+(BASELINE config 1 plumbing: (46,64,46) triplane, 64-ch UNet, DDIM-10, then voxel decode)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from sin3dm_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+
+
+def make_experiment(root, hwd=(46, 64, 46), mc=64):
+    from sin3dm_amd.utils import parser_util as pu
+    tag = os.path.join(root, "exp")
+    pu.train_args(["--tag", tag, "--data_path", "towerruins.npz", "--model_channels", str(mc), "--fm_reso", "64"])
+    H, W, D = hwd
+    np.savez_compressed(pu.encoding_feat_path(tag), feat_xy=np.tanh(T.synthetic_noise((12, H, W), 1)),
+                        feat_xz=np.tanh(T.synthetic_noise((12, H, D), 2)), feat_yz=np.tanh(T.synthetic_noise((12, W, D), 3)))
+    torch.save(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0), pu.diffusion_model_path(tag, 0.9999, 25000))
+    os.makedirs(os.path.join(pu.encoding_log_dir(tag), "model"), exist_ok=True)
+    net = T.synthetic_state_dict(T.ae_param_shapes(), 5)
+    net["geo_encoder.weight"] = torch.zeros(4, 1, 4, 4, 4); net["geo_encoder.bias"] = torch.zeros(4)
+    net["tex_encoder.weight"] = torch.zeros(8, 4, 4, 4, 4); net["tex_encoder.bias"] = torch.zeros(8)
+    net["aabb"] = torch.tensor([-0.72, -1.0, -0.72, 0.72, 1.0, 0.72])
+    torch.save({"net": net, "aabb": net["aabb"].numpy(), "featmap_size": hwd, "Ka": None, "Kd": None, "Ks": None, "Ns": None},
+               os.path.join(pu.encoding_log_dir(tag), "model", "ckpt_final.pth"))
+    return tag
+
+
+def test_sample_cli_ddim10_voxels(tmp_path):
+    from sin3dm_amd import sample
+    tag = make_experiment(str(tmp_path))
+    paths = sample.main(["--tag", tag, "--n_samples", "2", "--use_ddim", "True", "--timestep_respacing", "10",
+                         "--vox", "--reso", "32", "--output", "results"])
+    assert [os.path.relpath(p, tag) for p in paths] == ["results/000/feat.npz", "results/001/feat.npz"]
+    feats = []
+    for p in paths:
+        d = np.load(p)
+        assert d["feat_xy"].shape == (12, 46, 64) and d["feat_xz"].shape == (12, 46, 46) and d["feat_yz"].shape == (12, 64, 46)
+        assert all(np.isfinite(d[k]).all() for k in d.files)
+        feats.append(d["feat_xy"])
+        vox = np.load(os.path.join(os.path.dirname(p), "r32_voxel.npz"))["voxel"]
+        assert vox.shape == (23, 32, 23) and vox.dtype == bool         # floor(32 * 1.44 / 2.0) = 23
+    assert not np.array_equal(feats[0], feats[1])                       # different per-sample seeds
+    # retargeting (--resize 1 1.5 1): fully convolutional path, aabb scaled with the feature map
+    paths = sample.main(["--tag", tag, "--n_samples", "1", "--use_ddim", "True", "--timestep_respacing", "10",
+                         "--resize", "1", "1.5", "1", "--vox", "--reso", "32", "--output", "retarget"])
+    d = np.load(paths[0])
+    assert d["feat_xy"].shape == (12, 46, 96) and d["feat_yz"].shape == (12, 96, 46)
+    vox = np.load(os.path.join(os.path.dirname(paths[0]), "r32_voxel.npz"))["voxel"]
+    assert vox.shape == (15, 32, 15)                                    # y extent 1.5x: floor(32 * 1.44 / 3.0) = 15

@@ -1,0 +1,73 @@
+"""CPU-only, world_size 2 over gloo: the N>1 sampling path (striping, per-sample seeds, max-over-ranks timing,
+path gather) behaves as the single-process path."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import REPO
+
+WORKER = r"""
+import json, os, sys, time
+sys.path.insert(0, os.environ["S3D_REPO"])
+import torch
+from sin3dm_amd import parallel
+rank, local, world = parallel.init(backend="gloo")
+assert world == 2 and rank == int(os.environ["RANK"])
+mine = parallel.shard_indices(7, rank, world)
+# per-sample noise depends on the sample index only
+noise = {i: torch.randn(4, generator=torch.Generator().manual_seed(parallel.sample_seed(1000, i))).tolist() for i in mine}
+parallel.barrier()
+t = parallel.max_over_ranks(0.25 + rank)            # rank 1 is the slow one
+allp = parallel.gather_objects({"rank": rank, "mine": mine, "noise": noise})
+if rank == 0:
+    print("RESULT " + json.dumps({"t": t, "all": allp}))
+parallel.barrier()
+"""
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_striping(tmp_path):
+    import json
+    import torch
+    from sin3dm_amd import parallel
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0]
+    res = json.loads(line[len("RESULT "):])
+    assert res["t"] == pytest.approx(1.25)                      # MAX over ranks
+    got = sorted(i for r in res["all"] for i in r["mine"])
+    assert got == list(range(7))                                 # every sample exactly once
+    assert res["all"][0]["mine"] == [0, 2, 4, 6] and res["all"][1]["mine"] == [1, 3, 5]
+    # identical to what one process would draw for the same sample indices
+    for r in res["all"]:
+        for i, v in r["noise"].items():
+            ref = torch.randn(4, generator=torch.Generator().manual_seed(parallel.sample_seed(1000, int(i)))).tolist()
+            assert v == ref
+
+
+def test_shard_helpers():
+    from sin3dm_amd import parallel
+    for n in (0, 1, 5, 64):
+        for world in (1, 2, 4, 8):
+            parts = [parallel.shard_indices(n, r, world) for r in range(world)]
+            assert sorted(i for p in parts for i in p) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert list(parallel.batches(list(range(5)), 2)) == [[0, 1], [2, 3], [4]]
