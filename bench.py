@@ -170,8 +170,14 @@ def main():
         roof = None
         if prof.launches[0] > 0:
             ach = prof.flops[0] / (prof.ms[0] * 1e-3) / 1e12
+            traffic = None
+            try:    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH/WRITE_SIZE)
+                traffic = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["dominant_traffic_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)",
                     "kernel": "k_conv_mfma<3x3> (dense part of the rollout TriplaneConv)",
                     "avg_launch_us": round(prof.ms[0] / prof.launches[0] * 1e3, 2),
                     "launches_timed": int(prof.launches[0]),

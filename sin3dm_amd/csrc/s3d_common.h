@@ -190,6 +190,8 @@ int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st);
 // bilinear (align_corners=False) resize into a channel slice of a wider NHWC tensor
 int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, int ho, int wo, int out_cstride,
                     int out_coff, hipStream_t st);
+// exact-2x bilinear upsample of u fused with the concat [up(u) | skip] for all three planes (out.C = u.C + sk.C)
+int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st);
 int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, int out_cstride, int out_coff,
                       hipStream_t st);
 

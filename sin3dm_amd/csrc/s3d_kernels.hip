@@ -10,7 +10,9 @@
 
 namespace s3d {
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+// x * sigmoid(x) on the hardware exp/rcp units (v_exp_f32 / v_rcp_f32, ~1-2 ulp each): the activation kernels
+// are otherwise VALU-bound on the IEEE expf + division sequence.  Limits: exp(-v) -> inf gives v * 0, -> 0 gives v.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
@@ -124,6 +126,7 @@ __global__ void k_gn_partials(GnPartArgs a) {
     const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     const float4* src = reinterpret_cast<const float4*>(a.x[p] + size_t(b) * npix * a.C) + q;
+#pragma unroll 8
     for (int pix = p0 + l; pix < p1; pix += a.pl) {
         const float4 v = src[size_t(pix) * a.cq];
         s[0] += v.x; ss[0] += double(v.x) * v.x;
@@ -449,6 +452,61 @@ int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, i
     S3D_HIP(hipGetLastError());
     return 0;
 }
+// TriplaneUpsample2x + concat in one pass over all three planes: out[..., 0:Cu] = bilinear2x(u), out[..., Cu:] = skip
+// (src/diffusion/unet_triplane.py:106-124, 501-503).  Used when 2x the low-resolution size equals the skip's size.
+struct UpCatArgs {
+    const float* u[3]; const float* sk[3]; float* out[3];
+    int hi[3], wi[3];          // low-resolution sizes; outputs are 2x
+    int cuq, csq, B;           // float4 per pixel of the upsampled / skip parts
+    long long begin[4];
+};
+__global__ void k_upcat(UpCatArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.begin[3] * a.B) return;
+    const int b = int(i / a.begin[3]);
+    long long r = i % a.begin[3];
+    const int p = r >= a.begin[2] ? 2 : (r >= a.begin[1] ? 1 : 0);
+    r -= a.begin[p];
+    const int oq = a.cuq + a.csq;
+    const int q = int(r % oq);
+    const long long pix = r / oq;
+    const int ho = 2 * a.hi[p], wo = 2 * a.wi[p];
+    const int xo = int(pix % wo), yo = int(pix / wo);
+    float4 o;
+    if (q >= a.cuq) {
+        o = reinterpret_cast<const float4*>(a.sk[p])[((size_t(b) * ho + yo) * wo + xo) * a.csq + (q - a.cuq)];
+    } else {
+        const int hi = a.hi[p], wi = a.wi[p];
+        float fy = 0.5f * (float(yo) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = 0.5f * (float(xo) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+        int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+        const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+        const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+        const float4* src = reinterpret_cast<const float4*>(a.u[p]) + size_t(b) * hi * wi * a.cuq + q;
+        const float4 v00 = src[(size_t(y0) * wi + x0) * a.cuq], v01 = src[(size_t(y0) * wi + x1) * a.cuq];
+        const float4 v10 = src[(size_t(y1) * wi + x0) * a.cuq], v11 = src[(size_t(y1) * wi + x1) * a.cuq];
+        o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+        o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+        o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+        o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    }
+    reinterpret_cast<float4*>(a.out[p])[((size_t(b) * ho + yo) * wo + xo) * oq + q] = o;
+}
+int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st) {
+    UpCatArgs a;
+    a.cuq = u.C / 4; a.csq = sk.C / 4; a.B = B; a.begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.u[p] = u.p[p]; a.sk[p] = sk.p[p]; a.out[p] = out.p[p]; a.hi[p] = u.g.h[p]; a.wi[p] = u.g.w[p];
+        a.begin[p + 1] = a.begin[p] + (long long)4 * u.g.h[p] * u.g.w[p] * (a.cuq + a.csq);
+    }
+    const long long n = a.begin[3] * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_upcat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 __global__ void k_copy_slice(const float* __restrict__ in, float* __restrict__ out, long long npix, int cq, int out_cq,
                              int out_q0) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -522,14 +580,15 @@ __global__ void k_out_head(OutHeadArgs a) {
         const int nco = min(kOutCo, a.Cout - co0);
         for (int k = 0; k < nco; ++k) {
             const float4 wv = reinterpret_cast<const float4*>(a.w + (size_t(p) * a.Cout + co0 + k) * a.C)[q];
-            sm[(size_t(lp) * kOutCo + k) * a.cq + q] = act[0] * wv.x + act[1] * wv.y + act[2] * wv.z + act[3] * wv.w;
+            // rows of cq+1 floats: the column-wise reads of the reduction below hit distinct banks
+            sm[(size_t(k) * a.ppb + lp) * (a.cq + 1) + q] = act[0] * wv.x + act[1] * wv.y + act[2] * wv.z + act[3] * wv.w;
         }
         __syncthreads();
         for (int it = threadIdx.x; it < a.ppb * nco; it += blockDim.x) {
             const int k = it / a.ppb, l2 = it % a.ppb;           // consecutive threads -> consecutive pixels
             const int px = blockIdx.x * a.ppb + l2;
             if (px >= npix) continue;
-            const float* row = sm + (size_t(l2) * kOutCo + k) * a.cq;
+            const float* row = sm + (size_t(k) * a.ppb + l2) * (a.cq + 1);
             float acc = a.bias[p * a.Cout + co0 + k];
             for (int j = 0; j < a.cq; ++j) acc += row[j];
             const int y = px / w, xx = px % w;
@@ -553,7 +612,7 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
     thread_shape(x.C, a.cq, a.ppb);
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "out head: C=%d unsupported", x.C);
     if (!maxpix || !B) return 0;
-    size_t shm = std::max(size_t(64), size_t(a.ppb) * kOutCo * a.cq) * sizeof(float);
+    size_t shm = std::max(size_t(64), size_t(a.ppb) * kOutCo * (a.cq + 1)) * sizeof(float);
     hipLaunchKernelGGL(k_out_head, dim3(cdiv(maxpix, a.ppb), 4, B), dim3(a.cq * a.ppb), shm, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

@@ -442,6 +442,9 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
             Tri sk = hs.back(); hs.pop_back();
             inp = f.alloc_tri(h.C + sk.C, sk.g);
             const Geo up = h.g.twice();
+            if (up == sk.g) {                                       // the common case: one fused pass for all planes
+                if (!meas) S3D_TRY(launch_upcat(h, sk, B, inp, st));
+            } else
             for (int p = 0; p < 3; ++p) {
                 const bool same = up.h[p] == sk.g.h[p] && up.w[p] == sk.g.w[p];
                 if (same) {
