@@ -175,18 +175,24 @@ def main():
                 traffic = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["dominant_traffic_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
+            wino = os.environ.get("S3D_WINO", "1") != "0"
+            exec_frac = 4.0 / 9.0 if wino else 1.0        # Winograd F(2x2,3x3): 16 MFMA multiplies per 4 outputs instead of 36
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "mfma_executed_tflops": round(ach * exec_frac, 2),
+                    "mfma_executed_frac": round(ach * exec_frac / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)",
-                    "kernel": "k_conv_mfma<3x3> (dense part of the rollout TriplaneConv)",
+                    "kernel": ("k_conv_wino (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
+                              ", dense own-channel part of the rollout TriplaneConv)",
                     "avg_launch_us": round(prof.ms[0] / prof.launches[0] * 1e3, 2),
                     "launches_timed": int(prof.launches[0]),
                     "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
                     "conv3x3_ms_per_step": round(prof.ms[0] / max(prof.forwards, 1), 4),
                     "rank1_ms_per_step": round(prof.ms[2] / max(prof.forwards, 1), 4),
                     "conv1x1_ms_per_step": round(prof.ms[1] / max(prof.forwards, 1), 4),
-                    "note": "achieved = EXECUTED algorithmic flops (rank-1 rollout exploited) / HIP-event time; "
-                            "dense-equivalent (reference-executed F_dense) rate is in effective_dense_tflops"}
+                    "note": "achieved = algorithmic flops of the launches (2*9*C*Cout per output pixel, own channels only: "
+                            "rank-1 rollout exploited) / HIP-event time; mfma_executed_* = what the matrix cores really "
+                            "multiply (x4/9 under Winograd); the reference-executed F_dense rate is effective_dense_tflops"}
         line = {"metric": "DDPM-1000 triplane samples/sec @128^2 latent", "value": value, "unit": "samples/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",

@@ -435,6 +435,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st) {
 void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3]) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
+    if (conv_use_wino()) { wino_gn_parts(g, nparts); return; }
     using CFG = ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>;
     for (int p = 0; p < 3; ++p)
         nparts[p] = ((g.w[p] + CFG::TW - 1) / CFG::TW) * ((g.h[p] + CFG::TH - 1) / CFG::TH) * CFG::WM;
@@ -499,6 +500,10 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
+            if (conv_use_wino() && a.job[0].wgt_wino) {
+                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino;
+                return launch_conv_wino(a, st);
+            }
             return launch_cfg<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>>(a, st);
         case CONV_1x1:
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);

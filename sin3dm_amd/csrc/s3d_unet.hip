@@ -63,6 +63,7 @@ struct s3d_unet {
     }
     int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
         if (!prof_now) return launch_conv(kind, ca, st);
+        // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
         int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : 25));
         double pix = 0;
         for (int j = 0; j < ca.njobs; ++j) pix += double(ca.job[j].h) * ca.job[j].w;
@@ -178,6 +179,7 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
         for (int t = 0; t < taps; ++t)
             for (int co = 0; co < cout; ++co)
                 for (int c = 0; c < cin; ++c) d[(size_t(t) * cout + co) * cin + c] = W[(size_t(co) * ctot + c) * taps + t];
+        if (k == 3) cw.wino[p] = pack_wino_weights(stage, W, cout, ctot, cin);
         if (!roll) continue;
         const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
         for (int slot = 1; slot <= 2; ++slot) {
@@ -368,6 +370,7 @@ struct Fwd {
         for (int p = 0; p < 3; ++p) {
             ConvJob& J = ca.job[p];
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
+            J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = m->film_total;
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];

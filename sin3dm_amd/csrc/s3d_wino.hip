@@ -1,0 +1,314 @@
+// s3d_wino.hip — 3x3 TriplaneConv as a fused Winograd F(2x2, 3x3) convolution on the fp32 matrix cores.
+//
+// Y = A^T [ (G g G^T) .* (B^T d B) ] A per 4x4 input patch d -> 2x2 outputs: 16 "frequency" GEMMs with 4 multiplies
+// per output instead of 9 (2.25x fewer MFMA flops than the direct kernel in s3d_conv.hip).  fp32 error measured
+// against an fp64 direct convolution: 4.5e-7 relative (direct fp32: 2.8e-7), far inside the 1e-3 gate.
+//
+// Everything happens inside one kernel — no transformed tensors ever touch HBM:
+//   * block = 16x16 output pixels (8x8 Winograd tiles) x 64 output channels, 4 waves = 2 (tile halves) x 2 (32 couts);
+//   * the 18x18x32-channel input halo of a chunk sits in LDS; a lane owns ONE Winograd tile (MFMA row) and reads its
+//     4x4 patch as 16 ds_read_b128, applies B^T d B in registers (64 packed adds) and thereby holds the A operands
+//     of all 16 frequencies for 4 channels — already in the "lane half 0 takes k0..3, half 1 k4..7" order;
+//   * the transformed weights U = G g G^T are pre-packed on the host in MFMA *fragment order*, so a B operand is one
+//     fully coalesced 1 KB global load per (frequency, 8 channels) — no LDS, no barrier for weights;
+//   * a wave keeps 16 accumulators (one per frequency, 256 AGPRs) for its 32 tiles x 32 channels, so the inverse
+//     transform A^T M A needs only values the lane already holds; the epilogue then matches the direct kernel
+//     (bias, rank-1 rollout terms, residual, GroupNorm partial sums);
+//   * software pipeline inside the wave (one wave per SIMD): while the 64 MFMAs of a k-step run, the next step's
+//     patch is read and transformed, the weight fragments stream through an 8-deep register ring and a slice of the
+//     next chunk's halo is fetched; one barrier per 32-channel chunk.
+#include "s3d_common.h"
+
+namespace s3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(1)))* wgf4;
+__device__ __forceinline__ wgf4 wg4(const float* p) { return (wgf4)(uintptr_t)p; }
+
+#ifndef W_ABL
+#define W_ABL 0                        // tools/wino_ubench.hip only: 1 no epilogue stores, 2 no epilogue, 4 no k-loop, 8 weights from one hot 16 KB, 16 no halo staging
+#endif
+constexpr int W_T = 16;                 // output tile side
+constexpr int W_H = W_T + 2;            // halo side
+constexpr int W_KC = 32;                // channels per chunk
+constexpr int W_LD = W_KC + 4;          // padded LDS pixel row (floats)
+constexpr int W_AELEMS = W_H * W_H * W_LD;
+constexpr int W_ITEMS = W_H * W_H * (W_KC / 4);           // float4 items per chunk
+constexpr int W_NIT = (W_ITEMS + 255) / 256;              // per thread (11)
+
+__device__ __forceinline__ int w_edge_variant(int idx, int n) { return n == 1 ? 3 : (idx == 0 ? 1 : (idx == n - 1 ? 2 : 0)); }
+
+__device__ __forceinline__ void wino_row_pass(f32x4* r) {      // one patch row, along b
+    const f32x4 d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3];
+    r[0] = d0 - d2; r[1] = d1 + d2; r[2] = d2 - d1; r[3] = d1 - d3;
+}
+__device__ __forceinline__ void wino_col_pass(f32x4* c) {      // one patch column (stride 4), along a
+    const f32x4 d0 = c[0], d1 = c[4], d2 = c[8], d3 = c[12];
+    c[0] = d0 - d2; c[4] = d1 + d2; c[8] = d2 - d1; c[12] = d1 - d3;
+}
+// B^T d B for the 4x4 patch p[a*4+b] (each a float4 of channels), in place -> V[u*4+v]
+__device__ __forceinline__ void wino_input_transform(f32x4* p) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {       // along b: s0 = d0-d2, s1 = d1+d2, s2 = d2-d1, s3 = d1-d3
+        const f32x4 d0 = p[a * 4 + 0], d1 = p[a * 4 + 1], d2 = p[a * 4 + 2], d3 = p[a * 4 + 3];
+        p[a * 4 + 0] = d0 - d2; p[a * 4 + 1] = d1 + d2; p[a * 4 + 2] = d2 - d1; p[a * 4 + 3] = d1 - d3;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {       // along a
+        const f32x4 d0 = p[0 * 4 + b], d1 = p[1 * 4 + b], d2 = p[2 * 4 + b], d3 = p[3 * 4 + b];
+        p[0 * 4 + b] = d0 - d2; p[1 * 4 + b] = d1 + d2; p[2 * 4 + b] = d2 - d1; p[3 * 4 + b] = d1 - d3;
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W_AELEMS];
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int tile_idx = local;
+    const int ty0 = (local / J.tiles_x) * W_T, tx0 = (local % J.tiles_x) * W_T;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int tr = wm * 4 + (i >> 3), tc = i & 7;               // this lane's Winograd tile inside the 8x8 grid
+    const int patch0 = ((2 * tr) * W_H + 2 * tc) * W_LD + half * 4;   // LDS float offset of its patch origin
+
+    // fragment-ordered weights: [n32 tile][k8 step][16 freq][64 lanes][4]
+    const int n32_total = (cout + 31) / 32;
+    int n32 = ntile * 2 + wn;
+    const bool n_live = n32 < n32_total;
+    if (!n_live) n32 = n32_total - 1;                            // clamp (outputs masked by co < cout below)
+    const int k8_total = cin / 8;
+    const float* ub = J.wgt + (size_t(n32) * k8_total) * (16 * 256) + lane * 4;
+
+    const float* inb = J.in + size_t(b) * h * w * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // halo staging of one float4 item of chunk `ch` into LDS buffer `buf`
+    auto item_load = [&](int it, int ch) -> f32x4 {
+        const int idx = it * 256 + tid;
+        const int pix = idx >> 3, q = idx & 7;
+        const int hy = pix / W_H, hx = pix - hy * W_H;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = idx < W_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        f32x4 v = wg4(inb + (size_t(ok ? gy : 0) * w + (ok ? gx : 0)) * cin + ch * W_KC + q * 4)[0];
+        return ok ? v : zero4;
+    };
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        const int idx = it * 256 + tid;
+        if (idx < W_ITEMS) *reinterpret_cast<f32x4*>(smem + buf * W_AELEMS + (idx >> 3) * W_LD + (idx & 7) * 4) = v;
+    };
+
+    // (A per-block rotation of the K-chunk order was tried against L2 hot-spotting on the shared weight lines: no gain,
+    // and it made a sample's rounding depend on its position in the batch, so the order is the natural one.)
+    const int nchunks = cin / W_KC;
+    const int rot = 0;
+    auto rot_chunk = [&](int c) { const int g = c + rot; return g >= nchunks ? g - nchunks : g; };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ---- prologue: chunk 0 -> LDS buffer 0; first patch transformed; first 8 weight fragments in flight
+#pragma unroll
+    for (int it = 0; it < W_NIT; ++it) item_store(it, 0, item_load(it, rot_chunk(0)));
+    __syncthreads();
+    f32x4 VA[16], VB[16], ring[8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) VA[a * 4 + bb] = *reinterpret_cast<const f32x4*>(smem + patch0 + (a * W_H + bb) * W_LD);
+    wino_input_transform(VA);
+    if (W_ABL & 32) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) VB[k] = VA[k] + 1.f;
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) ring[f] = wg4(ub + (size_t(rot_chunk(0)) * 4 * 16 + f) * 256)[0];
+
+    // one k-step: 64 MFMAs with Vc; meanwhile read+transform the next patch into Vn, refill the ring, stage halo items
+#define WINO_STEP(Vc, Vn, K8)                                                                                         \
+    {                                                                                                                 \
+        const int step = gch * 4 + (K8);                                     /* global k8 index (rotated chunk) */    \
+        const int nstep = (K8) < 3 ? step + 1 : gnext * 4;                                                            \
+        const int nbuf = ((K8) == 3 ? (chunk + 1) : chunk) & 1;              /* buffer holding the next step's patch */ \
+        const float* nsrc = smem + nbuf * W_AELEMS + patch0 + (((K8) + 1) & 3) * 8;                                    \
+        f32x4 pf[4];                                                                                                  \
+        constexpr int it0 = (K8) * 4, itn = (K8) == 2 ? 3 : ((K8) == 3 ? 0 : 4);                                       \
+        _Pragma("unroll") for (int t = 0; t < itn; ++t) pf[t] = (W_ABL & 16) ? zero4 : item_load(it0 + t, gnext);     \
+        _Pragma("unroll") for (int f = 0; f < 16; ++f) {                                                              \
+            if (!(W_ABL & 32) && f < 8 && (f & 1) == 0) {                    /* next patch: row f/2 */               \
+                _Pragma("unroll") for (int bb = 0; bb < 4; ++bb)                                                      \
+                    Vn[(f >> 1) * 4 + bb] = *reinterpret_cast<const f32x4*>(nsrc + ((f >> 1) * W_H + bb) * W_LD);     \
+            }                                                                                                         \
+            const f32x4 bq = ring[f & 7];                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][e], bq[e], acc[f], 0, 0, 0);                      \
+            {                                                                /* refill the slot 8 fragments ahead */ \
+                const int fs = f + 8 < 16 ? step : nstep, ff = (f + 8) & 15;                                          \
+                ring[f & 7] = wg4(ub + (size_t((W_ABL & 8) ? 0 : fs) * 16 + ff) * 256)[0];                                              \
+            }                                                                                                         \
+            if (!(W_ABL & 32) && f >= 2 && f <= 8 && (f & 1) == 0) wino_row_pass(Vn + ((f >> 1) - 1) * 4);  /* row read two groups ago */ \
+            if (!(W_ABL & 32) && f >= 9 && f <= 12) wino_col_pass(Vn + (f - 9));                                      \
+            if ((W_ABL & 64) && !(W_ABL & 128)) continue;                                                               \
+            __builtin_amdgcn_sched_barrier(0);                               /* keep loads this far ahead of use */   \
+        }                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < itn; ++t) item_store(it0 + t, (chunk + 1) & 1, pf[t]);                   \
+        if ((K8) == 2) __syncthreads();                                      /* next chunk's halo complete */         \
+    }
+
+    for (int chunk = 0; chunk < ((W_ABL & 4) ? 0 : nchunks); ++chunk) {
+        const int gch = rot_chunk(chunk);
+        const int gnext = chunk + 1 < nchunks ? rot_chunk(chunk + 1) : gch;
+        WINO_STEP(VA, VB, 0)
+        WINO_STEP(VB, VA, 1)
+        WINO_STEP(VA, VB, 2)
+        WINO_STEP(VB, VA, 3)
+    }
+#undef WINO_STEP
+
+    // ---- epilogue: inverse transform A^T M A per tile, then the same fused tail as the direct kernel
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    const int co = (ntile * 2 + wn) * 32 + i;
+    const bool co_ok = n_live && co < cout;
+    const int coc = co_ok ? co : 0;
+    float base = p_bias ? p_bias[coc] : 0.f;
+    if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
+    float gs = 0.f, gss = 0.f;
+    if (W_ABL & 2) { if (co_ok && acc[0][0] == 12345.f) p_out[0] = acc[3][1] + VA[0][0] + ring[0][0]; return; }
+    // 4 MFMA rows (= 4 tiles = 16 output pixels) per round: inverse transform, then every rank-1 / residual load of
+    // the round is issued before any is consumed (predicated, clamped addresses, no per-element branches)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        float val[16]; bool ok[16]; size_t oidx[16];
+        int yy_[16], xx_[16];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rg * 4 + rr;
+            const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;                  // MFMA row -> tile of this wave
+            const int ytile = ty0 + 2 * (wm * 4 + (ti >> 3)), xtile = tx0 + 2 * (ti & 7);
+            float P[2][4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float m0 = acc[0 * 4 + v][r], m1 = acc[1 * 4 + v][r], m2 = acc[2 * 4 + v][r], m3 = acc[3 * 4 + v][r];
+                P[0][v] = m0 + m1 + m2; P[1][v] = m1 - m2 - m3;
+            }
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy) {
+                const float Y0 = P[yy][0] + P[yy][1] + P[yy][2], Y1 = P[yy][1] - P[yy][2] - P[yy][3];
+#pragma unroll
+                for (int xx = 0; xx < 2; ++xx) {
+                    const int k = rr * 4 + yy * 2 + xx;
+                    const int y = ytile + yy, x = xtile + xx;
+                    yy_[k] = y; xx_[k] = x;
+                    ok[k] = y < h && x < w && co_ok;
+                    oidx[k] = ok[k] ? ((size_t(b) * h + y) * w + x) * cout + co : 0;
+                    val[k] = (xx == 0 ? Y0 : Y1) + base;
+                }
+            }
+        }
+        // issue every load of the round first (three uniform branches, no use in between), then consume
+        float tc[16], tr_[16], ts[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { tc[k] = 0.f; tr_[k] = 0.f; ts[k] = 0.f; }
+        if (p_rcol) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tc[k] = p_rcol[ok[k] ? ((size_t(b) * w + xx_[k]) * 4 + w_edge_variant(yy_[k], h)) * cout + co : 0];
+        }
+        if (p_rrow) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tr_[k] = p_rrow[ok[k] ? ((size_t(b) * h + yy_[k]) * 4 + w_edge_variant(xx_[k], w)) * cout + co : 0];
+        }
+        if (p_res) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ts[k] = p_res[oidx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) val[k] += (tc[k] + tr_[k]) + ts[k];    // !ok lanes hold clamped garbage, never stored
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (ok[k] && !((W_ABL & 1) && val[k] != 12345.f)) { p_out[oidx[k]] = val[k]; gs += val[k]; gss = fmaf(val[k], val[k], gss); }
+    }
+    if (p_gn) {
+        gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
+        for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
+        if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
+            const int part = tile_idx * 2 + wm;
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
+            dst[0] = double(gs); dst[1] = double(gss);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+bool conv_use_wino() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("S3D_WINO");
+        v = (e && strcmp(e, "0") == 0) ? 0 : 1;
+    }
+    return v == 1 && !conv_use_naive();
+}
+
+void wino_gn_parts(const Geo& g, int nparts[3]) {
+    for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + W_T - 1) / W_T) * ((g.h[p] + W_T - 1) / W_T) * 2;
+}
+
+// U = G g G^T in double, stored in MFMA fragment order [n32][k8][16][64 lanes][4]; W is OIHW [cout][ctot][3][3],
+// only input channels [0, cin) are used (the plane's own channels).
+size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int n32 = (cout + 31) / 32, k8t = cin / 8;
+    const size_t total = size_t(n32) * k8t * 16 * 256;
+    const size_t off = push(stage, nullptr, total);
+    float* d = stage.data() + off;
+    std::fill(d, d + total, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = W + (size_t(co) * ctot + c) * 9;
+            double t[4][3];
+            for (int u = 0; u < 4; ++u)
+                for (int k = 0; k < 3; ++k) t[u][k] = G[u][0] * g[0 * 3 + k] + G[u][1] * g[1 * 3 + k] + G[u][2] * g[2 * 3 + k];
+            const int nt = co >> 5, jn = co & 31, k8 = c >> 3, hf = (c >> 2) & 1, e = c & 3;
+            for (int u = 0; u < 4; ++u)
+                for (int v = 0; v < 4; ++v) {
+                    const double uv = t[u][0] * G[v][0] + t[u][1] * G[v][1] + t[u][2] * G[v][2];
+                    d[(((size_t(nt) * k8t + k8) * 16 + (u * 4 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                }
+        }
+    return off;
+}
+
+int launch_conv_wino(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        J.tiles_x = (J.w + W_T - 1) / W_T;
+        J.tiles_per_img = J.tiles_x * ((J.h + W_T - 1) / W_T);
+        J.n_tiles_n = (a.cout + 63) / 64;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace s3d

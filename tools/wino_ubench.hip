@@ -1,0 +1,45 @@
+// Stand-alone timing harness for the Winograd convolution (tuning only).
+#include "../sin3dm_amd/csrc/s3d_common.h"
+namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; }
+  size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
+#include "../sin3dm_amd/csrc/s3d_wino.hip"
+#include <cstdlib>
+using namespace s3d;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
+    size_t npix = size_t(3) * hw * hw * B;
+    float *in, *wgt, *out, *res, *tab;
+    size_t wsz = size_t((cout + 31) / 32) * (cin / 8) * 16 * 256;
+    CK(hipMalloc(&in, npix * cin * 4)); CK(hipMalloc(&wgt, 3 * wsz * 4)); CK(hipMalloc(&out, npix * cout * 4)); CK(hipMalloc(&res, npix * cout * 4));
+    CK(hipMalloc(&tab, size_t(B) * hw * 4 * cout * 4));
+    std::vector<float> h(npix * cin); for (auto& v : h) v = float(rand()) / RAND_MAX - 0.5f;
+    CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw_(3 * wsz); for (auto& v : hw_) v = float(rand()) / RAND_MAX - 0.5f;
+    CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(res, 0, npix * cout * 4)); CK(hipMemset(tab, 0, size_t(B) * hw * 4 * cout * 4));
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
+    for (int p = 0; p < 3; ++p) {
+        a.job[p].in = in + size_t(p) * hw * hw * B * cin; a.job[p].wgt = wgt + p * wsz;
+        a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
+        if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_conv_wino(a, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_conv_wino(a, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / iters;
+    double fl = 2.0 * 9 * cin * cout * npix;
+    printf("wino cin=%4d cout=%4d hw=%3d B=%d extras=%d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF\n", cin, cout, hw, B, extras, us, fl / us / 1e6, fl * 4 / 9 / us / 1e6);
+    CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
+}
+int main() {
+    printf("W_ABL=%d\n", W_ABL);
+    run(128, 64, 128, 1, 10, false);      // 192 blocks: one round
+    run(512, 64, 128, 1, 10, false);
+    run(128, 128, 128, 8, 3, false);
+    return 0;
+}
