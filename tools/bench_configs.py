@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Step time of the sampling hot path on the other BASELINE configs (not the scored bench line):
+   python tools/bench_configs.py            # prints one JSON line per config"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sin3dm_amd import testing as T
+from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
+from bench import f_dense_per_step
+
+CONFIGS = [  # name, model_channels, (H,W,D), batch, respacing, ddim, steps timed
+    ("C1 towerruins@64 64-ch DDIM-10 B=1", 64, (46, 64, 46), 1, "10", True, 10),
+    ("64-ch 128^3 DDPM B=1", 64, (128, 128, 128), 1, "", False, 100),
+    ("C2 128-ch 128^3 DDPM B=1", 128, (128, 128, 128), 1, "", False, 100),
+    ("C3 128-ch 128^3 DDIM-100 B=8 per GPU", 128, (128, 128, 128), 8, "100", True, 30),
+    ("C5 128-ch (256,256,128) DDPM B=1", 128, (256, 256, 128), 1, "", False, 50),
+]
+dev = torch.device("cuda:0")
+for name, mc, (H, W, D), B, resp, ddim, steps in CONFIGS:
+    model = TriplaneUNetModelSmall(12, mc, 12, use_scale_shift_norm=True)
+    model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0))
+    model.to(dev).eval()
+    diff = create_gaussian_diffusion(steps=1000, predict_xstart=True, timestep_respacing=resp)
+    Tn = diff.num_timesteps
+    x = torch.randn(B, 12, H + D, W + D, device=dev)
+    step = diff.ddim_sample if ddim else diff.p_sample
+    def run(n, x):
+        with torch.no_grad():
+            for k in range(n):
+                t = torch.full((B,), (Tn - 1 - k) % Tn, device=dev, dtype=torch.int64)
+                x = step(model, x, t, model_kwargs=dict(H=H, W=W, D=D))["sample"]
+        return x
+    x = run(3, x); torch.cuda.synchronize()
+    t0 = time.perf_counter(); x = run(steps, x); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    fd = f_dense_per_step(mc, H, W, D) * B
+    print(json.dumps({"config": name, "ms_per_step": round(dt * 1e3, 3), "samples_per_s_full_run": round(B / (dt * Tn), 4),
+                      "steps_per_sample": Tn, "effective_dense_tflops": round(fd / dt / 1e12, 1), "finite": bool(torch.isfinite(x).all())}),
+          flush=True)
+    del model
+    torch.cuda.empty_cache()
