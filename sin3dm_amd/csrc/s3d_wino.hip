@@ -255,18 +255,229 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs args) {
     }
 }
 
+// ------------------------------------------------------------------ two waves per SIMD: the frequencies split in halves
+// Same data flow as k_conv_wino with an 8x16-pixel tile (one 32-row MFMA tile); a (tile, 32-channel) unit is shared by TWO waves that each own 8 of
+// the 16 frequencies (rows u = 2*fh, 2*fh+1 of the 4x4 frequency grid): 128 accumulator registers per wave instead of
+// 256, so two waves fit on every SIMD.  That (a) lets one wave's barrier / prologue / epilogue time be covered by its
+// neighbour's MFMAs and (b) halves the scheduling quantum, which removes most of the last-round imbalance at batch 1
+// (1536 units on 1024 SIMDs became 3072 half-units that the dispatcher packs 3 per SIMD).  Costs: each wave redoes the
+// cheap column pass of the input transform for its rows only (12 of the 16 patch reads), and the inverse transform
+// needs one 4-float exchange per output tile between the two waves through LDS.
+constexpr int W2_TH = 8, W2_TW = 16;                      // output tile: 4 x 8 Winograd tiles = one 32-row MFMA tile
+constexpr int W2_HH = W2_TH + 2, W2_HW = W2_TW + 2;
+constexpr int W2_AELEMS = W2_HH * W2_HW * W_LD;
+constexpr int W2_ITEMS = W2_HH * W2_HW * (W_KC / 4);
+constexpr int W2_ITEMS_PT = (W2_ITEMS + 255) / 256;       // halo float4 items per thread and chunk (6)
+
+__global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_AELEMS];
+    const int bid = blockIdx.x;
+    int j = 0;
+    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int tile_idx = local;
+    const int ty0 = (local / J.tiles_x) * W2_TH, tx0 = (local % J.tiles_x) * W2_TW;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = wid & 1, wn = wid >> 1;
+    const int i = lane & 31, half = lane >> 5;
+    const int tr = i >> 3, tc = i & 7;
+    // patch rows this wave needs: fh, fh+1, fh+2 (u0,u1 need d0,d1,d2; u2,u3 need d1,d2,d3)
+    const int patch0 = ((2 * tr + fh) * W2_HW + 2 * tc) * W_LD + half * 4;
+
+    const int n32_total = (cout + 31) / 32;
+    int n32 = ntile * 2 + wn;
+    const bool n_live = n32 < n32_total;
+    if (!n_live) n32 = n32_total - 1;
+    const int k8_total = cin / 8;
+    const float* ub = J.wgt + ((size_t(n32) * k8_total) * 16 + fh * 8) * 256 + lane * 4;
+    const float* inb = J.in + size_t(b) * h * w * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    auto item_load = [&](int it, int ch) -> f32x4 {
+        const int idx = it * 256 + tid;
+        const int pix = idx >> 3, q = idx & 7;
+        const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = idx < W2_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        f32x4 v = wg4(inb + (size_t(ok ? gy : 0) * w + (ok ? gx : 0)) * cin + ch * W_KC + q * 4)[0];
+        return ok ? v : zero4;
+    };
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        const int idx = it * 256 + tid;
+        if (idx < W2_ITEMS) *reinterpret_cast<f32x4*>(smem + buf * W2_AELEMS + (idx >> 3) * W_LD + (idx & 7) * 4) = v;
+    };
+    // column pass for this wave's two frequency rows from patch rows r0,r1,r2 (= d[fh], d[fh+1], d[fh+2])
+    auto col_pair = [&](const f32x4& r0, const f32x4& r1, const f32x4& r2, f32x4& t0, f32x4& t1) {
+        if (fh == 0) { t0 = r0 - r2; t1 = r1 + r2; }      // u0 = d0 - d2, u1 = d1 + d2
+        else         { t0 = r1 - r0; t1 = r0 - r2; }      // u2 = d2 - d1, u3 = d1 - d3
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int nchunks = cin / W_KC;
+#pragma unroll
+    for (int it = 0; it < W2_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+    __syncthreads();
+    f32x4 VA[8], VB[8], ring[8];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + patch0 + (0 * W2_HW + bb) * W_LD);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(smem + patch0 + (1 * W2_HW + bb) * W_LD);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(smem + patch0 + (2 * W2_HW + bb) * W_LD);
+        col_pair(r0, r1, r2, VA[bb], VA[4 + bb]);
+    }
+    wino_row_pass(VA); wino_row_pass(VA + 4);
+#pragma unroll
+    for (int f = 0; f < 8; ++f) ring[f] = wg4(ub + f * 256)[0];
+
+#define WINO2_STEP(Vc, Vn, K8)                                                                                        \
+    {                                                                                                                 \
+        const int step = chunk * 4 + (K8);                                                                            \
+        const int nstep = (K8) < 3 ? step + 1 : gnext * 4;                                                            \
+        const int nbuf = ((K8) == 3 ? (chunk + 1) : chunk) & 1;                                                       \
+        const float* nsrc = smem + nbuf * W2_AELEMS + patch0 + (((K8) + 1) & 3) * 8;                                    \
+        f32x4 pf[2], cr0, cr1, cr2;                                                                                   \
+        constexpr int it0 = (K8) * 2, itn = (K8) == 3 ? 0 : 2;                                                        \
+        _Pragma("unroll") for (int t = 0; t < itn; ++t) pf[t] = item_load(it0 + t, gnext);                            \
+        _Pragma("unroll") for (int f = 0; f < 8; ++f) {                                                               \
+            if (f < 4) {                                                     /* next patch: column f, 3 rows */       \
+                cr0 = *reinterpret_cast<const f32x4*>(nsrc + (0 * W2_HW + f) * W_LD);                                   \
+                cr1 = *reinterpret_cast<const f32x4*>(nsrc + (1 * W2_HW + f) * W_LD);                                   \
+                cr2 = *reinterpret_cast<const f32x4*>(nsrc + (2 * W2_HW + f) * W_LD);                                   \
+            }                                                                                                         \
+            const f32x4 bq = ring[f];                                                                                 \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][e], bq[e], acc[f], 0, 0, 0);                      \
+            ring[f] = wg4(ub + (size_t(nstep) * 16 + f) * 256)[0];           /* same frequency, next step */          \
+            if (f < 4) col_pair(cr0, cr1, cr2, Vn[f], Vn[4 + f]);                                                     \
+            if (f == 5) wino_row_pass(Vn);                                                                            \
+            if (f == 6) wino_row_pass(Vn + 4);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < itn; ++t) item_store(it0 + t, (chunk + 1) & 1, pf[t]);                   \
+        if ((K8) == 2) __syncthreads();                                                                               \
+    }
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int gnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
+        WINO2_STEP(VA, VB, 0)
+        WINO2_STEP(VB, VA, 1)
+        WINO2_STEP(VA, VB, 2)
+        WINO2_STEP(VB, VA, 3)
+    }
+#undef WINO2_STEP
+
+    // ---- epilogue.  M[u][v] = acc[ui*4+v] with u = 2*fh + ui.  Output row y of a tile needs P[y][v]:
+    //   P[0][v] = M0 + M1 + M2,  P[1][v] = M1 - M2 - M3.
+    // Wave fh=0 finishes y=0 and needs M2 from its partner; wave fh=1 finishes y=1 and needs M1.
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    const int co = (ntile * 2 + wn) * 32 + i;
+    const bool co_ok = n_live && co < cout;
+    const int coc = co_ok ? co : 0;
+    float base = p_bias ? p_bias[coc] : 0.f;
+    if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
+    float gs = 0.f, gss = 0.f;
+    float* xw = smem + wid * (16 * 64);                  // this wave's exchange slot: [4 rows][4 v][64 lanes]
+    const float* xr = smem + (wid ^ 1) * (16 * 64);      // partner (same wn, other fh)
+    __syncthreads();                                     // all patch reads of the last step are done
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        float own[4][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = rg * 4 + rr;
+                const float ma = acc[0 * 4 + v][r], mb = acc[1 * 4 + v][r];   // fh=0: M0, M1 ; fh=1: M2, M3
+                own[rr][v] = fh == 0 ? ma + mb : -ma - mb;
+                xw[(rr * 4 + v) * 64 + lane] = fh == 0 ? mb : ma;            // send M1 (fh=0) or M2 (fh=1)
+            }
+        __syncthreads();
+        float val[8]; bool ok[8]; size_t oidx[8]; int yy_[8], xx_[8];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rg * 4 + rr;
+            const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int y = ty0 + 2 * (ti >> 3) + fh, xt = tx0 + 2 * (ti & 7);
+            float P[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) P[v] = own[rr][v] + xr[(rr * 4 + v) * 64 + lane];
+            const float Y0 = P[0] + P[1] + P[2], Y1 = P[1] - P[2] - P[3];
+#pragma unroll
+            for (int xx = 0; xx < 2; ++xx) {
+                const int k = rr * 2 + xx, x = xt + xx;
+                yy_[k] = y; xx_[k] = x;
+                ok[k] = y < h && x < w && co_ok;
+                oidx[k] = ok[k] ? ((size_t(b) * h + y) * w + x) * cout + co : 0;
+                val[k] = (xx == 0 ? Y0 : Y1) + base;
+            }
+        }
+        float tc_[8], tr_[8], ts[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { tc_[k] = 0.f; tr_[k] = 0.f; ts[k] = 0.f; }
+        if (p_rcol) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tc_[k] = p_rcol[ok[k] ? ((size_t(b) * w + xx_[k]) * 4 + w_edge_variant(yy_[k], h)) * cout + co : 0];
+        }
+        if (p_rrow) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tr_[k] = p_rrow[ok[k] ? ((size_t(b) * h + yy_[k]) * 4 + w_edge_variant(xx_[k], w)) * cout + co : 0];
+        }
+        if (p_res) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ts[k] = p_res[oidx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = val[k] + ((tc_[k] + tr_[k]) + ts[k]);
+            if (ok[k]) { p_out[oidx[k]] = v; gs += v; gss = fmaf(v, v, gss); }
+        }
+        __syncthreads();                                 // exchange slots are rewritten next round
+    }
+    if (p_gn) {
+        gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
+        for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
+        if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
+            const int part = tile_idx * 2 + fh;
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
+            dst[0] = double(gs); dst[1] = double(gss);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
-bool conv_use_wino() {
+static int wino_variant() {          // 2: two waves per SIMD (default), 1: one wave per SIMD, 0: direct kernel
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("S3D_WINO");
-        v = (e && strcmp(e, "0") == 0) ? 0 : 1;
+        v = e ? atoi(e) : 2;
+        if (v < 0 || v > 2) v = 2;
     }
-    return v == 1 && !conv_use_naive();
+    return v;
 }
+bool conv_use_wino() { return wino_variant() != 0 && !conv_use_naive(); }
 
 void wino_gn_parts(const Geo& g, int nparts[3]) {
-    for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + W_T - 1) / W_T) * ((g.h[p] + W_T - 1) / W_T) * 2;
+    for (int p = 0; p < 3; ++p) {
+        if (wino_variant() == 2) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 2;
+        else nparts[p] = ((g.w[p] + W_T - 1) / W_T) * ((g.h[p] + W_T - 1) / W_T) * 2;
+    }
 }
 
 // U = G g G^T in double, stored in MFMA fragment order [n32][k8][16][64 lanes][4]; W is OIHW [cout][ctot][3][3],
@@ -296,17 +507,20 @@ size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, in
 
 int launch_conv_wino(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
+    const bool two = wino_variant() == 2;
+    const int th = two ? W2_TH : W_T, tw = two ? W2_TW : W_T;
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
-        J.tiles_x = (J.w + W_T - 1) / W_T;
-        J.tiles_per_img = J.tiles_x * ((J.h + W_T - 1) / W_T);
+        J.tiles_x = (J.w + tw - 1) / tw;
+        J.tiles_per_img = J.tiles_x * ((J.h + th - 1) / th);
         J.n_tiles_n = (a.cout + 63) / 64;
         J.block_begin = blocks;
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);
+    if (two) hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
