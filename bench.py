@@ -182,7 +182,7 @@ def main():
                     "mfma_executed_tflops": round(ach * exec_frac, 2),
                     "mfma_executed_frac": round(ach * exec_frac / PEAK_FP32_MFMA_TFLOPS, 4),
                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)",
-                    "kernel": ("k_conv_wino (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
+                    "kernel": ("k_conv_wino2 (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
                               ", dense own-channel part of the rollout TriplaneConv)",
                     "avg_launch_us": round(prof.ms[0] / prof.launches[0] * 1e3, 2),
                     "launches_timed": int(prof.launches[0]),
