@@ -37,9 +37,11 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
 int main() {
-    printf("W_ABL=%d\n", W_ABL);
-    run(128, 64, 128, 1, 10, false);      // 192 blocks: one round
-    run(512, 64, 128, 1, 10, false);
+    printf("W_ABL=%d S3D_WINO=%s\n", W_ABL, getenv("S3D_WINO") ? getenv("S3D_WINO") : "(default 2)");
+    for (int c : {128, 256, 512}) run(c, 64, 128, 1, 10, false);     // 384 blocks (wino2) / 192 (wino1)
+    for (int c : {128, 256, 512}) run(c, 128, 128, 1, 10, false);    // 768 / 384
+    run(256, 256, 64, 1, 10, false);                                  // the half-resolution layer
     run(128, 128, 128, 8, 3, false);
+    run(128, 128, 128, 1, 10, true);
     return 0;
 }
