@@ -190,6 +190,13 @@ def schedule_tables(keep=None, steps=1000):
     return tab, tmap
 
 
+def schedule_tables_named(steps=1000):
+    """The forward-process tables q_sample needs (gaussian_diffusion.py:141-146), float64, from the same betas."""
+    tab, _ = schedule_tables(None, steps)
+    return {"betas": tab[0], "alphas_cumprod": tab[1], "sqrt_alphas_cumprod": np.sqrt(tab[1]),
+            "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - tab[1])}
+
+
 def p_sample_update(model_out, x, eps, tab, t, clip=True):
     (mo, a), (x, b), (eps, c) = _f(model_out), _f(x), _f(eps)
     s, p = np.empty_like(mo), np.empty_like(mo)

@@ -104,3 +104,40 @@ def p_sample_update(model_out, x, eps, tab, t):
     mean = float(tab[6][t]) * x0 + float(tab[7][t]) * x
     var = tab[5][1] if t == 0 else tab[0][t]
     return mean + (0.0 if t == 0 else 1.0) * math.exp(0.5 * math.log(var)) * eps, x0
+
+
+# ---------------------------------------------------------------------------------------------- training tier
+def q_sample(x0, noise, sqrt_ac, sqrt_1mac, t):
+    """src/diffusion/gaussian_diffusion.py:189-207; sqrt_ac / sqrt_1mac: float64 numpy tables, t: int64 [B]."""
+    a = torch.from_numpy(sqrt_ac)[t].float()[:, None, None, None]
+    b = torch.from_numpy(sqrt_1mac)[t].float()[:, None, None, None]
+    return a * x0 + b * noise
+
+
+def training_losses(sd, x0, t, noise, tabs, H, W, D, **unet_kw):
+    """training_losses with MSE / START_X (gaussian_diffusion.py:771-856): per-plane mean-squared errors summed.
+    sd tensors may require grad; returns {"mse_xy","mse_xz","mse_yz","loss"} each [B], and x_t."""
+    x_t = q_sample(x0, noise, tabs["sqrt_alphas_cumprod"], tabs["sqrt_one_minus_alphas_cumprod"], t)
+    out = unet_forward(sd, x_t, t.float(), H, W, D, **unet_kw)
+    terms = {}
+    for name, tgt, o in zip(PLANES, _decompose(x0, H, W, D), _decompose(out, H, W, D)):
+        terms["mse_" + name] = ((tgt - o) ** 2).flatten(1).mean(1)
+    terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]
+    return terms, x_t
+
+
+def _decompose(c, H, W, D):
+    return c[..., :H, :W], c[..., :H, W:], c[..., H:, :W].transpose(-1, -2)
+
+
+def adamw_ema_step(params, grads, m, v, ema, step, lr, wd, ema_rate, b1=0.9, b2=0.999, eps=1e-8):
+    """One torch.optim.AdamW step (decoupled decay, bias-corrected) followed by update_ema (src/diffusion/nn.py:55-65),
+    in place on lists of tensors; `step` counts from 1."""
+    c1, c2 = 1 - b1 ** step, 1 - b2 ** step
+    for p, g, mi, vi, e in zip(params, grads, m, v, ema):
+        p.mul_(1 - lr * wd)
+        mi.mul_(b1).add_(g, alpha=1 - b1)
+        vi.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (vi.sqrt() / math.sqrt(c2)).add_(eps)
+        p.addcdiv_(mi, denom, value=-lr / c1)
+        e.mul_(ema_rate).add_(p, alpha=1 - ema_rate)

@@ -296,10 +296,102 @@ def gen_compose():
     save("compose", xy=fm[0], xz=fm[1], yz=fm[2], composed=comp, hwd=np.asarray([H, W, D]))
 
 
+def grad_digest(named, prefix, out, full_max=512, full_names=()):
+    """Digest of an ordered {name: tensor} map (order = the module's named_parameters()): per tensor the L2 norm, the
+    projection on a fixed pseudo-random direction (keyed by the name, sin3dm_amd.testing.synthetic_tensor) and the
+    first 8 elements, stacked into three arrays; the tensor itself when small or explicitly listed."""
+    norms, projs, heads = [], [], []
+    for k, g in named.items():
+        g = g.detach().double().reshape(-1)
+        r = torch.from_numpy(T.synthetic_tensor("digest/" + k, (g.numel(),), 7)).double()
+        norms.append(float(g.norm()))
+        projs.append(float((g * r).sum()))
+        heads.append(torch.nn.functional.pad(g[:8], (0, max(0, 8 - g.numel()))).float().numpy())
+        if g.numel() <= full_max or k in full_names:
+            out[f"{prefix}/full/{k}"] = g.float()
+    out[f"{prefix}/names"] = np.asarray(list(named))
+    out[f"{prefix}/norm"] = np.asarray(norms)
+    out[f"{prefix}/proj"] = np.asarray(projs)
+    out[f"{prefix}/head"] = np.stack(heads)
+
+
+TRAIN_FULL = ("input_blocks.0.0.in_layers.2.conv_xy.weight", "output_blocks.1.0.skip_connection.conv_yz.weight",
+              "input_blocks.1.1.emb_layers.1.weight", "in_conv.0.conv_xz.weight", "out.2.conv_yz.weight")
+
+
+def gen_train():
+    """training_losses + backward (gaussian_diffusion.py:771-856, train_util.py:205-236) and three AdamW/EMA/anneal
+    steps (train_util.py:163-172, 238-247; nn.py:55-65) on the tiny configs."""
+    torch.set_grad_enabled(True)
+    out = {}
+    diffusion = make_diffusion("")
+    cases = (("mc32_a", 32, False, (2, 10, 14, 6), True, "1,2"),
+             ("mc32_odd", 32, False, (2, 9, 13, 7), True, "1,2"),
+             ("mc32_raw", 32, True, (2, 10, 14, 6), True, "1,2"),
+             ("mc32_add", 32, False, (1, 10, 14, 6), False, "1,2"),
+             ("mc32_3lev", 32, False, (1, 12, 16, 8), True, "1,2,2"))
+    for tag, mc, raw, (B, H, W, D), ssn, cm in cases:
+        model = make_unet(mc, raw, ssn, cm)
+        model.train()
+        x0 = rnd((B, 12, H + D, W + D), 400).clamp(-1, 1)
+        noise = rnd((B, 12, H + D, W + D), 401)
+        t = torch.tensor([700, 3][:B], dtype=torch.int64)
+        w = torch.ones(B)
+        terms = diffusion.training_losses(model, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+        loss = (terms["loss"] * w).mean()
+        model.zero_grad()
+        loss.backward()
+        out[f"{tag}.t"] = t                                # x0 / noise: synthetic_noise seeds 400 / 401
+        out[f"{tag}.hwd"] = np.asarray([H, W, D])
+        for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+            out[f"{tag}.{k}"] = terms[k].detach()
+        out[f"{tag}.x_t"] = diffusion.q_sample(x0, t, noise=noise)
+        grad_digest({k: p.grad for k, p in model.named_parameters()}, f"{tag}.grad", out,
+                    full_names=TRAIN_FULL if tag == "mc32_a" else ())
+    save("train_grads", **out)
+
+    # three optimizer steps exactly as TrainLoop.run_step does them (AdamW -> EMA -> linear anneal), fixed t / noise
+    out = {}
+    tag, mc, (B, H, W, D) = "mc32_a", 32, (2, 10, 14, 6)
+    lr0, ema_rate, wd, anneal = 5e-4, 0.99, 0.0, 10        # ema 0.99 (default 0.9999) so that three steps move the EMA by more than fp32 round-off
+    from diffusion.nn import update_ema
+    import copy
+    for wd_tag, wd in (("wd0", 0.0), ("wd01", 0.01)):
+        model = make_unet(mc)
+        model.train()
+        params = list(model.parameters())
+        names = [k for k, _ in model.named_parameters()]
+        init = [p.detach().clone() for p in params]
+        opt = torch.optim.AdamW(params, lr=lr0, weight_decay=wd)
+        ema = copy.deepcopy(params)
+        x0 = rnd((B, 12, H + D, W + D), 400).clamp(-1, 1)
+        losses = []
+        for step in range(3):
+            noise = rnd((B, 12, H + D, W + D), 500 + step)
+            t = torch.tensor([[700, 3], [12, 999], [450, 451]][step], dtype=torch.int64)
+            for p in params:
+                if p.grad is not None:
+                    p.grad.detach_(); p.grad.zero_()
+            terms = diffusion.training_losses(model, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+            (terms["loss"] * torch.ones(B)).mean().backward()
+            opt.step()
+            update_ema(ema, params, rate=ema_rate)
+            lr = lr0 * (1 - step / anneal)                     # _anneal_lr runs after the step, with self.step = step
+            for gr in opt.param_groups:
+                gr["lr"] = lr
+            losses.append(terms["loss"].detach().clone())
+        out[f"{wd_tag}.losses"] = torch.stack(losses)
+        out[f"{wd_tag}.hyper"] = np.asarray([lr0, ema_rate, wd, anneal])
+        grad_digest({k: p.detach() - i for k, p, i in zip(names, params, init)}, f"{wd_tag}.dparam", out, full_names=TRAIN_FULL[:1])
+        grad_digest({k: e.detach() - i for k, e, i in zip(names, ema, init)}, f"{wd_tag}.dema", out, full_max=64)
+    save("train_steps", **out)
+    torch.set_grad_enabled(False)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
-                     ("decoder", gen_decoder), ("compose", gen_compose)):
+                     ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train)):
         if not only or name in only:
             fn()

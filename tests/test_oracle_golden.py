@@ -6,7 +6,7 @@ order than oneDNN; the north_star gate for the HIP path is 1e-3.
 import numpy as np
 import pytest
 
-from conftest import golden, relerr
+from conftest import golden, relerr, digest_errors, zero_grad_params
 from sin3dm_amd import testing as T
 
 TOL = 2e-5
@@ -173,3 +173,72 @@ def test_torch_port_unet_forward(oracle, tag, mc, raw, ssn, cm):
         y = tp.unet_forward(sd, torch.from_numpy(g[f"{tag}.x"]), torch.from_numpy(g[f"{tag}.t"]), H, W, D, mc, cm, ssn,
                             not raw).numpy()
     assert relerr(y, g[f"{tag}.y"]) < 5e-6
+
+
+TRAIN_CASES = [("mc32_a", 32, False, True, (1, 2), 2), ("mc32_odd", 32, False, True, (1, 2), 2),
+               ("mc32_raw", 32, True, True, (1, 2), 2), ("mc32_add", 32, False, False, (1, 2), 1),
+               ("mc32_3lev", 32, False, True, (1, 2, 2), 1)]
+
+
+def _train_inputs(g, tag, B):
+    import torch
+    H, W, D = (int(v) for v in g[f"{tag}.hwd"])
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 401))
+    return H, W, D, x0, noise, torch.from_numpy(g[f"{tag}.t"])
+
+
+@pytest.mark.parametrize("tag,mc,raw,ssn,cm,B", TRAIN_CASES)
+def test_torch_port_training_losses_and_grads(oracle, tag, mc, raw, ssn, cm, B):
+    """training tier oracle: loss terms and every parameter gradient against the reference's autograd."""
+    import torch
+    import torch_port as tp
+    g = golden("train_grads")
+    shapes = T.unet_param_shapes(model_channels=mc, rollout=not raw, use_scale_shift_norm=ssn, channel_mult=cm)
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 0).items()}
+    H, W, D, x0, noise, t = _train_inputs(g, tag, B)
+    tabs = oracle.schedule_tables_named(1000)
+    terms, x_t = tp.training_losses(sd, x0, t, noise, tabs, H, W, D, model_channels=mc, channel_mult=cm,
+                                    use_scale_shift_norm=ssn, rollout=not raw)
+    assert relerr(x_t.detach().numpy(), g[f"{tag}.x_t"]) < 1e-6
+    for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+        assert relerr(terms[k].detach().numpy(), g[f"{tag}.{k}"]) < 1e-5
+    terms["loss"].mean().backward()
+    w = digest_errors({k: v.grad.numpy() for k, v in sd.items()}, g, f"{tag}.grad")
+    assert w["norm"] < 1e-4 and w["proj"] < 1e-4 and w["head"] < 1e-3 and w["full"] < 1e-4, w
+
+
+@pytest.mark.parametrize("wd_tag", ["wd0", "wd01"])
+def test_torch_port_optimizer_steps(oracle, wd_tag):
+    """three AdamW + EMA + lr-anneal steps as TrainLoop.run_step orders them."""
+    import torch
+    import torch_port as tp
+    g = golden("train_steps")
+    lr0, ema_rate, wd, anneal = (float(v) for v in g[f"{wd_tag}.hyper"])
+    mc, B, (H, W, D) = 32, 2, (10, 14, 6)
+    shapes = T.unet_param_shapes(model_channels=mc)
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 0).items()}
+    init = {k: v.detach().clone() for k, v in sd.items()}
+    names = list(shapes)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    ema = [sd[k].detach().clone() for k in names]
+    tabs = oracle.schedule_tables_named(1000)
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1)
+    lr = lr0
+    for step in range(3):
+        noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 500 + step))
+        t = torch.tensor([[700, 3], [12, 999], [450, 451]][step])
+        for p in sd.values():
+            p.grad = None
+        terms, _ = tp.training_losses(sd, x0, t, noise, tabs, H, W, D, model_channels=mc)
+        terms["loss"].mean().backward()
+        assert relerr(terms["loss"].detach().numpy(), g[f"{wd_tag}.losses"][step]) < 1e-4
+        with torch.no_grad():
+            tp.adamw_ema_step([sd[k] for k in names], [sd[k].grad for k in names], m, v, ema, step + 1, lr, wd, ema_rate)
+        lr = lr0 * (1 - step / anneal)
+    wp = digest_errors({k: (sd[k].detach() - init[k]).numpy() for k in names}, g, f"{wd_tag}.dparam", zero_grad_params())
+    we = digest_errors({k: (e - init[k]).numpy() for k, e in zip(names, ema)}, g, f"{wd_tag}.dema", zero_grad_params())
+    # Adam turns a near-zero gradient element into a +-lr step: single elements may flip, the L2 error stays small
+    assert wp["norm"] < 1e-3 and wp["proj"] < 2e-3 and wp["full_l2"] < 5e-3, wp
+    assert we["norm"] < 1e-3 and we["proj"] < 2e-3, we
