@@ -173,6 +173,46 @@ S3D_API int s3d_decoder_decode_points(s3d_decoder* d, const float* pts, int64_t 
 S3D_API int s3d_decoder_grid_dims(const float aabb[6], int reso, int dims[3]);
 S3D_API int s3d_decoder_decode_grid(s3d_decoder* d, int reso, const float aabb[6], float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training tier: what the reference gets from autograd + torch.optim for
+ * GaussianDiffusion.training_losses (src/diffusion/gaussian_diffusion.py:771-856) and
+ * TrainLoop.run_step (src/diffusion/train_util.py:163-247).
+ *
+ * Parameters live in ONE caller-owned flat fp32 device vector: the state-dict tensors in the order of
+ * s3d_unet_param_info(), each in its PyTorch layout, tightly packed (6 989 860 floats at 64 channels).
+ * Gradients, Adam moments and EMA copies use the same layout, so the optimizer is one kernel and a
+ * data-parallel job needs one all-reduce of the gradient vector.
+ * ------------------------------------------------------------------------------------------------ */
+S3D_API int64_t s3d_unet_param_numel(const s3d_unet* m);
+S3D_API int s3d_unet_param_offset(const s3d_unet* m, int index, int64_t* offset);
+/* Make `params` (device, numel floats) the master copy.  The library keeps the pointer (not the memory) until the
+ * handle is destroyed or another vector is attached.  Call s3d_unet_repack after every change of its contents. */
+S3D_API int s3d_unet_train_attach(s3d_unet* m, float* params, int64_t numel);
+/* Rebuild the kernel-layout weight image (and the transposed operators of the backward pass) from the attached
+ * vector: one launch on `stream`. */
+S3D_API int s3d_unet_repack(s3d_unet* m, void* stream);
+/* model(x, t, H, W, D) keeping the activations for one s3d_unet_backward.  Same result as s3d_unet_forward. */
+S3D_API int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out,
+                                   void* stream);
+/* d_out: gradient of the composed output [B,Cout,H+D,W+D].  grads: numel floats, every element is overwritten
+ * (= the .grad of each parameter after loss.backward() from zeroed gradients). */
+S3D_API int s3d_unet_backward(s3d_unet* m, const float* d_out, float* grads, void* stream);
+
+/* q_sample (:189-207): x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise; tables fp32 [T] on the device, t int64 [B] */
+S3D_API int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                               const int64_t* t, int B, int64_t per_sample, float* x_t, void* stream);
+/* terms[b][p] = mean((target_p - out_p)^2) over plane p of the composed maps (:838-845); workspace: 96*B floats */
+S3D_API int s3d_train_mse_terms(const float* model_out, const float* target, int B, int C, int H, int W, int D,
+                                float* workspace, float* terms, void* stream);
+/* d_out = d( sum_{b,p} weight[b][p] * terms[b][p] ) / d model_out ; weight: [B][3] on the device */
+S3D_API int s3d_train_mse_grad(const float* model_out, const float* target, const float* weight, int B, int C, int H,
+                               int W, int D, float* d_out, void* stream);
+/* torch.optim.AdamW step `step` (1-based) on the flat vectors, then update_ema (src/diffusion/nn.py:55-65) of up to
+ * 4 EMA copies (device pointers in a host array). */
+S3D_API int s3d_train_adamw_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* const* ema,
+                                const float* ema_rates, int n_ema, int64_t numel, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

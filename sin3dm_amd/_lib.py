@@ -80,6 +80,23 @@ SIGNATURES = {
                                             C.c_void_p]),
     "s3d_decoder_grid_dims": (C.c_int, [c_fp, C.c_int, C.POINTER(C.c_int)]),
     "s3d_decoder_decode_grid": (C.c_int, [C.c_void_p, C.c_int, c_fp, C.c_void_p, C.c_void_p]),
+    # training tier
+    "s3d_unet_param_numel": (C.c_int64, [C.c_void_p]),
+    "s3d_unet_param_offset": (C.c_int, [C.c_void_p, C.c_int, c_i64p]),
+    "s3d_unet_train_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "s3d_unet_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "s3d_unet_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p]),
+    "s3d_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3d_train_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+                                     C.c_void_p, C.c_void_p]),
+    "s3d_train_mse_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
+    "s3d_train_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]),
+    "s3d_train_adamw_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), c_fp, C.c_int,
+                                      C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                      C.c_void_p]),
 }
 
 _lib = None

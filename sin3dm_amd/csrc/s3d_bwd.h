@@ -1,0 +1,74 @@
+// s3d_bwd.h — launchers of the backward kernels (s3d_bwd.hip), used by the training driver (s3d_train.hip).
+#pragma once
+#include "s3d_common.h"
+
+namespace s3d {
+
+// row / column sums of dy with the three edge variants: R[p] [B][h][3][C], Cs[p] [B][w][3][C]
+int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st);
+// dbias[p][C] from the row sums; per_sample [B][stride] (+= over planes) or null
+int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
+                     int per_sample_stride, hipStream_t st);
+
+struct SlotWgradArgs {
+    const float* rowvec[3]; const float* colvec[3];   // the conv's row-/column-varying mean vectors [B][h|w][C]
+    const float* R[3]; const float* Cs[3];            // edge sums of dy
+    float* dW[3];                                     // OIHW [cout][3C][3][3] gradient of each plane's conv weight
+    Geo g; int B, C, cout;
+};
+int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st);
+
+struct WgradArgs {
+    Tri dy;            // [B][h][w][cout]
+    Tri a;             // conv input; a.C is its channel stride, channels [0, cin) are used
+    float* part[3];    // split-K partials, wgrad_part_floats() each
+    float* dW[3];      // OIHW [cout][ctot][taps]; own channels [0, cin) are written
+    int B, cin, cout, ctot, taps, ksplit;
+};
+int wgrad_ksplit(const Geo& g, int B, int cin, int cout);
+size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps);
+int launch_wgrad(const WgradArgs& w, hipStream_t st);
+
+struct GnActBwd {
+    Tri x, dy, dx;
+    const float* const* rowadd; const float* const* coladd;   // arrays of 3 or null
+    const Tri* add;
+    const float* gamma[3]; const float* beta[3];
+    float* dgamma[3]; float* dbeta[3];
+    GnStats stats;
+    const float* film; float* dfilm; int film_stride;
+    float* ws;                                                // gn_bwd_ws_floats(B, C)
+    int B;
+};
+size_t gn_bwd_ws_floats(int B, int C);
+int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st);
+
+struct SmallOuter {
+    const float* s; int S;          // composed map [B][S][H+D][W+D]
+    Tri v;                          // NHWC planes, C channels
+    const float* Wt; Tri* dv;       // optional dv = Wt^T s
+    float* outer[3]; int outer_transposed;
+    float* const* ssum; float* const* vsum;
+    float* ws;                      // small_outer_ws_floats(S, C)
+    int H, W, D, C, B;
+};
+size_t small_outer_ws_floats(int S, int C);
+int launch_small_outer(const SmallOuter& s, hipStream_t st);
+
+int launch_pool_bwd_add(const Tri* dpool, const Tri* dskip, int skip_coff, int B, Tri& out, hipStream_t st);
+int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out_cstride, int out_coff, float* din, int hi,
+                        int wi, hipStream_t st);
+// y = L(f(in)): dW/db (when dW != null) and dx = (dy W) * f'(in) (when dx != null); dy rows are dy_stride apart
+int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
+                      float* db, float* dx, hipStream_t st);
+int launch_scale(float* v, long long n, float s, hipStream_t st);
+
+int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
+                    float* xt, hipStream_t st);
+constexpr int kMseWsFloats = 3 * 32;     // per sample
+int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st);
+int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st);
+int launch_adamw_ema(float* p, const float* g, float* m, float* v, float* const* ema, const float* ema_rate, int n_ema, long long n,
+                     float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);
+
+}  // namespace s3d

@@ -1,0 +1,849 @@
+// s3d_bwd.hip — backward kernels of the triplane UNet (training tier).
+//
+// Everything the reference gets from autograd for TriplaneUNetModelSmall (src/diffusion/unet_triplane.py), written
+// against the same NHWC-per-plane layout as the forward kernels.  The rollout structure is exploited in the backward
+// pass too: the two mean channel blocks of a TriplaneConv are constant along one image axis, so
+//   * their input gradient is a 1-D transposed convolution of row / column sums of dy   (edge sums -> k_rank1),
+//   * their weight gradient is a small GEMM between those sums and the mean vectors      (k_slot_wgrad),
+// and only the plane's own channels need the dense dgrad (the forward conv kernels with a transposed operator) and
+// the dense wgrad (k_wgrad_mfma).  All reductions are two-stage with a fixed order: bit-repeatable, no float atomics.
+#include "s3d_bwd.h"
+
+namespace s3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// ------------------------------------------------------------------ row / column sums of dy with edge variants
+// R[b][r][j][co]  = sum over columns c of dy[b][r][c][co] restricted by the horizontal tap j: j=0 -> c >= 1,
+//                   j=1 -> all c, j=2 -> c <= w-2   (the columns whose tap j stays inside the image)
+// Cs[b][c][j][co] = the same with rows and columns exchanged.
+struct EdgeArgs {
+    const float* dy[3]; float* R[3]; float* Cs[3];
+    int h[3], w[3];
+    int B, C;
+    int begin[7];             // block prefix over the 6 (plane, row|col) jobs, per sample
+};
+__global__ __launch_bounds__(256) void k_edge_sums(EdgeArgs a) {
+    const int per = a.begin[6];
+    const int b = blockIdx.x / per;
+    int r = blockIdx.x % per, v = 0;
+    while (r >= a.begin[v + 1]) ++v;
+    r -= a.begin[v];
+    const int p = v >> 1, is_col = v & 1;
+    const int h = a.h[p], w = a.w[p], C = a.C;
+    const int n = is_col ? h : w;                     // length of the summed axis
+    const size_t stride = is_col ? size_t(w) * C : size_t(C);
+    const float* base = a.dy[p] + size_t(b) * h * w * C + (is_col ? size_t(r) * C : size_t(r) * w * C);
+    float* out = (is_col ? a.Cs[p] + (size_t(b) * w + r) * 3 * C : a.R[p] + (size_t(b) * h + r) * 3 * C);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float first = base[c];
+        const float last = base[size_t(n - 1) * stride + c];
+        float mid = 0.f;
+        for (int k = 1; k < n - 1; ++k) mid += base[size_t(k) * stride + c];
+        float s0, s1, s2;
+        if (n >= 2) { s0 = mid + last; s2 = first + mid; s1 = first + mid + last; }
+        else { s0 = 0.f; s2 = 0.f; s1 = first; }
+        out[c] = s0; out[C + c] = s1; out[2 * C + c] = s2;
+    }
+}
+int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st) {
+    EdgeArgs a;
+    a.B = B; a.C = dy.C; a.begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.dy[p] = dy.p[p]; a.R[p] = R[p]; a.Cs[p] = Cs[p]; a.h[p] = dy.g.h[p]; a.w[p] = dy.g.w[p];
+        a.begin[2 * p + 1] = a.begin[2 * p] + dy.g.h[p];
+        a.begin[2 * p + 2] = a.begin[2 * p + 1] + dy.g.w[p];
+    }
+    if (!B || !a.begin[6]) return 0;
+    hipLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(std::min(256, dy.C)), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ bias gradients from the row sums
+// dbias[p][co] = sum_b sum_r R[p][b][r][1][co]; optionally the per-sample sums over all planes (the gradient of
+// emb_out when it is added to h, use_scale_shift_norm=False, src/diffusion/unet_triplane.py:298-303).
+struct BiasArgs { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
+__global__ void k_bias_grad(BiasArgs a) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co >= a.C) return;
+    for (int b = 0; b < a.B; ++b) {
+        float tot = 0.f;
+        for (int p = 0; p < 3; ++p) {
+            float s = 0.f;
+            const float* R = a.R[p] + size_t(b) * a.h[p] * 3 * a.C + a.C + co;
+            for (int r = 0; r < a.h[p]; ++r) s += R[size_t(r) * 3 * a.C];
+            tot += s;
+            if (a.dbias[p]) { if (b == 0) a.dbias[p][co] = s; else a.dbias[p][co] += s; }
+        }
+        if (a.per_sample) a.per_sample[size_t(b) * a.per_sample_stride + co] = tot;
+    }
+}
+int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
+                     int per_sample_stride, hipStream_t st) {
+    BiasArgs a;
+    for (int p = 0; p < 3; ++p) { a.R[p] = R[p]; a.dbias[p] = dbias ? dbias[p] : nullptr; a.h[p] = g.h[p]; }
+    a.per_sample = per_sample; a.per_sample_stride = per_sample_stride; a.B = B; a.C = C;
+    hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 64)), dim3(64), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ weight gradient of the two mean-channel slots
+// row-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_r' v[b][r'][ci] * R[b][r'-dr+1][dc][co]
+// col-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_c' v[b][c'][ci] * Cs[b][c'-dc+1][dr][co]
+struct SlotJob { const float* v; const float* S; float* dW; int L, slot, col_varying; };
+struct SlotArgs { SlotJob job[6]; int B, C, cout, ctot; };
+__global__ __launch_bounds__(256) void k_slot_wgrad(SlotArgs a) {
+    const SlotJob J = a.job[blockIdx.y];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.C * a.cout) return;
+    const int ci = idx % a.C, co = idx / a.C;
+    float acc[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[t][j] = 0.f;
+    for (int b = 0; b < a.B; ++b)
+        for (int pos = 0; pos < J.L; ++pos) {
+            const float v = J.v[(size_t(b) * J.L + pos) * a.C + ci];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {                 // tap along the vector's own axis
+                const int q = pos - t + 1;
+                if (q < 0 || q >= J.L) continue;
+                const float* S = J.S + (size_t(b) * J.L + q) * 3 * a.cout + co;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[t][j] = fmaf(v, S[j * a.cout], acc[t][j]);
+            }
+        }
+    float* d = J.dW + (size_t(co) * a.ctot + J.slot * a.C + ci) * 9;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int dr = J.col_varying ? j : t, dc = J.col_varying ? t : j;
+            d[dr * 3 + dc] = acc[t][j];
+        }
+}
+int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
+    SlotArgs a;
+    a.B = s.B; a.C = s.C; a.cout = s.cout; a.ctot = 3 * s.C;
+    for (int p = 0; p < 3; ++p) {
+        const bool a_is_col = (p == 0);
+        // row-varying vector (length h) and column-varying vector (length w) of this plane's conv
+        SlotJob& jr = a.job[2 * p];
+        jr.v = s.rowvec[p]; jr.S = s.R[p]; jr.dW = s.dW[p]; jr.L = s.g.h[p]; jr.slot = a_is_col ? 2 : 1; jr.col_varying = 0;
+        SlotJob& jc = a.job[2 * p + 1];
+        jc.v = s.colvec[p]; jc.S = s.Cs[p]; jc.dW = s.dW[p]; jc.L = s.g.w[p]; jc.slot = a_is_col ? 1 : 2; jc.col_varying = 1;
+    }
+    hipLaunchKernelGGL(k_slot_wgrad, dim3(cdiv(s.C * s.cout, 256), 6), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ dense weight gradient on the fp32 MFMA
+// dW[co][ci][dr][dc] = sum_{b,r,c} dy[b][r][c][co] * a[b][r+dr-1][c+dc-1][ci]          (3x3, pad 1;  1x1: no shift)
+// GEMM view: M = co, N = ci (x taps), K = pixels.  v_mfma_f32_32x32x2_f32 takes K = 2 pixels per instruction:
+// A[i][k] = dy[pixel k][co0+i], B[k][j] = a[pixel k + tap][ci0+j] — both operands are runs of 32 consecutive
+// channels of one pixel, i.e. exactly what NHWC stores, so neither needs a transpose.  LDS holds the pixel tile
+// as 32-channel panels [panel][pixel][32] so the two k-halves of a wave hit disjoint bank halves.
+// One block = 64 co x 64 ci x all taps for a slice of the pixel tiles (split-K); partials are added in slice order
+// by k_wgrad_reduce, which also scatters into the reference's OIHW layout.
+constexpr int WG_TR = 4, WG_TC = 16;                 // pixel tile
+template <int TAPS>
+struct WgSmem {
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int AR = WG_TR + 2 * HALO, AC = WG_TC + 2 * HALO;
+    float dy[2][WG_TR * WG_TC][32];
+    float a[2][AR * AC][32];
+};
+struct WgJob { const float* dy; const float* a; float* part; int h, w, tiles_x, tiles; int block_begin; };
+struct WgArgs { WgJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci; };
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
+    using SM = WgSmem<TAPS>;
+    __shared__ __attribute__((aligned(16))) SM sm;
+    constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = TAPS == 9 ? 3 : 1;
+    int p = 0;
+    while (p < 2 && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
+    const WgJob& J = args.job[p];
+    int local = blockIdx.x - J.block_begin;
+    const int ks = local % args.ksplit; local /= args.ksplit;
+    const int tci = local % args.n_ci, tco = local / args.n_ci;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, kk = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int co0 = tco * 64, ci0 = tci * 64;
+    const bool wave_on = co0 + wm * 32 < args.cout && ci0 + wn * 32 < args.cin;
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const long long total = (long long)J.tiles * args.B;
+    const long long t_begin = total * ks / args.ksplit, t_end = total * (ks + 1) / args.ksplit;
+    for (long long tt = t_begin; tt < t_end; ++tt) {
+        const int b = int(tt / J.tiles), tile = int(tt % J.tiles);
+        const int r0 = (tile / J.tiles_x) * WG_TR, c0 = (tile % J.tiles_x) * WG_TC;
+        __syncthreads();
+        // stage dy tile: [2 panels][64 px][32]
+        for (int it = tid; it < 2 * WG_TR * WG_TC * 8; it += 256) {
+            const int q = it & 7, px = (it >> 3) % (WG_TR * WG_TC), pan = it / (8 * WG_TR * WG_TC);
+            const int r = r0 + px / WG_TC, c = c0 + px % WG_TC, ch = co0 + pan * 32 + q * 4;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (r < J.h && c < J.w && ch < args.cout)
+                v = *reinterpret_cast<const float4*>(J.dy + ((size_t(b) * J.h + r) * J.w + c) * args.cout + ch);
+            *reinterpret_cast<float4*>(&sm.dy[pan][px][q * 4]) = v;
+        }
+        for (int it = tid; it < 2 * AR * AC * 8; it += 256) {
+            const int q = it & 7, px = (it >> 3) % (AR * AC), pan = it / (8 * AR * AC);
+            const int r = r0 - HALO + px / AC, c = c0 - HALO + px % AC, ch = ci0 + pan * 32 + q * 4;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (r >= 0 && r < J.h && c >= 0 && c < J.w && ch < args.cin)
+                v = *reinterpret_cast<const float4*>(J.a + ((size_t(b) * J.h + r) * J.w + c) * args.a_cstride + ch);
+            *reinterpret_cast<float4*>(&sm.a[pan][px][q * 4]) = v;
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+#pragma unroll
+        for (int r = 0; r < WG_TR; ++r)
+#pragma unroll 2
+            for (int c = 0; c < WG_TC; c += 2) {
+                const float av = sm.dy[wm][r * WG_TC + c + kk][i];
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int dr = t / KW, dc = t % KW;
+                    const float bv = sm.a[wn][(r + dr) * AC + c + kk + dc][i];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+    }
+    if (!wave_on) return;
+    // partial [ks][co][ci][TAPS]
+    float* part = J.part + size_t(ks) * args.cout * args.cin * TAPS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = ci0 + wn * 32 + i;
+        float* d = part + (size_t(co) * args.cin + ci) * TAPS;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) d[t] = acc[t][r];
+    }
+}
+
+struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps; };
+__global__ void k_wgrad_reduce(WgRedArgs a) {
+    const long long n = (long long)a.cout * a.cin * a.taps;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int p = blockIdx.y;
+    float s = 0.f;
+    for (int k = 0; k < a.ksplit; ++k) s += a.part[p][size_t(k) * n + idx];
+    const int t = int(idx % a.taps);
+    const long long r = idx / a.taps;
+    const int ci = int(r % a.cin), co = int(r / a.cin);
+    a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
+}
+
+int wgrad_ksplit(const Geo& g, int B, int cin, int cout) {
+    long long tiles = 0;
+    for (int p = 0; p < 3; ++p) tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC);
+    const long long base = (long long)cdiv(cout, 64) * cdiv(cin, 64) * 3;
+    long long ks = (1024 + base - 1) / base;                         // aim for ~1000 blocks
+    const long long per_plane = std::max<long long>(1, tiles * B / 3);
+    ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
+    return int(std::min<long long>(ks, 256));
+}
+size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
+
+int launch_wgrad(const WgradArgs& w, hipStream_t st) {
+    S3D_CHECK(w.taps == 9 || w.taps == 1, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
+    S3D_CHECK(w.cin % 32 == 0 && w.cout % 32 == 0, S3D_ERR_INVALID, "wgrad: channels must be multiples of 32");
+    WgArgs a;
+    a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
+    a.n_co = cdiv(w.cout, 64); a.n_ci = cdiv(w.cin, 64);
+    int blocks = 0;
+    for (int p = 0; p < 3; ++p) {
+        WgJob& J = a.job[p];
+        J.dy = w.dy.p[p]; J.a = w.a.p[p]; J.part = w.part[p]; J.h = w.dy.g.h[p]; J.w = w.dy.g.w[p];
+        J.tiles_x = cdiv(J.w, WG_TC); J.tiles = J.tiles_x * cdiv(J.h, WG_TR);
+        J.block_begin = blocks;
+        blocks += a.n_co * a.n_ci * a.ksplit;
+    }
+    if (!blocks || !w.B) return 0;
+    if (w.taps == 9) hipLaunchKernelGGL(k_wgrad_mfma<9>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_wgrad_mfma<1>, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    WgRedArgs r;
+    for (int p = 0; p < 3; ++p) { r.part[p] = w.part[p]; r.dW[p] = w.dW[p]; }
+    r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.taps = w.taps;
+    const long long n = (long long)w.cout * w.cin * w.taps;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, st, r);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ GroupNorm (+FiLM) + SiLU backward
+// Forward (s3d_kernels.hip:k_gn_act): xh = (x-mean)*rstd ; u = xh*gamma+beta ; z = u*(1+s)+sh ; y = silu(z).
+// With dz = dy*silu'(z), per (b, plane, channel):  A1 = sum_px dz,  A2 = sum_px dz*xh.  Then
+//   dshift = A1, dscale = gamma*A2 + beta*A1, dbeta = sum_b (1+s)A1, dgamma = sum_b (1+s)A2,
+//   dx = rstd * ( g*dz - mean_grp(g*dz) - xh * mean_grp(g*dz*xh) ),  g = gamma*(1+s).
+// dy here is the dense dgrad of the plane's own channels plus the broadcast gradients of its two axis means.
+struct GnBwdArgs {
+    const float* x[3]; const float* dy[3]; float* dx[3];
+    const float* rowadd[3]; const float* coladd[3];      // [B][h][C], [B][w][C] (already divided by the mean length) or null
+    const float* add[3];                                  // extra gradient path added to dx, or null
+    const float* gamma[3]; const float* beta[3];
+    const float* mr; const float* film; int film_stride;
+    float* part;                                          // [B][3][nchunk][C][2]
+    const float* coef;                                    // [B][3][C][2] = {mean_grp(g*dz), mean_grp(g*dz*xh)}
+    int h[3], w[3];
+    int C, B, nchunk, silu;
+};
+constexpr int kGnBwdChunks = 64;
+__device__ __forceinline__ float gn_bwd_dz(const GnBwdArgs& a, int p, int b, int r, int c, size_t pix, int ch, float mean, float rstd,
+                                           float gam, float bet, float sc, float sh, float& xh) {
+    const int C = a.C;
+    const float x = a.x[p][pix * C + ch];
+    float dy = a.dy[p][pix * C + ch];
+    if (a.rowadd[p]) dy += a.rowadd[p][(size_t(b) * a.h[p] + r) * C + ch];
+    if (a.coladd[p]) dy += a.coladd[p][(size_t(b) * a.w[p] + c) * C + ch];
+    xh = (x - mean) * rstd;
+    if (!a.silu) return dy;
+    const float z = (xh * gam + bet) * sc + sh;
+    const float sg = sigmoid_f(z);
+    return dy * sg * (1.0f + z * (1.0f - sg));
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_partials(GnBwdArgs a) {
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int h = a.h[p], w = a.w[p], C = a.C, cg = C / 32;
+    const long long npix = (long long)h * w;
+    const long long p0 = npix * chunk / a.nchunk, p1 = npix * (chunk + 1) / a.nchunk;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
+        const float mean = mr[0], rstd = mr[1], gam = a.gamma[p][ch], bet = a.beta[p][ch];
+        const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
+        const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
+        float a1 = 0.f, a2 = 0.f;
+        for (long long q = p0; q < p1; ++q) {
+            const int r = int(q / w), c = int(q % w);
+            float xh;
+            const float dz = gn_bwd_dz(a, p, b, r, c, size_t(b) * npix + q, ch, mean, rstd, gam, bet, sc, sh, xh);
+            a1 += dz; a2 = fmaf(dz, xh, a2);
+        }
+        float* o = a.part + ((((size_t(b) * 3 + p) * a.nchunk + chunk) * C) + ch) * 2;
+        o[0] = a1; o[1] = a2;
+    }
+}
+// A[b][p][c][2] = sum over chunks (double) ; then group coefficients and the parameter / FiLM gradients
+struct GnBwdFinArgs {
+    const float* part; float* A; float* coef;
+    const float* gamma[3]; const float* beta[3];
+    float* dgamma[3]; float* dbeta[3];
+    const float* film; float* dfilm; int film_stride;    // dfilm [B][film_stride]: dscale at [0,C), dshift at [C,2C)
+    double count[3];
+    int C, B, nchunk;
+};
+__global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over B*3*C
+    if (idx >= a.B * 3 * a.C) return;
+    const int ch = idx % a.C, bp = idx / a.C;
+    double s1 = 0, s2 = 0;
+    for (int k = 0; k < a.nchunk; ++k) {
+        const float* q = a.part + ((size_t(bp) * a.nchunk + k) * a.C + ch) * 2;
+        s1 += q[0]; s2 += q[1];
+    }
+    a.A[size_t(idx) * 2] = float(s1); a.A[size_t(idx) * 2 + 1] = float(s2);
+}
+__global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
+    const int C = a.C, cg = C / 32;
+    // (1) group coefficients
+    for (int idx = threadIdx.x; idx < a.B * 3 * 32; idx += blockDim.x) {
+        const int g = idx % 32, bp = idx / 32, b = bp / 3, p = bp % 3;
+        double g1 = 0, g2 = 0;
+        for (int k = 0; k < cg; ++k) {
+            const int ch = g * cg + k;
+            const double sc = a.film ? 1.0 + a.film[size_t(b) * a.film_stride + ch] : 1.0;
+            const double gg = double(a.gamma[p][ch]) * sc;
+            g1 += gg * a.A[(size_t(bp) * C + ch) * 2]; g2 += gg * a.A[(size_t(bp) * C + ch) * 2 + 1];
+        }
+        for (int k = 0; k < cg; ++k) {
+            const int ch = g * cg + k;
+            a.coef[(size_t(bp) * C + ch) * 2] = float(g1 / a.count[p]);
+            a.coef[(size_t(bp) * C + ch) * 2 + 1] = float(g2 / a.count[p]);
+        }
+    }
+    // (2) dgamma / dbeta (sum over the batch)
+    for (int idx = threadIdx.x; idx < 3 * C; idx += blockDim.x) {
+        const int ch = idx % C, p = idx / C;
+        double dg = 0, db = 0;
+        for (int b = 0; b < a.B; ++b) {
+            const double sc = a.film ? 1.0 + a.film[size_t(b) * a.film_stride + ch] : 1.0;
+            const float* A = a.A + ((size_t(b) * 3 + p) * C + ch) * 2;
+            db += sc * A[0]; dg += sc * A[1];
+        }
+        a.dgamma[p][ch] = float(dg); a.dbeta[p][ch] = float(db);
+    }
+    // (3) FiLM gradients (sum over the planes: the three planes share emb_out)
+    if (a.dfilm)
+        for (int idx = threadIdx.x; idx < a.B * C; idx += blockDim.x) {
+            const int ch = idx % C, b = idx / C;
+            double ds = 0, dh = 0;
+            for (int p = 0; p < 3; ++p) {
+                const float* A = a.A + ((size_t(b) * 3 + p) * C + ch) * 2;
+                ds += double(a.gamma[p][ch]) * A[1] + double(a.beta[p][ch]) * A[0];
+                dh += A[0];
+            }
+            a.dfilm[size_t(b) * a.film_stride + ch] = float(ds);
+            a.dfilm[size_t(b) * a.film_stride + C + ch] = float(dh);
+        }
+}
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, long long begin1, long long begin2, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total * a.B) return;
+    const int b = int(idx / total);
+    long long r = idx % total;
+    const int p = r >= begin2 ? 2 : (r >= begin1 ? 1 : 0);
+    r -= p == 2 ? begin2 : (p == 1 ? begin1 : 0);
+    const int C = a.C, cg = C / 32;
+    const int ch = int(r % C);
+    const long long q = r / C;
+    const int w = a.w[p], h = a.h[p];
+    const int row = int(q / w), col = int(q % w);
+    const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
+    const float mean = mr[0], rstd = mr[1], gam = a.gamma[p][ch], bet = a.beta[p][ch];
+    const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
+    const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
+    const size_t pix = size_t(b) * h * w + q;
+    float xh;
+    const float dz = gn_bwd_dz(a, p, b, row, col, pix, ch, mean, rstd, gam, bet, sc, sh, xh);
+    const float* cf = a.coef + ((size_t(b) * 3 + p) * C + ch) * 2;
+    float dx = rstd * (gam * sc * dz - cf[0] - xh * cf[1]);
+    if (a.add[p]) dx += a.add[p][pix * C + ch];
+    a.dx[p][pix * C + ch] = dx;
+}
+size_t gn_bwd_ws_floats(int B, int C) { return size_t(B) * 3 * kGnBwdChunks * C * 2 + size_t(B) * 3 * C * 4; }
+int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
+    GnBwdArgs a;
+    const Tri& x = s.x;
+    long long begin[4] = {0, 0, 0, 0};
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = x.p[p]; a.dy[p] = s.dy.p[p]; a.dx[p] = s.dx.p[p];
+        a.rowadd[p] = s.rowadd ? s.rowadd[p] : nullptr; a.coladd[p] = s.coladd ? s.coladd[p] : nullptr;
+        a.add[p] = s.add ? s.add->p[p] : nullptr;
+        a.gamma[p] = s.gamma[p]; a.beta[p] = s.beta[p];
+        a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p];
+        begin[p + 1] = begin[p] + (long long)x.g.h[p] * x.g.w[p] * x.C;
+    }
+    a.mr = s.stats.mr; a.film = s.film; a.film_stride = s.film_stride;
+    a.C = x.C; a.B = s.B; a.nchunk = kGnBwdChunks; a.silu = 1;
+    float* part = s.ws;
+    float* A = part + size_t(s.B) * 3 * kGnBwdChunks * x.C * 2;
+    float* coef = A + size_t(s.B) * 3 * x.C * 2;
+    a.part = part; a.coef = coef;
+    if (!s.B || !begin[3]) return 0;
+    hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(std::min(256, x.C)), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    GnBwdFinArgs f;
+    f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride;
+    for (int p = 0; p < 3; ++p) {
+        f.gamma[p] = s.gamma[p]; f.beta[p] = s.beta[p]; f.dgamma[p] = s.dgamma[p]; f.dbeta[p] = s.dbeta[p];
+        f.count[p] = double(x.C / 32) * x.g.h[p] * x.g.w[p];
+    }
+    f.C = x.C; f.B = s.B; f.nchunk = kGnBwdChunks;
+    hipLaunchKernelGGL(k_gn_bwd_sum, dim3(cdiv(s.B * 3 * x.C, 256)), dim3(256), 0, st, f);
+    S3D_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_gn_bwd_coefs, dim3(1), dim3(1024), 0, st, f);
+    S3D_HIP(hipGetLastError());
+    const long long n = begin[3] * s.B;
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, begin[1], begin[2], begin[3]);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ outer products with the composed 12-channel map
+// The first and last TriplaneConv are 1x1 over the composed map's few channels (in_conv.0: 12 -> C, out.2: C -> 12).
+// With s[px][o] a pixel of the composed NCHW tensor (decompose_featmaps views, src/utils/triplane_util.py:20-25)
+// and v[px][c] an NHWC plane:
+//   outer[p][o][c] = sum_{b,px} s[o]*v[c] ;  ssum[p][o] = sum s[o] ;  vsum[p][c] = sum v[c] ;
+//   optional dv[px][c] = sum_o Wt[p][o][c]*s[px][o]                                      (out.2's dgrad)
+// Two-stage: per-chunk partials, then k_small_reduce adds them in order.
+constexpr int kSmallChunks = 64, kSmallMaxS = 16;
+struct SmallArgs {
+    const float* s;                 // composed [B][S][H+D][W+D]
+    const float* v[3];              // NHWC [B][h][w][C]
+    const float* Wt;                // [3][S][C] or null
+    float* dv[3];                   // NHWC or null
+    float* part;                    // [3][chunks][S+1][C] (row S = vsum) followed by [3][chunks][S] (ssum)
+    int H, W, D, S, C, B;
+};
+__device__ __forceinline__ size_t composed_index(int p, int H, int W, int D, int S, int b, int o, int r, int c) {
+    const int Y = p == 2 ? H + c : r, X = p == 0 ? c : (p == 1 ? W + c : r);
+    return ((size_t(b) * S + o) * (H + D) + Y) * (W + D) + X;
+}
+__global__ __launch_bounds__(256) void k_small_outer(SmallArgs a) {
+    __shared__ float ss[kSmallMaxS];
+    const int chunk = blockIdx.x, p = blockIdx.y;
+    const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
+    const long long npix = (long long)a.B * h * w;
+    const long long p0 = npix * chunk / kSmallChunks, p1 = npix * (chunk + 1) / kSmallChunks;
+    const int S = a.S, C = a.C;
+    // each thread owns channels tid, tid+256, ... ; accumulators for up to 2 channels per thread (C <= 512)
+    float acc[2][kSmallMaxS + 1];
+    for (int k = 0; k < 2; ++k) for (int o = 0; o <= kSmallMaxS; ++o) acc[k][o] = 0.f;
+    float ssum = 0.f;                                   // thread o < S accumulates sum s[o]
+    for (long long q = p0; q < p1; ++q) {
+        const int b = int(q / ((long long)h * w));
+        const long long pq = q % ((long long)h * w);
+        const int r = int(pq / w), c = int(pq % w);
+        __syncthreads();
+        if (int(threadIdx.x) < S) {
+            const float sv = a.s[composed_index(p, a.H, a.W, a.D, S, b, threadIdx.x, r, c)];
+            ss[threadIdx.x] = sv; ssum += sv;
+        }
+        __syncthreads();
+        for (int k = 0; k < 2; ++k) {
+            const int ch = threadIdx.x + k * 256;
+            if (ch >= C) break;
+            const float v = a.v[p][size_t(q) * C + ch];
+            float dv = 0.f;
+            for (int o = 0; o < S; ++o) {
+                acc[k][o] = fmaf(ss[o], v, acc[k][o]);
+                if (a.Wt) dv = fmaf(a.Wt[(size_t(p) * S + o) * C + ch], ss[o], dv);
+            }
+            acc[k][S] += v;
+            if (a.dv[p]) a.dv[p][size_t(q) * C + ch] = dv;
+        }
+    }
+    float* part = a.part + (size_t(p) * kSmallChunks + chunk) * (S + 1) * C;
+    for (int k = 0; k < 2; ++k) {
+        const int ch = threadIdx.x + k * 256;
+        if (ch >= C) break;
+        for (int o = 0; o <= S; ++o) part[size_t(o) * C + ch] = acc[k][o];
+    }
+    float* sp = a.part + size_t(3) * kSmallChunks * (S + 1) * C + (size_t(p) * kSmallChunks + chunk) * S;
+    if (int(threadIdx.x) < S) sp[threadIdx.x] = ssum;
+}
+struct SmallRedArgs {
+    const float* part; int S, C;
+    float* outer[3]; int outer_transposed;   // 0: outer[p][o*C + c] ; 1: outer[p][c*S + o]
+    float* ssum[3]; float* vsum[3];          // optional
+};
+__global__ void k_small_reduce(SmallRedArgs a) {
+    const int p = blockIdx.y, S = a.S, C = a.C;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (S + 1) * C) {
+        const int o = idx / C, c = idx % C;
+        double s = 0;
+        for (int k = 0; k < kSmallChunks; ++k) s += a.part[((size_t(p) * kSmallChunks + k) * (S + 1) + o) * C + c];
+        if (o < S) a.outer[p][a.outer_transposed ? size_t(c) * S + o : size_t(o) * C + c] = float(s);
+        else if (a.vsum[p]) a.vsum[p][c] = float(s);
+    } else if (idx < (S + 1) * C + S && a.ssum[p]) {
+        const int o = idx - (S + 1) * C;
+        double s = 0;
+        for (int k = 0; k < kSmallChunks; ++k)
+            s += a.part[size_t(3) * kSmallChunks * (S + 1) * C + (size_t(p) * kSmallChunks + k) * S + o];
+        a.ssum[p][o] = float(s);
+    }
+}
+size_t small_outer_ws_floats(int S, int C) { return size_t(3) * kSmallChunks * ((S + 1) * C + S); }
+int launch_small_outer(const SmallOuter& s, hipStream_t st) {
+    S3D_CHECK(s.S <= kSmallMaxS && s.C <= 512, S3D_ERR_UNSUPPORTED, "small_outer: S=%d C=%d", s.S, s.C);
+    SmallArgs a;
+    a.s = s.s; a.Wt = s.Wt; a.part = s.ws; a.H = s.H; a.W = s.W; a.D = s.D; a.S = s.S; a.C = s.C; a.B = s.B;
+    for (int p = 0; p < 3; ++p) { a.v[p] = s.v.p[p]; a.dv[p] = s.dv ? s.dv->p[p] : nullptr; }
+    hipLaunchKernelGGL(k_small_outer, dim3(kSmallChunks, 3), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    SmallRedArgs r;
+    r.part = s.ws; r.S = s.S; r.C = s.C; r.outer_transposed = s.outer_transposed;
+    for (int p = 0; p < 3; ++p) { r.outer[p] = s.outer[p]; r.ssum[p] = s.ssum ? s.ssum[p] : nullptr; r.vsum[p] = s.vsum ? s.vsum[p] : nullptr; }
+    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv((s.S + 1) * s.C + s.S, 256), 3), dim3(256), 0, st, r);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ resampling backward
+// avg_pool2d(2,2) backward (+ the skip-connection slice of the concat gradient): one thread per float4
+struct PoolBwdArgs {
+    const float* dpool[3]; const float* dskip[3]; float* out[3];
+    int h[3], w[3];
+    int cq, skip_cq, skip_q0, B;
+    long long begin[4];
+};
+__global__ void k_pool_bwd_add(PoolBwdArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.begin[3] * a.B) return;
+    const int b = int(i / a.begin[3]);
+    long long r = i % a.begin[3];
+    const int p = r >= a.begin[2] ? 2 : (r >= a.begin[1] ? 1 : 0);
+    r -= a.begin[p];
+    const int q = int(r % a.cq);
+    const long long pix = r / a.cq;
+    const int h = a.h[p], w = a.w[p], hp = h / 2, wp = w / 2;
+    const int y = int(pix / w), x = int(pix % w);
+    float4 o = make_float4(0, 0, 0, 0);
+    if (a.dpool[p] && y / 2 < hp && x / 2 < wp) {
+        const float4 v = reinterpret_cast<const float4*>(a.dpool[p])[((size_t(b) * hp + y / 2) * wp + x / 2) * a.cq + q];
+        o.x = 0.25f * v.x; o.y = 0.25f * v.y; o.z = 0.25f * v.z; o.w = 0.25f * v.w;
+    }
+    if (a.dskip[p]) {
+        const float4 v = reinterpret_cast<const float4*>(a.dskip[p])[((size_t(b) * h + y) * w + x) * a.skip_cq + a.skip_q0 + q];
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    }
+    reinterpret_cast<float4*>(a.out[p])[((size_t(b) * h + y) * w + x) * a.cq + q] = o;
+}
+int launch_pool_bwd_add(const Tri* dpool, const Tri* dskip, int skip_coff, int B, Tri& out, hipStream_t st) {
+    PoolBwdArgs a;
+    a.cq = out.C / 4; a.B = B; a.skip_cq = dskip ? dskip->C / 4 : 0; a.skip_q0 = skip_coff / 4; a.begin[0] = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.dpool[p] = dpool ? dpool->p[p] : nullptr; a.dskip[p] = dskip ? dskip->p[p] : nullptr; a.out[p] = out.p[p];
+        a.h[p] = out.g.h[p]; a.w[p] = out.g.w[p];
+        a.begin[p + 1] = a.begin[p] + (long long)out.g.h[p] * out.g.w[p] * a.cq;
+    }
+    const long long n = a.begin[3] * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_pool_bwd_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// bilinear (align_corners=False) backward as a gather: d_in[y][x] = sum over the output pixels whose two source
+// taps include (y, x), with the weights recomputed exactly as k_bilinear computes them.
+__device__ __forceinline__ void bl_src(int o, int in, float scale, int& i0, int& i1, float& l0, float& l1) {
+    float f = scale * (float(o) + 0.5f) - 0.5f; f = f < 0.f ? 0.f : f;
+    i0 = int(f); i0 = i0 > in - 1 ? in - 1 : i0;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = f - float(i0); l0 = 1.f - l1;
+}
+__global__ void k_bilinear_bwd(const float* __restrict__ dout, float* __restrict__ din, int B, int cq, int hi, int wi,
+                               int ho, int wo, int out_cq, int out_q0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)B * hi * wi * cq;
+    if (i >= n) return;
+    const int q = int(i % cq);
+    long long r = i / cq;
+    const int x = int(r % wi); r /= wi;
+    const int y = int(r % hi);
+    const int b = int(r / hi);
+    const float sh = float(hi) / float(ho), sw = float(wi) / float(wo);
+    // candidate output rows: src in (y-1, y+1)  <=>  o in ((y-0.5)/s - 0.5, (y+1.5)/s - 0.5); widen by one and clamp
+    int oy0 = int(floorf((float(y) - 0.5f) / sh - 0.5f)) - 1, oy1 = int(ceilf((float(y) + 1.5f) / sh - 0.5f)) + 1;
+    int ox0 = int(floorf((float(x) - 0.5f) / sw - 0.5f)) - 1, ox1 = int(ceilf((float(x) + 1.5f) / sw - 0.5f)) + 1;
+    oy0 = max(oy0, 0); oy1 = min(oy1, ho - 1); ox0 = max(ox0, 0); ox1 = min(ox1, wo - 1);
+    if (y == 0) oy0 = 0;                     // clamped sources (src < 0) all land on index 0
+    if (x == 0) ox0 = 0;
+    float4 acc = make_float4(0, 0, 0, 0);
+    const float4* src = reinterpret_cast<const float4*>(dout);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+        int y0, y1; float ly0, ly1;
+        bl_src(oy, hi, sh, y0, y1, ly0, ly1);
+        const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+            int x0, x1; float lx0, lx1;
+            bl_src(ox, wi, sw, x0, x1, lx0, lx1);
+            const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+            if (wx == 0.f) continue;
+            const float4 v = src[((size_t(b) * ho + oy) * wo + ox) * out_cq + out_q0 + q];
+            const float wgt = wy * wx;
+            acc.x = fmaf(wgt, v.x, acc.x); acc.y = fmaf(wgt, v.y, acc.y); acc.z = fmaf(wgt, v.z, acc.z); acc.w = fmaf(wgt, v.w, acc.w);
+        }
+    }
+    reinterpret_cast<float4*>(din)[i] = acc;
+}
+int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out_cstride, int out_coff, float* din, int hi,
+                        int wi, hipStream_t st) {
+    const long long n = (long long)B * hi * wi * (C / 4);
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_bilinear_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, din, B, C / 4, hi, wi, ho, wo,
+                       out_cstride / 4, out_coff / 4);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ the timestep MLP backward (tiny)
+// dW[o][i] = sum_b dy[b][o] * f(in[b][i]) ; db[o] = sum_b dy[b][o]        (f = identity, SiLU, or sinusoid of t)
+__device__ __forceinline__ float lin_in(const float* in, int b, int i, int I, int mode) {
+    if (mode == 2) {                                    // timestep_embedding (src/diffusion/nn.py:103-121): cos | sin
+        const int half = I / 2;
+        if (i >= 2 * half) return 0.f;
+        const int k = i < half ? i : i - half;
+        const float freq = expf(-logf(10000.0f) * float(k) / float(half));
+        const float arg = in[b] * freq;
+        return i < half ? cosf(arg) : sinf(arg);
+    }
+    const float v = in[size_t(b) * I + i];
+    return mode == 1 ? v * (1.0f / (1.0f + expf(-v))) : v;
+}
+__global__ void k_linear_bwd_w(const float* __restrict__ dy, int dy_stride, const float* __restrict__ in, int B, int I, int O,
+                               int in_mode, float* __restrict__ dW, float* __restrict__ db) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)O * I) return;
+    const int i = int(idx % I), o = int(idx / I);
+    float s = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = dy[size_t(b) * dy_stride + o]; s = fmaf(d, lin_in(in, b, i, I, in_mode), s); sb += d; }
+    dW[idx] = s;
+    if (i == 0) db[o] = sb;
+}
+// dx[b][i] = (sum_o dy[b][o] * W[o][i]) * (in_mode == 1 ? silu'(in[b][i]) : 1)
+__global__ void k_linear_bwd_x(const float* __restrict__ dy, int dy_stride, const float* __restrict__ W,
+                               const float* __restrict__ in, int B, int I, int O, int in_mode, float* __restrict__ dx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * I) return;
+    const int i = idx % I, b = idx / I;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(dy[size_t(b) * dy_stride + o], W[size_t(o) * I + i], s);
+    if (in_mode == 1) {
+        const float v = in[idx], sg = 1.0f / (1.0f + expf(-v));
+        s *= sg * (1.0f + v * (1.0f - sg));
+    }
+    dx[idx] = s;
+}
+int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
+                      float* db, float* dx, hipStream_t st) {
+    if (dW) {
+        hipLaunchKernelGGL(k_linear_bwd_w, dim3((unsigned)(((long long)O * I + 255) / 256)), dim3(256), 0, st, dy, dy_stride, in, B, I,
+                           O, in_mode, dW, db);
+        S3D_HIP(hipGetLastError());
+    }
+    if (dx) {
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3(cdiv(B * I, 256)), dim3(256), 0, st, dy, dy_stride, W, in, B, I, O, in_mode, dx);
+        S3D_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+// scale a [B][L][C] vector set in place (mean gradients: divide by the averaged length)
+__global__ void k_scale(float* __restrict__ v, long long n, float s) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= s;
+}
+int launch_scale(float* v, long long n, float s, hipStream_t st) {
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, n, s);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ diffusion training elementwise pieces
+// q_sample (src/diffusion/gaussian_diffusion.py:189-207): x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps
+__global__ void k_q_sample(const float* __restrict__ x0, const float* __restrict__ eps, const float* __restrict__ sa,
+                           const float* __restrict__ sb, const int64_t* __restrict__ t, long long per, int B,
+                           float* __restrict__ xt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * B) return;
+    const int b = int(i / per);
+    xt[i] = sa[t[b]] * x0[i] + sb[t[b]] * eps[i];
+}
+// per-plane mean squared error of the composed maps (:838-851) and its gradient:
+// terms[b][p] = mean over the plane's C*h*w elements of (target - out)^2 ; d_out = 2 (out - target) * wgt[b][p] / n_p
+// (zero in the unused DxD corner).  Deterministic two-stage sum.
+constexpr int kMseChunks = 32;
+struct MseArgs { const float* out; const float* tgt; float* part; float* terms; const float* wgt; float* dout; int B, C, H, W, D; };
+__global__ __launch_bounds__(256) void k_mse_partials(MseArgs a) {
+    __shared__ double red[256];
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
+    const long long n = (long long)a.C * h * w;
+    const long long i0 = n * chunk / kMseChunks, i1 = n * (chunk + 1) / kMseChunks;
+    double s = 0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int c = int(i % w); long long r = i / w;
+        const int rr = int(r % h), ch = int(r / h);
+        const size_t k = composed_index(p, a.H, a.W, a.D, a.C, b, ch, rr, c);
+        const float d = a.tgt[k] - a.out[k];
+        s += double(d * d);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (int(threadIdx.x) < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) a.part[(size_t(b) * 3 + p) * kMseChunks + chunk] = float(red[0]);
+}
+__global__ void k_mse_finalize(MseArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.B * 3) return;
+    const int p = idx % 3;
+    const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
+    double s = 0;
+    for (int k = 0; k < kMseChunks; ++k) s += a.part[size_t(idx) * kMseChunks + k];
+    a.terms[idx] = float(s / (double(a.C) * h * w));
+}
+__global__ void k_mse_grad(MseArgs a) {
+    const long long per = (long long)a.C * (a.H + a.D) * (a.W + a.D);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * a.B) return;
+    const int b = int(i / per);
+    const int X = int(i % (a.W + a.D)), Y = int((i / (a.W + a.D)) % (a.H + a.D));
+    float g = 0.f;
+    if (!(Y >= a.H && X >= a.W)) {
+        const int p = Y >= a.H ? 2 : (X >= a.W ? 1 : 0);
+        const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
+        g = 2.0f * (a.out[i] - a.tgt[i]) * a.wgt[b * 3 + p] / float((long long)a.C * h * w);
+    }
+    a.dout[i] = g;
+}
+int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
+                    float* xt, hipStream_t st) {
+    const long long n = per * B;
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, eps, sa, sb, t, per, B, xt);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st) {
+    MseArgs a{out, tgt, ws, terms, nullptr, nullptr, B, C, H, W, D};
+    if (!B) return 0;
+    hipLaunchKernelGGL(k_mse_partials, dim3(kMseChunks, 3, B), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_mse_finalize, dim3(cdiv(B * 3, 64)), dim3(64), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st) {
+    MseArgs a{out, tgt, nullptr, nullptr, wgt, dout, B, C, H, W, D};
+    const long long n = (long long)B * C * (H + D) * (W + D);
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_mse_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ AdamW + EMA on the flat parameter vector
+// torch.optim.AdamW (decoupled weight decay, bias correction) followed by update_ema (src/diffusion/nn.py:55-65)
+// for up to 4 EMA copies, one pass over the parameters.
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; float* ema[4]; float ema_rate[4]; int n_ema;
+    long long n; float lr, b1, b2, eps, wd, c1, c2s;          // c1 = 1-b1^t, c2s = sqrt(1-b2^t)
+};
+__global__ void k_adamw_ema(AdamArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float p = a.p[i];
+    const float g = a.g[i];
+    p *= 1.0f - a.lr * a.wd;
+    const float m = a.m[i] * a.b1 + (1.0f - a.b1) * g;             // exp_avg.lerp_(grad, 1-b1) == mul_(b1).add_(g, 1-b1) to 1 ulp
+    const float v = a.v[i] * a.b2 + (1.0f - a.b2) * g * g;
+    a.m[i] = m; a.v[i] = v;
+    const float denom = sqrtf(v) / a.c2s + a.eps;
+    p -= (a.lr / a.c1) * (m / denom);
+    a.p[i] = p;
+    for (int k = 0; k < a.n_ema; ++k) a.ema[k][i] = a.ema[k][i] * a.ema_rate[k] + (1.0f - a.ema_rate[k]) * p;
+}
+int launch_adamw_ema(float* p, const float* g, float* m, float* v, float* const* ema, const float* ema_rate, int n_ema, long long n,
+                     float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st) {
+    S3D_CHECK(n_ema >= 0 && n_ema <= 4 && step >= 1, S3D_ERR_INVALID, "adamw_ema: n_ema=%d step=%d", n_ema, step);
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n_ema = n_ema; a.n = n;
+    for (int k = 0; k < 4; ++k) { a.ema[k] = k < n_ema ? ema[k] : nullptr; a.ema_rate[k] = k < n_ema ? ema_rate[k] : 0.f; }
+    a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.wd = wd;
+    a.c1 = float(1.0 - pow(double(b1), step)); a.c2s = float(sqrt(1.0 - pow(double(b2), step)));
+    if (!n) return 0;
+    hipLaunchKernelGGL(k_adamw_ema, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace s3d

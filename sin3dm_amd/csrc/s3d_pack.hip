@@ -1,0 +1,223 @@
+// s3d_pack.hip — device-side weight repacking for the training tier.
+//
+// Inference packs the kernel-layout weight image on the host once (s3d_unet.hip:pack_all).  During training the
+// parameters change on the device every step, so the same image — plus the transposed operators the backward pass
+// needs — is rebuilt by ONE launch from the flat, reference-layout master parameter vector (OIHW conv weights,
+// [out][in] linears; SURVEY.md §8b state-dict names).  Every job writes the same values the host packer would
+// (sums in double, same order), which tests/test_hip_train.py checks bit-for-bit.
+#include "s3d_model.h"
+
+namespace s3d {
+
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_RANK1, PK_RANK1_BWD };
+
+__device__ __forceinline__ bool var_tap(int var, int o) {
+    // taps of the summed-out axis that stay inside the image, by edge variant (0 interior, 1 first, 2 last, 3 single)
+    return o == 1 || (o == 0 && (var == 0 || var == 2)) || (o == 2 && (var == 0 || var == 1));
+}
+
+__global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ descs, int ndesc, const float* __restrict__ flat,
+                                                float* __restrict__ wbuf, float* __restrict__ tbuf) {
+    // find this block's job (descs are sorted by block_begin)
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= int(blockIdx.x)) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const long long i = (long long)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
+    if (i >= d.n) return;
+    const float* W = flat + d.src;
+    float* dst = (d.to_tbuf ? tbuf : wbuf) + d.dst;
+    const int cout = d.cout, ctot = d.ctot, cin = d.cin, taps = d.taps;
+    switch (d.kind) {
+        case PK_COPY: dst[i] = W[i]; break;
+        case PK_TRANS2D: {                       // src [cout][cin] -> dst [cin][cout]
+            const int c = int(i / cout), o = int(i % cout);
+            dst[i] = W[(size_t)o * cin + c];
+            break;
+        }
+        case PK_DENSE: {                         // dst [(t*cout + co)*cin + c]
+            const int c = int(i % cin); long long r = i / cin;
+            const int co = int(r % cout), t = int(r / cout);
+            dst[i] = W[((size_t)co * ctot + c) * taps + t];
+            break;
+        }
+        case PK_DENSE_T: {                       // dst [(t*cin + c)*cout + co]: the dgrad operator as a forward conv
+            const int co = int(i % cout); long long r = i / cout;
+            const int c = int(r % cin), t = int(r / cin);
+            dst[i] = W[((size_t)co * ctot + c) * taps + (taps - 1 - t)];
+            break;
+        }
+        case PK_WINO:
+        case PK_WINO_T: {                        // item = one (n, k) filter of the (possibly transposed) operator
+            // operator dims: N outputs x K inputs; forward: N = cout, K = cin; transposed: N = cin, K = cout, taps flipped
+            const bool tr = d.kind == PK_WINO_T;
+            const int N = tr ? cin : cout, K = tr ? cout : cin;
+            const int n = int(i / K), k = int(i % K);
+            double g[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                g[q] = tr ? double(W[((size_t)k * ctot + n) * 9 + (8 - q)]) : double(W[((size_t)n * ctot + k) * 9 + q]);
+            const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            double t[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) t[u][q] = G[u][0] * g[0 * 3 + q] + G[u][1] * g[1 * 3 + q] + G[u][2] * g[2 * 3 + q];
+            const int k8t = K / 8;
+            const int nt = n >> 5, jn = n & 31, k8 = k >> 3, hf = (k >> 2) & 1, e = k & 3;
+            (void)N;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double uv = t[u][0] * G[v][0] + t[u][1] * G[v][1] + t[u][2] * G[v][2];
+                    dst[((((size_t)nt * k8t + k8) * 16 + (u * 4 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                }
+            break;
+        }
+        case PK_RANK1: {                         // dst [(t*4*cout + var*cout + co)*cin + c]
+            const int c = int(i % cin); long long r = i / cin;
+            const int co = int(r % cout); r /= cout;
+            const int var = int(r % 4), t = int(r / 4);
+            double s = 0;
+            for (int o = 0; o < 3; ++o) {
+                if (!var_tap(var, o)) continue;
+                const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
+                s += double(W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw]);
+            }
+            dst[i] = float(s);
+            break;
+        }
+        case PK_RANK1_BWD: {                     // dst [(tap*cin + c)*(3*cout) + j*cout + co]
+            const int co = int(i % cout); long long r = i / cout;
+            const int j = int(r % 3); r /= 3;
+            const int c = int(r % cin), tap = int(r / cin);
+            const int dr = d.col_varying ? j : 2 - tap, dc = d.col_varying ? 2 - tap : j;
+            dst[i] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + dr * 3 + dc];
+            break;
+        }
+    }
+}
+
+namespace {
+
+struct Plan {
+    s3d_unet* m;
+    size_t tsize = 0;                                  // floats in tbuf
+    size_t flat_of(const std::string& name) const {
+        for (size_t i = 0; i < m->specs.size(); ++i)
+            if (m->specs[i].name == name) return m->flat_off[i];
+        return size_t(-1);
+    }
+    size_t talloc(size_t n) { size_t off = (tsize + 63) & ~size_t(63); tsize = off + n; return off; }
+    void add(int kind, size_t src, size_t dst, long long n, int cout = 0, int ctot = 0, int cin = 0, int taps = 0, int slot = 0,
+             int colv = 0, int to_t = 0) {
+        PackDesc d{};
+        d.kind = kind; d.cout = cout; d.ctot = ctot; d.cin = cin; d.slot = slot; d.taps = taps; d.col_varying = colv;
+        d.to_tbuf = to_t; d.src = (long long)src; d.dst = (long long)dst; d.n = n;
+        m->descs.push_back(d);
+    }
+    void norm(const std::string& prefix, int c, const NormW& nw) {
+        static const char* kP[3] = {"xy", "xz", "yz"};
+        for (int p = 0; p < 3; ++p) {
+            add(PK_COPY, flat_of(prefix + ".norm_" + kP[p] + ".weight"), nw.gamma[p], c);
+            add(PK_COPY, flat_of(prefix + ".norm_" + kP[p] + ".bias"), nw.beta[p], c);
+        }
+    }
+    void tconv(const std::string& prefix, const ConvW& cw, ConvWT& wt) {
+        static const char* kP[3] = {"xy", "xz", "yz"};
+        const int cin = cw.cin, cout = cw.cout, k = cw.k, taps = k * k, ctot = cw.rollout ? 3 * cin : cin;
+        for (int p = 0; p < 3; ++p) {
+            const size_t w = flat_of(prefix + ".conv_" + kP[p] + ".weight");
+            add(PK_COPY, flat_of(prefix + ".conv_" + kP[p] + ".bias"), cw.bias[p], cout);
+            add(PK_DENSE, w, cw.dense[p], (long long)taps * cout * cin, cout, ctot, cin, taps);
+            wt.dense_T[p] = talloc(size_t(taps) * cout * cin);
+            add(PK_DENSE_T, w, wt.dense_T[p], (long long)taps * cout * cin, cout, ctot, cin, taps, 0, 0, 1);
+            if (k == 3) {
+                add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
+                // transposed operator: cin outputs (padded to 32) x cout inputs
+                wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
+                add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
+            }
+            if (!cw.rollout) continue;
+            const bool a_is_col = (p == 0);
+            for (int slot = 1; slot <= 2; ++slot) {
+                const bool colv = (slot == 1) ? a_is_col : !a_is_col;
+                add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)3 * 4 * cout * cin, cout, ctot, cin, 9, slot, colv);
+                const size_t off = talloc(size_t(3) * cin * 3 * cout);
+                (colv ? wt.rcol_T[p] : wt.rrow_T[p]) = off;
+                add(PK_RANK1_BWD, w, off, (long long)3 * cin * 3 * cout, cout, ctot, cin, 9, slot, colv, 1);
+            }
+        }
+    }
+};
+
+}  // namespace
+
+// Build the repack plan for the current packed layout (pack_all must have run) and allocate the training image.
+int build_pack_plan(s3d_unet* m) {
+    S3D_CHECK(m->packed, S3D_ERR_INVALID, "build_pack_plan: parameters are not packed yet");
+    const s3d_unet_cfg& c = m->cfg;
+    const int mc = c.model_channels, ted = 4 * mc;
+    const bool ssn = c.use_scale_shift_norm != 0;
+    m->descs.clear();
+    Plan P{m};
+    P.add(PK_COPY, P.flat_of("time_embed.0.weight"), m->te0_w, (long long)ted * mc);
+    P.add(PK_COPY, P.flat_of("time_embed.0.bias"), m->te0_b, ted);
+    P.add(PK_COPY, P.flat_of("time_embed.2.weight"), m->te2_w, (long long)ted * ted);
+    P.add(PK_COPY, P.flat_of("time_embed.2.bias"), m->te2_b, ted);
+    m->in_blocks_t.assign(m->in_blocks.size(), ResBlockWT());
+    m->out_blocks_t.assign(m->out_blocks.size(), ResBlockWT());
+    auto block = [&](const ResBlockW& rb, ResBlockWT& wt) {
+        const int eo = ssn ? 2 * rb.Cout : rb.Cout;
+        P.add(PK_COPY, P.flat_of(rb.prefix + ".emb_layers.1.weight"), m->film_w + size_t(rb.film_off) * ted, (long long)eo * ted);
+        P.add(PK_COPY, P.flat_of(rb.prefix + ".emb_layers.1.bias"), m->film_b + rb.film_off, eo);
+        P.norm(rb.prefix + ".in_layers.0", rb.C, rb.n1);
+        P.tconv(rb.prefix + ".in_layers.2", rb.c1, wt.c1);
+        P.norm(rb.prefix + ".out_layers.0", rb.Cout, rb.n2);
+        P.tconv(rb.prefix + ".out_layers.2", rb.c2, wt.c2);
+        if (rb.has_skip) P.tconv(rb.prefix + ".skip_connection", rb.skip, wt.skip);
+    };
+    for (size_t i = 0; i < m->in_blocks.size(); ++i) block(m->in_blocks[i], m->in_blocks_t[i]);
+    for (size_t i = 0; i < m->out_blocks.size(); ++i) block(m->out_blocks[i], m->out_blocks_t[i]);
+    static const char* kP[3] = {"xy", "xz", "yz"};
+    {
+        const int ci = c.in_channels, co = c.channel_mult[0] * mc;
+        for (int p = 0; p < 3; ++p) {
+            P.add(PK_TRANS2D, P.flat_of(std::string("in_conv.0.conv_") + kP[p] + ".weight"), m->in_wT + size_t(p) * ci * co,
+                  (long long)ci * co, co, 0, ci);
+            P.add(PK_COPY, P.flat_of(std::string("in_conv.0.conv_") + kP[p] + ".bias"), m->in_b + size_t(p) * co, co);
+        }
+    }
+    {
+        const int ci = c.channel_mult[0] * mc, co = c.out_channels;
+        P.norm("out.0", ci, m->out_norm);
+        for (int p = 0; p < 3; ++p) {
+            P.add(PK_COPY, P.flat_of(std::string("out.2.conv_") + kP[p] + ".weight"), m->out_w + size_t(p) * co * ci, (long long)co * ci);
+            P.add(PK_COPY, P.flat_of(std::string("out.2.conv_") + kP[p] + ".bias"), m->out_b + size_t(p) * co, co);
+        }
+    }
+    int blocks = 0;
+    for (auto& d : m->descs) {
+        S3D_CHECK(d.src >= 0 && d.src < m->flat_numel, S3D_ERR_INVALID, "build_pack_plan: unresolved parameter");
+        d.block_begin = blocks;
+        blocks += int((d.n + 255) / 256);
+    }
+    m->pack_blocks = blocks;
+    S3D_TRY(m->tbuf.reserve(std::max<size_t>(P.tsize, 64) * sizeof(float)));
+    S3D_HIP(hipMemset(m->tbuf.p, 0, P.tsize * sizeof(float)));       // the Winograd images are zero-padded to 32 outputs
+    S3D_TRY(upload(m->descs_dev, m->descs.data(), m->descs.size() * sizeof(PackDesc)));
+    return 0;
+}
+
+int launch_repack(s3d_unet* m, hipStream_t st) {
+    S3D_CHECK(m->flat && m->pack_blocks > 0, S3D_ERR_INVALID, "repack: no flat parameter vector attached");
+    hipLaunchKernelGGL(k_repack, dim3(m->pack_blocks), dim3(256), 0, st, static_cast<const PackDesc*>(m->descs_dev.p),
+                       int(m->descs.size()), m->flat, static_cast<float*>(m->wbuf.p), static_cast<float*>(m->tbuf.p));
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace s3d

@@ -1,103 +1,7 @@
 // s3d_unet.hip — host side of the denoiser: parameter registry, weight repacking and the kernel
 // sequence of TriplaneUNetModelSmall.forward (src/diffusion/unet_triplane.py:465-510).
-#include <algorithm>
-#include <cmath>
-#include <memory>
+#include "s3d_model.h"
 
-#include "s3d_common.h"
-
-namespace s3d {
-
-static const char* kPlane[3] = {"xy", "xz", "yz"};
-
-struct ParamSpec {
-    std::string name;
-    std::vector<int64_t> shape;
-    size_t numel() const { size_t n = 1; for (auto d : shape) n *= size_t(d); return n; }
-};
-
-struct NormW { size_t gamma[3], beta[3]; };
-struct ResBlockW {
-    std::string prefix;
-    int C, Cout;
-    NormW n1, n2;
-    ConvW c1, c2, skip;
-    bool has_skip;
-    int film_off;                      // offset of this block's emb_layers output in the concatenated FiLM row
-};
-
-}  // namespace s3d
-
-using namespace s3d;
-
-struct s3d_unet {
-    s3d_unet_cfg cfg;
-    std::vector<ParamSpec> specs;
-    std::map<std::string, std::vector<float>> host;     // as handed to set_param (PyTorch layouts)
-    bool packed = false;
-
-    // packed parameters, one device allocation, offsets in floats
-    DevBuf wbuf;
-    std::vector<float> stage;                            // host staging of the packed image
-    size_t te0_w, te0_b, te2_w, te2_b, film_w, film_b;
-    int film_total = 0;
-    size_t in_wT, in_b, out_w, out_b;
-    NormW out_norm;
-    std::vector<ResBlockW> in_blocks, out_blocks;
-
-    Arena arena;
-
-    // optional live timing of the convolution launches (s3d_unet_profile)
-    struct ProfRec { int cls; hipEvent_t e0, e1; double flops; };
-    int prof_every = 0;
-    long fwd_count = 0;
-    bool prof_now = false;
-    std::vector<ProfRec> prof_recs;
-    std::vector<hipEvent_t> prof_pool;
-    int64_t prof_forwards = 0;
-    hipEvent_t prof_event() {
-        hipEvent_t e = nullptr;
-        if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
-        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
-        return e;
-    }
-    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
-        if (!prof_now) return launch_conv(kind, ca, st);
-        // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
-        int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : 25));
-        double pix = 0;
-        for (int j = 0; j < ca.njobs; ++j) pix += double(ca.job[j].h) * ca.job[j].w;
-        ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B};
-        if (r.e0) (void)hipEventRecord(r.e0, st);
-        int rc = launch_conv(kind, ca, st);
-        if (r.e1) (void)hipEventRecord(r.e1, st);
-        prof_recs.push_back(r);
-        return rc;
-    }
-    // side stream for work that is independent of the latency-bound norm/rank-1 chain (the 1x1 skip convolutions)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_ok() {
-        // measured neutral-to-slightly-negative at batch 1 (1.73 vs 1.72 ms/step): opt-in only
-        static const bool enabled = getenv("S3D_SIDE_STREAM") && strcmp(getenv("S3D_SIDE_STREAM"), "1") == 0;
-        if (!enabled) return false;
-        if (!side) {
-            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
-            if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return false;
-        }
-        return ev_fork && ev_join;
-    }
-    ~s3d_unet() {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
-        for (auto& r : prof_recs) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
-        for (auto e : prof_pool) (void)hipEventDestroy(e);
-    }
-
-    const float* dev(size_t off) const { return static_cast<const float*>(wbuf.p) + off; }
-};
 
 namespace s3d {
 
@@ -234,7 +138,7 @@ static void pack_norm(s3d_unet* m, const std::string& prefix, int c, NormW& nw) 
     }
 }
 
-static int pack_all(s3d_unet* m) {
+int pack_all(s3d_unet* m) {
     for (const auto& sp : m->specs)
         S3D_CHECK(m->host.count(sp.name), S3D_ERR_MISSING, "parameter '%s' was never set (load_state_dict incomplete)", sp.name.c_str());
     const s3d_unet_cfg& c = m->cfg;
@@ -293,145 +197,17 @@ static int pack_all(s3d_unet* m) {
 }
 
 // ------------------------------------------------------------------ forward
-struct Fwd {
-    s3d_unet* m;
-    int B;
-    hipStream_t st;
-    const float* film;      // [B][film_total]
-    Arena& ar() { return m->arena; }
 
-    Tri alloc_tri(int C, const Geo& g) {
-        Tri t; t.C = C; t.g = g;
-        for (int p = 0; p < 3; ++p) t.p[p] = ar().alloc<float>(size_t(B) * g.h[p] * g.w[p] * C);
-        return t;
-    }
-    // GroupNorm {mean, rstd} of x: taken from its producer's epilogue when available, otherwise one read pass.
-    int stats_of(const Tri& x, GnStats& out) {
-        if (x.gn) { out.mr = x.gn; return 0; }
-        GnPartials part;
-        part.p = ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64);
-        part.maxparts = kGnChunks; part.nsub = 32;
-        for (int p = 0; p < 3; ++p) part.nparts[p] = kGnChunks;
-        out.mr = ar().alloc<float>(size_t(B) * 3 * 64);
-        if (ar().measuring) return 0;
-        S3D_TRY(launch_gn_partials(x, B, part, st));
-        return launch_gn_finalize(part, x.g, x.C, B, out, st);
-    }
-
-    // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and
-    // the rank-1 tables its epilogue needs.  Returns activated tensor; fills rrow/rcol table pointers.
-    int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
-                 const float* rcol[3]) {
-        const bool measuring = ar().measuring;
-        GnStats stats;
-        S3D_TRY(stats_of(x, stats));
-        y = alloc_tri(x.C, x.g);
-        ActArgs aa;
-        for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(nw.gamma[p]); aa.beta[p] = m->dev(nw.beta[p]); }
-        aa.film = film_ptr; aa.film_stride = m->film_total;
-        const bool roll = cw && cw->rollout;
-        MeanPartials mp; MeanVecs mv;
-        float* tab_row[3]; float* tab_col[3];
-        for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
-        if (roll) {
-            for (int p = 0; p < 3; ++p) {
-                const int h = x.g.h[p], w = x.g.w[p];
-                const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
-                mp.rowpart[p] = ar().alloc<float>(size_t(B) * ntc * h * x.C);
-                mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * x.C);
-                mv.rowmean[p] = ar().alloc<float>(size_t(B) * h * x.C);
-                mv.colmean[p] = ar().alloc<float>(size_t(B) * w * x.C);
-                tab_row[p] = ar().alloc<float>(size_t(B) * h * 4 * cw->cout);
-                tab_col[p] = ar().alloc<float>(size_t(B) * w * 4 * cw->cout);
-                rrow[p] = tab_row[p]; rcol[p] = tab_col[p];
-            }
-        }
-        if (measuring) return 0;
-        S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st));
-        if (!roll) return 0;
-        S3D_TRY(launch_means_finalize(x.g, x.C, B, mp, mv, st));
-        // rank-1 rollout terms: six 1-D convolutions of the mean vectors, all in one launch
-        ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = B; ca.cin = x.C; ca.cout = 4 * cw->cout; ca.njobs = 6;
-        // row-varying / column-varying vector of each plane
-        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
-        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
-        for (int p = 0; p < 3; ++p) {
-            ConvJob& jr = ca.job[2 * p];
-            jr.in = rowvec[p]; jr.wgt = m->dev(cw->rrow[p]); jr.out = tab_row[p]; jr.h = 1; jr.w = x.g.h[p];
-            ConvJob& jc = ca.job[2 * p + 1];
-            jc.in = colvec[p]; jc.wgt = m->dev(cw->rcol[p]); jc.out = tab_col[p]; jc.h = 1; jc.w = x.g.w[p];
-        }
-        S3D_TRY(m->timed_conv(2, CONV_1x3_VEC, ca, st));
-        return 0;
-    }
-
-    // want_stats: also reduce the GroupNorm statistics of the output in the epilogue (3x3 MFMA path only)
-    int conv(const Tri& y, const ConvW& cw, const float* bbias, const float* const rrow[3], const float* const rcol[3],
-             const Tri* res, Tri& out, bool want_stats = false, hipStream_t on = nullptr) {
-        hipStream_t st = on ? on : this->st;
-        out = alloc_tri(cw.cout, y.g);
-        want_stats = want_stats && cw.k == 3 && !conv_use_naive();
-        GnPartials part; GnStats gs{nullptr};
-        if (want_stats) {
-            conv_gn_parts(CONV_3x3, y.g, part.nparts);
-            part.maxparts = std::max(part.nparts[0], std::max(part.nparts[1], part.nparts[2]));
-            part.nsub = cw.cout / gn_subgroup(cw.cout);
-            part.p = ar().alloc<double>(size_t(B) * 3 * part.maxparts * part.nsub * 2);
-            gs.mr = ar().alloc<float>(size_t(B) * 3 * 64);
-            out.gn = gs.mr;
-        }
-        if (ar().measuring) return 0;
-        ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
-        if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
-        for (int p = 0; p < 3; ++p) {
-            ConvJob& J = ca.job[p];
-            J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
-            J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
-            J.bbias = bbias; J.bbias_stride = m->film_total;
-            J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
-            J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
-            J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
-        }
-        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
-        if (want_stats) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
-        return 0;
-    }
-
-    // TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311)
-    int resblock(const ResBlockW& rb, const Tri& x, Tri& out, bool out_feeds_norm) {
-        const bool ssn = m->cfg.use_scale_shift_norm != 0;
-        const float* film_ptr = film ? film + rb.film_off : nullptr;
-        Tri y1, h1, y2;
-        const float *rr[3], *rc[3];
-        // skip_connection(x) only depends on x: enqueue it on the side stream first so it fills the CUs that the
-        // latency-bound norm / rank-1 chain and the Winograd conv's half-empty last round leave idle
-        Tri skip;
-        const Tri* res = &x;
-        const bool fork = rb.has_skip && !ar().measuring && m->side_ok();
-        if (rb.has_skip) {
-            if (fork) { S3D_HIP(hipEventRecord(m->ev_fork, st)); S3D_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
-            S3D_TRY(conv(x, rb.skip, nullptr, nullptr, nullptr, nullptr, skip, false, fork ? m->side : nullptr));
-            if (fork) S3D_HIP(hipEventRecord(m->ev_join, m->side));
-            res = &skip;
-        }
-        S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc));
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, true));   // (!ssn: h = h + emb_out, :298-303)
-        S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc));
-        if (fork) S3D_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
-        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_feeds_norm));
-        return 0;
-    }
-};
-
-static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st) {
+int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
+                Tape* tape) {
     const s3d_unet_cfg& c = m->cfg;
     const int mc = c.model_channels, ted = 4 * mc;
     Fwd f{m, B, st, nullptr};
+    f.tape = tape;
     Arena& ar = m->arena;
     const bool meas = ar.measuring;
     ar.reset();
+    if (tape) { *tape = Tape(); tape->B = B; tape->H = H; tape->W = W; tape->D = D; tape->x = x; tape->t = t; }
 
     // emb = time_embed(timestep_embedding(t)) ; all blocks' emb_layers in one stacked linear
     float* e1 = ar.alloc<float>(size_t(B) * ted);
@@ -439,14 +215,17 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
     float* film = ar.alloc<float>(size_t(B) * m->film_total);
     f.film = film;
     if (!meas) {
-        S3D_TRY(launch_linear(t, B, mc, m->dev(m->te0_w), m->dev(m->te0_b), ted, e1, 2, 1, st));
-        S3D_TRY(launch_linear(e1, B, ted, m->dev(m->te2_w), m->dev(m->te2_b), ted, emb, 0, 0, st));
+        // training keeps the pre-activation of time_embed.0 (SiLU is applied on the way into the next layer instead)
+        S3D_TRY(launch_linear(t, B, mc, m->dev(m->te0_w), m->dev(m->te0_b), ted, e1, 2, tape ? 0 : 1, st));
+        S3D_TRY(launch_linear(e1, B, ted, m->dev(m->te2_w), m->dev(m->te2_b), ted, emb, tape ? 1 : 0, 0, st));
         S3D_TRY(launch_linear(emb, B, ted, m->dev(m->film_w), m->dev(m->film_b), m->film_total, film, 1, 0, st));
     }
+    if (tape) { tape->pre1 = e1; tape->emb = emb; tape->film = film; }
 
     Geo g0 = Geo::from_hwd(H, W, D);
     Tri h = f.alloc_tri(c.channel_mult[0] * mc, g0);
     if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st));
+    if (tape) tape->h0 = h;
 
     std::vector<Tri> hs;
     for (int level = 0; level < c.n_levels; ++level) {
@@ -459,12 +238,14 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
         }
         Tri o;
         S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1));   // the deepest output goes straight into a norm
+        if (tape) { f.last_rb.index = level; f.last_rb.is_out = false; tape->in_rb.push_back(f.last_rb); }
         h = o;
         hs.push_back(o);
     }
     for (int oi = 0; oi < c.n_levels; ++oi) {
         const int level = c.n_levels - 1 - oi;
         Tri inp;
+        if (tape) tape->up_src.push_back(oi == 0 ? Tri() : h);
         if (oi == 0) { inp = hs.back(); hs.pop_back(); }
         else {
             // previous block's output `h` -> TriplaneUpsample2x (:106-124) -> resize to the skip's size when it
@@ -493,12 +274,14 @@ static int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H
         }
         Tri o;
         S3D_TRY(f.resblock(m->out_blocks[oi], inp, o, oi == c.n_levels - 1));       // ... and so does the last one (out head)
+        if (tape) { f.last_rb.index = oi; f.last_rb.is_out = true; tape->out_rb.push_back(f.last_rb); tape->cat_in.push_back(inp); }
         h = o;
         (void)level;
     }
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
     GnStats stats;
     S3D_TRY(f.stats_of(h, stats));
+    if (tape) { tape->head_in = h; tape->head_stats = stats; tape->arena_off = ar.off; tape->valid = !meas; }
     if (!meas) {
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
@@ -560,11 +343,12 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
     S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "unet_forward: null argument");
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "unet_forward: B,H,W,D must be >= 1");
     if (!m->packed) S3D_TRY(pack_all(m));
+    m->tape.valid = false;                    // the workspace is shared with the training tape
     hipStream_t st = static_cast<hipStream_t>(stream);
     // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows)
     m->arena.measuring = true;
     m->arena.high = 0;
-    int rc = run_forward(m, x, t, B, H, W, D, out, st);
+    int rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
     m->arena.measuring = false;
     if (rc) return rc;
     if (m->arena.high > m->arena.buf.cap) {
@@ -574,7 +358,7 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
     m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
     ++m->fwd_count;
     if (m->prof_now) ++m->prof_forwards;
-    rc = run_forward(m, x, t, B, H, W, D, out, st);
+    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
     m->prof_now = false;
     return rc;
 }

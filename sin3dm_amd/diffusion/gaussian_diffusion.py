@@ -266,8 +266,108 @@ class GaussianDiffusion:
             pass
         return final["sample"]
 
+    # ------------------------------------------------------------------ training
+    def _train_tables(self, device):
+        key = "train/" + str(device)
+        tab = self._dev_tables.get(key)
+        if tab is None:
+            rows = np.stack([self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod])
+            tab = th.from_numpy(rows.astype(np.float32)).contiguous().to(device)
+            self._dev_tables[key] = tab
+        return tab
+
+    def q_sample_hip(self, x_start, t, noise):
+        """q_sample (:189-207) as one kernel: the coefficient gather happens on the device."""
+        _lib.require_gpu(x_start)
+        x0, eps = x_start.contiguous().float(), noise.contiguous().float()
+        tab = self._train_tables(x0.device)
+        t64 = t.to(device=x0.device, dtype=th.int64).contiguous()
+        x_t = th.empty_like(x0)
+        with th.cuda.device(x0.device):
+            _lib.check(_lib.load().s3d_train_q_sample(_lib.ptr(x0), _lib.ptr(eps), _lib.ptr(tab[0]), _lib.ptr(tab[1]),
+                                                      _lib.ptr(t64), x0.shape[0], x0[0].numel(), _lib.ptr(x_t),
+                                                      _lib.stream_ptr()))
+        return x_t
+
+    def _training_target(self, x_start, x_t, t, noise):
+        if self.model_mean_type == ModelMeanType.START_X:
+            return x_start
+        if self.model_mean_type == ModelMeanType.EPSILON:
+            return noise
+        raise NotImplementedError(self.model_mean_type)
+
     def training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
-        raise NotImplementedError("training (backward kernels) is the next tier: SURVEY.md §8f rank 1")
+        """Per-sample training losses for one timestep batch (:771-856, MSE branch with fixed variances): returns
+        {"mse_xy", "mse_xz", "mse_yz", "loss"} each of shape [N]; `loss` is differentiable with respect to the
+        model's parameters — `(terms["loss"] * weights).mean().backward()` fills their `.grad` through the HIP
+        backward pass."""
+        if self.loss_type not in (LossType.MSE, LossType.RESCALED_MSE):
+            raise NotImplementedError(self.loss_type)                   # the reference raises for KL too (:795)
+        if self.model_var_type not in (ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
+            raise NotImplementedError("learned variances are not runnable with the Sin3DM UNet (see _model_variance_tables)")
+        if model_kwargs is None:
+            model_kwargs = {}
+        if noise is None:
+            noise = th.randn_like(x_start)
+        x_t = self.q_sample_hip(x_start, t, noise)
+        model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
+        target = self._training_target(x_start, x_t, t, noise).contiguous().float()
+        assert model_output.shape == target.shape == x_start.shape
+        H, W, D = model_kwargs["H"], model_kwargs["W"], model_kwargs["D"]
+        mse = _TriplaneMSE.apply(model_output, target, int(H), int(W), int(D))       # [N, 3]
+        terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2]}
+        terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]
+        return terms
+
+    def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None):
+        """Fast path of TrainLoop.forward_backward (train_util.py:205-236) without an autograd graph:
+        loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`)."""
+        if noise is None:
+            noise = th.randn_like(x_start)
+        H, W, D = (int(model_kwargs[k]) for k in "HWD")
+        x_t = self.q_sample_hip(x_start, t, noise)
+        out = model.forward_train(x_t, self._scale_timesteps(t), H, W, D)
+        target = self._training_target(x_start, x_t, t, noise).contiguous().float()
+        mse = _mse_terms(out, target, H, W, D)
+        wgt = (weights.to(out.device, th.float32) / out.shape[0])[:, None].expand(-1, 3).contiguous()
+        g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out)
+        terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2], "loss": mse.sum(1)}
+        return terms, g
+
+
+def _mse_terms(out, target, H, W, D):
+    B, Cc = out.shape[:2]
+    terms = th.empty((B, 3), device=out.device, dtype=th.float32)
+    ws = th.empty(96 * B, device=out.device, dtype=th.float32)
+    with th.cuda.device(out.device):
+        _lib.check(_lib.load().s3d_train_mse_terms(_lib.ptr(out), _lib.ptr(target), B, Cc, H, W, D, _lib.ptr(ws),
+                                                   _lib.ptr(terms), _lib.stream_ptr()))
+    return terms
+
+
+def _mse_grad(out, target, wgt, H, W, D):
+    B, Cc = out.shape[:2]
+    d_out = th.empty_like(out)
+    with th.cuda.device(out.device):
+        _lib.check(_lib.load().s3d_train_mse_grad(_lib.ptr(out), _lib.ptr(target), _lib.ptr(wgt), B, Cc, H, W, D,
+                                                  _lib.ptr(d_out), _lib.stream_ptr()))
+    return d_out
+
+
+class _TriplaneMSE(th.autograd.Function):
+    """[N,3] per-plane mean squared errors of two composed maps (mean_flat over each decomposed plane, :838-845)."""
+
+    @staticmethod
+    def forward(ctx, out, target, H, W, D):
+        out = out.contiguous().float()
+        ctx.save_for_backward(out, target)
+        ctx.hwd = (H, W, D)
+        return _mse_terms(out, target, H, W, D)
+
+    @staticmethod
+    def backward(ctx, g):
+        out, target = ctx.saved_tensors
+        return _mse_grad(out, target, g.contiguous().float(), *ctx.hwd), None, None, None, None
 
 
 def _extract_into_tensor(arr, timesteps, broadcast_shape):

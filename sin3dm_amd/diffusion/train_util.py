@@ -1,0 +1,219 @@
+"""Diffusion training loop on the MI355X (reference: src/diffusion/train_util.py, fp32 path).
+
+Same constructor, step order and checkpoint files as the reference's TrainLoop —
+    run_step = forward_backward -> optimizer step -> EMA update -> linear lr anneal          (:163-172)
+    save     = ema_<rate>_<step:06d>.pt (state_dict by name) + opt<step:06d>.pt                (:258-279)
+— but built for one process per GPU: the model's parameters are views of one flat device vector
+(TriplaneUNetModelSmall.flat_parameters), so that
+  * forward + loss + backward run without an autograd graph (GaussianDiffusion.training_losses_and_grads),
+  * data-parallel training is ONE RCCL all-reduce of the flat gradient vector per step (28 MB at 64 channels),
+  * AdamW + all EMA copies are ONE kernel over the flat vectors (FlatAdamW -> s3d_train_adamw_ema).
+The reference is single-process (its DDP is commented out, :8-9, :98-99); with world_size 1 the arithmetic is the
+reference's.  tensorboard / matplotlib logging is out of scope: scalars go to stdout and progress.jsonl.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+from .. import _lib
+from .resample import LossAwareSampler, UniformSampler
+
+
+class FlatAdamW:
+    """torch.optim.AdamW (betas 0.9/0.999, eps 1e-8, decoupled weight decay) + update_ema (src/diffusion/nn.py:55-65)
+    on the model's flat parameter vector; `ema` holds one flat copy per rate, initialised to the parameters (:92-95)."""
+
+    def __init__(self, model, lr, weight_decay=0.0, ema_rates=(), betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        flat = model.flat_parameters
+        self.exp_avg = th.zeros_like(flat)
+        self.exp_avg_sq = th.zeros_like(flat)
+        self.ema_rates = [float(r) for r in ema_rates]
+        self.ema = [flat.detach().clone() for _ in self.ema_rates]
+        self.steps = 0
+
+    def step(self, flat_grad):
+        flat = self.model.flat_parameters
+        assert flat_grad.shape == flat.shape and flat_grad.is_cuda
+        self.steps += 1
+        n = len(self.ema)
+        ema_ptrs = (C.c_void_p * max(n, 1))(*[C.c_void_p(e.data_ptr()) for e in self.ema])
+        rates = (C.c_float * max(n, 1))(*self.ema_rates)
+        with th.cuda.device(flat.device):
+            _lib.check(_lib.load().s3d_train_adamw_ema(
+                _lib.ptr(flat), _lib.ptr(flat_grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), ema_ptrs, rates, n,
+                flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.steps,
+                _lib.stream_ptr()))
+        self.model.mark_parameters_changed()
+
+    # torch.optim.AdamW-compatible state (parameter order = model.parameters()), so opt*.pt files interchange
+    def state_dict(self):
+        names = [n for n, _ in self.model.named_parameters()]
+        m, v = self.model.split_flat(self.exp_avg), self.model.split_flat(self.exp_avg_sq)
+        state = {i: {"step": th.tensor(float(self.steps)), "exp_avg": m[n].clone(), "exp_avg_sq": v[n].clone()}
+                 for i, n in enumerate(names)} if self.steps else {}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        names = [n for n, _ in self.model.named_parameters()]
+        m, v = self.model.split_flat(self.exp_avg), self.model.split_flat(self.exp_avg_sq)
+        for i, n in enumerate(names):
+            st = sd["state"].get(i)
+            if st is None:
+                continue
+            m[n].copy_(st["exp_avg"]); v[n].copy_(st["exp_avg_sq"])
+            self.steps = int(float(st["step"]))
+        g = sd["param_groups"][0]
+        self.lr, self.weight_decay, self.eps, self.betas = float(g["lr"]), float(g["weight_decay"]), float(g["eps"]), tuple(g["betas"])
+
+
+class TrainLoop:
+    def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
+                 resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
+                 lr_anneal_steps=0, log_dir=None):
+        if use_fp16:
+            raise NotImplementedError("use_fp16 is not runnable in the reference (see TriplaneUNetModelSmall) and not implemented")
+        self.model, self.diffusion, self.data = model, diffusion, data
+        self.batch_size = batch_size
+        self.microbatch = microbatch if microbatch > 0 else batch_size
+        assert self.microbatch == self.batch_size, "the reference eliminated the microbatch feature (:211-212)"
+        self.lr = lr
+        self.ema_rate = [ema_rate] if isinstance(ema_rate, float) else [float(x) for x in str(ema_rate).split(",")]
+        self.log_interval, self.save_interval = log_interval, save_interval
+        self.resume_checkpoint = resume_checkpoint
+        self.schedule_sampler = schedule_sampler or UniformSampler(diffusion)
+        self.weight_decay, self.lr_anneal_steps = weight_decay, lr_anneal_steps
+        self.log_dir = log_dir
+        self.step = 0
+        self.resume_step = 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.global_batch = self.batch_size * self.world
+        self._kvs = {}
+        self._t_last = None
+
+        if resume_checkpoint:
+            self.resume_step = parse_resume_step_from_filename(resume_checkpoint)
+            self.model.load_state_dict(th.load(resume_checkpoint, map_location="cpu"))
+        if self.world > 1:                           # identical start on every rank (the role of sync_params)
+            dist.broadcast(self.model.flat_parameters, src=0)
+            self.model.mark_parameters_changed()
+        self.opt = FlatAdamW(model, lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
+        if self.resume_step:
+            self._load_optimizer_and_ema()
+        self._grad = th.empty_like(self.model.flat_parameters)
+
+    # ------------------------------------------------------------------ resume
+    def _load_optimizer_and_ema(self):
+        base = os.path.dirname(self.resume_checkpoint)
+        opt_path = os.path.join(base, f"opt{self.resume_step:06}.pt")
+        if os.path.exists(opt_path):
+            self.opt.load_state_dict(th.load(opt_path, map_location=self.model.flat_parameters.device))
+        for k, rate in enumerate(self.ema_rate):
+            path = os.path.join(base, f"ema_{rate}_{self.resume_step:06d}.pt")
+            if os.path.exists(path):
+                sd = th.load(path, map_location="cpu")
+                for name, view in self.model.split_flat(self.opt.ema[k]).items():
+                    view.copy_(sd[name])
+
+    # ------------------------------------------------------------------ loop
+    def run_loop(self):
+        while not self.lr_anneal_steps or self.step + self.resume_step < self.lr_anneal_steps:
+            batch, cond = next(self.data)
+            self.run_step(batch, cond)
+            if self.step % self.log_interval == 0:
+                self.dumpkvs()
+            if self.step % self.save_interval == 0 and self.step > 0:
+                self.save()
+                if os.environ.get("DIFFUSION_TRAINING_TEST", "") and self.step > 0:
+                    return
+            self.step += 1
+        if (self.step - 1) % self.save_interval != 0:
+            self.save()
+
+    def run_step(self, batch, cond):
+        self.forward_backward(batch, cond)
+        self.opt.step(self._grad)
+        self._anneal_lr()
+        self.log_step()
+
+    def forward_backward(self, batch, cond):
+        dev = self.model.flat_parameters.device
+        micro = batch.to(dev)
+        t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+        losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
+        if self.world > 1:                            # loss = mean over the GLOBAL batch: average the rank gradients
+            dist.all_reduce(grad)
+            grad.mul_(1.0 / self.world)
+        if isinstance(self.schedule_sampler, LossAwareSampler):
+            self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
+        if self.step % 10 == 0:
+            self.log_loss_dict(t, {k: v * weights for k, v in losses.items()})
+
+    def _anneal_lr(self):
+        if not self.lr_anneal_steps:
+            return
+        frac_done = (self.step + self.resume_step) / self.lr_anneal_steps
+        self.opt.lr = self.lr * (1 - frac_done)
+
+    # ------------------------------------------------------------------ logging (stdout + progress.jsonl)
+    def logkv(self, k, v):
+        self._kvs[k] = v
+
+    def log_step(self):
+        self.logkv("step", self.step + self.resume_step)
+        self.logkv("samples", (self.step + self.resume_step + 1) * self.global_batch)
+        self.logkv("lr", self.opt.lr)
+
+    def log_loss_dict(self, ts, losses):
+        for key, values in losses.items():
+            vals = values.detach().float().cpu().numpy()
+            self.logkv(key, float(vals.mean()))
+            for sub_t, sub_loss in zip(ts.cpu().numpy(), vals):
+                quartile = int(4 * sub_t / self.diffusion.num_timesteps)
+                self.logkv(f"{key}_q{quartile}", float(sub_loss))
+
+    def dumpkvs(self):
+        now = time.time()
+        if self._t_last is not None:
+            self.logkv("sec_per_step", (now - self._t_last) / max(self.log_interval, 1))
+        self._t_last = now
+        if self.rank == 0:
+            print(" | ".join(f"{k} {v:.6g}" if isinstance(v, float) else f"{k} {v}" for k, v in sorted(self._kvs.items())), flush=True)
+            if self.log_dir:
+                with open(os.path.join(self.log_dir, "progress.jsonl"), "a") as f:
+                    f.write(json.dumps(self._kvs) + "\n")
+        self._kvs = {}
+
+    # ------------------------------------------------------------------ checkpoints
+    def save(self):
+        if self.rank != 0 or not self.log_dir:
+            return
+        step = self.step + self.resume_step
+        for rate, flat in zip(self.ema_rate, self.opt.ema):
+            sd = {k: v.detach().cpu().clone() for k, v in self.model.split_flat(flat).items()}
+            sd = {k: sd[k] for k in self.model.state_dict().keys()}          # the module's key order
+            th.save(sd, os.path.join(self.log_dir, f"ema_{rate}_{step:06d}.pt"))
+        th.save(self.opt.state_dict(), os.path.join(self.log_dir, f"opt{step:06d}.pt"))
+
+
+def parse_resume_step_from_filename(filename):
+    """path/to/modelNNNNNN.pt -> NNNNNN (0 when the name has no step)."""
+    split = filename.split("model")
+    if len(split) < 2:
+        return 0
+    try:
+        return int(split[-1].split(".")[0])
+    except ValueError:
+        return 0

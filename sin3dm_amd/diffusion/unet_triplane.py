@@ -3,8 +3,13 @@ and forward signature (src/diffusion/unet_triplane.py:315-510, 513-702) — exec
 
 The module owns ordinary nn.Parameters under the reference's state_dict names, so `load_state_dict`,
 `.to(dev)`, `.eval()`, `.parameters()` and checkpoints written by the reference all work.  Their values are
-mirrored into the HIP handle (repacked to the kernels' layouts) whenever they change.  Inference only:
-the forward is not differentiable (sampling runs under no_grad in the reference, gaussian_diffusion.py:525).
+mirrored into the HIP handle (repacked to the kernels' layouts) whenever they change.
+
+Under no_grad (sampling, gaussian_diffusion.py:525) the forward is the inference kernel sequence.  With grad enabled
+and trainable parameters it is an autograd node whose backward is the HIP backward pass (training tier): the
+parameters are then re-homed as views of ONE flat device vector (state-dict order of the C ABI, PyTorch layouts) so
+that the optimizer / EMA / all-reduce can work on a single buffer; `.grad` of every parameter is filled as
+`loss.backward()` would.  The gradient with respect to the input x is not computed (training never needs it).
 """
 from __future__ import annotations
 
@@ -62,6 +67,10 @@ class _TriplaneUNetBase(nn.Module):
 
         self._handle = None
         self._synced = None
+        self._flat = None           # training: flat master parameters on the device (see _ensure_flat)
+        self._flat_layout = None    # [(name, offset, numel, shape)]
+        self._flat_dirty = False
+        self.last_flat_grad = None  # flat gradient vector of the most recent backward
 
     @staticmethod
     def _init_tensor(name, shape, gen):
@@ -98,6 +107,15 @@ class _TriplaneUNetBase(nn.Module):
             self._handle = h
         params = dict(self.named_parameters())
         stamp = tuple((p.data_ptr(), p._version) for p in params.values())
+        if self._flat is not None:
+            if self._flat_intact(params):
+                if stamp != self._synced or self._flat_dirty:      # parameters changed on the device: repack there
+                    with th.cuda.device(self._flat.device):
+                        _lib.check(lib.s3d_unet_repack(self._handle, _lib.stream_ptr()))
+                    self._synced, self._flat_dirty = stamp, False
+                return lib
+            self._flat = None                                       # .to(...) re-homed the parameters: start over
+            self._synced = None
         if stamp != self._synced:
             for name in self._param_names:
                 host = params[name].detach().to("cpu", th.float32).contiguous()
@@ -106,6 +124,85 @@ class _TriplaneUNetBase(nn.Module):
                                                   host.dim()))
             self._synced = stamp
         return lib
+
+    # ------------------------------------------------------------------ training tier: flat parameters
+    def _flat_intact(self, params):
+        base = self._flat.data_ptr()
+        return all(params[n].data_ptr() == base + 4 * off and params[n].device == self._flat.device
+                   for n, off, _, _ in self._flat_layout)
+
+    def _ensure_flat(self):
+        """Re-home every parameter as a view of one flat fp32 device vector and attach it to the handle."""
+        lib = self._ensure_handle()
+        if self._flat is not None:
+            return lib
+        params = dict(self.named_parameters())
+        dev = next(iter(params.values())).device
+        _lib.require_gpu(next(iter(params.values())))
+        n = lib.s3d_unet_num_params(self._handle)
+        layout = []
+        for i in range(n):
+            name, shape, nd, off = C.c_char_p(), (C.c_int64 * 4)(), C.c_int(), C.c_int64()
+            _lib.check(lib.s3d_unet_param_info(self._handle, i, C.byref(name), shape, C.byref(nd)))
+            _lib.check(lib.s3d_unet_param_offset(self._handle, i, C.byref(off)))
+            shp = tuple(shape[k] for k in range(nd.value))
+            numel = 1
+            for d in shp:
+                numel *= d
+            layout.append((name.value.decode(), off.value, numel, shp))
+        total = lib.s3d_unet_param_numel(self._handle)
+        flat = th.empty(total, device=dev, dtype=th.float32)
+        with th.no_grad():
+            for name, off, numel, shp in layout:
+                p = params[name]
+                assert tuple(p.shape) == shp, (name, tuple(p.shape), shp)
+                view = flat[off:off + numel].view(shp)
+                view.copy_(p.detach().to(dev, th.float32))
+                p.data = view
+        with th.cuda.device(dev):
+            _lib.check(lib.s3d_unet_train_attach(self._handle, _lib.ptr(flat), total))
+            _lib.check(lib.s3d_unet_repack(self._handle, _lib.stream_ptr()))
+        self._flat, self._flat_layout = flat, layout
+        self._synced = tuple((p.data_ptr(), p._version) for p in dict(self.named_parameters()).values())
+        self._flat_dirty = False
+        return lib
+
+    @property
+    def flat_parameters(self):
+        """The flat master vector (allocating / attaching it on first use)."""
+        self._ensure_flat()
+        return self._flat
+
+    def mark_parameters_changed(self):
+        """Call after writing to `flat_parameters` directly (a fused optimizer step): forces a device repack."""
+        self._flat_dirty = True
+
+    def forward_train(self, x, timesteps, H, W, D):
+        """Forward pass that keeps the activations for one `backward_flat` (no autograd graph)."""
+        lib = self._ensure_flat()
+        self._ensure_handle()                      # repack if the parameters changed
+        h, t, out = self._prep(x, timesteps, H, W, D)
+        with th.cuda.device(h.device):
+            _lib.check(lib.s3d_unet_forward_train(self._handle, _lib.ptr(h), _lib.ptr(t), h.shape[0], int(H), int(W), int(D),
+                                                  _lib.ptr(out), _lib.stream_ptr()))
+        self._train_inputs = (h, t)                # keep the tensors the tape points at alive until the backward
+        return out
+
+    def backward_flat(self, d_out, out=None):
+        """Backward of the last forward_train: returns the flat gradient vector (layout of flat_parameters)."""
+        lib = _lib.load()
+        d_out = d_out.contiguous().float()
+        g = out if out is not None else th.empty_like(self._flat)
+        with th.cuda.device(d_out.device):
+            _lib.check(lib.s3d_unet_backward(self._handle, _lib.ptr(d_out), _lib.ptr(g), _lib.stream_ptr()))
+        self._train_inputs = None
+        self.last_flat_grad = g
+        return g
+
+    def split_flat(self, flat):
+        """{name: view} of a vector laid out like flat_parameters."""
+        self._ensure_flat()
+        return {name: flat[off:off + numel].view(shp) for name, off, numel, shp in self._flat_layout}
 
     def __del__(self):
         h = self.__dict__.pop("_handle", None)      # not via nn.Module.__setattr__: it may run at interpreter exit
@@ -139,20 +236,48 @@ class _TriplaneUNetBase(nn.Module):
         (reference: unet_triplane.py:465-510)."""
         assert H is not None and W is not None and D is not None
         _lib.require_gpu(x)
-        h = x if y is None else th.cat([x, y], dim=1)
-        h = h.contiguous().float()
-        B, Cin, Hc, Wc = h.shape
-        assert Cin == self.in_channels, f"expected {self.in_channels} input channels, got {Cin}"
-        assert Hc == H + D and Wc == W + D, f"composed map {tuple(h.shape[-2:])} != (H+D, W+D) = {(H + D, W + D)}"
-        assert timesteps.shape == (B,)
+        if y is not None:
+            x = th.cat([x, y], dim=1)
+        if th.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self._ensure_flat()
+            names = [n for n, _, _, _ in self._flat_layout]
+            params = dict(self.named_parameters())
+            return _UNetFn.apply(self, x, timesteps, int(H), int(W), int(D), *[params[n] for n in names])
+        h, t, out = self._prep(x, timesteps, H, W, D)
+        B = h.shape[0]
         lib = self._ensure_handle()
-        t = timesteps.to(device=h.device, dtype=th.float32).contiguous()
-        out = th.empty((B, self.out_channels, Hc, Wc), device=h.device, dtype=th.float32)
         with th.cuda.device(h.device):
             _lib.check(lib.s3d_unet_forward(self._handle, _lib.ptr(h), _lib.ptr(t), B, int(H), int(W), int(D),
                                             _lib.ptr(out), _lib.stream_ptr()))
         assert out.shape == x.shape or y is not None
         return out
+
+    def _prep(self, x, timesteps, H, W, D):
+        h = x.contiguous().float()
+        B, Cin, Hc, Wc = h.shape
+        assert Cin == self.in_channels, f"expected {self.in_channels} input channels, got {Cin}"
+        assert Hc == H + D and Wc == W + D, f"composed map {tuple(h.shape[-2:])} != (H+D, W+D) = {(H + D, W + D)}"
+        assert timesteps.shape == (B,)
+        t = timesteps.to(device=h.device, dtype=th.float32).contiguous()
+        out = th.empty((B, self.out_channels, Hc, Wc), device=h.device, dtype=th.float32)
+        return h, t, out
+
+
+class _UNetFn(th.autograd.Function):
+    """model(x, t) as an autograd node: backward = the HIP backward pass.  Each backward writes a fresh flat gradient
+    vector and hands autograd views of it, so accumulation into existing .grad tensors keeps its usual meaning."""
+
+    @staticmethod
+    def forward(ctx, model, x, t, H, W, D, *params):
+        ctx.model = model
+        return model.forward_train(x.detach(), t, H, W, D)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        model = ctx.model
+        g = model.backward_flat(d_out)
+        views = tuple(g[off:off + numel].view(shp) for _, off, numel, shp in model._flat_layout)
+        return (None, None, None, None, None, None) + views
 
 
 class TriplaneUNetModelSmall(_TriplaneUNetBase):

@@ -1,0 +1,172 @@
+"""Training tier on the MI355X: loss terms, every parameter gradient and three optimizer steps
+against digests captured from the reference's autograd / torch.optim.AdamW (tests/golden/train_*.npz)."""
+import numpy as np
+import pytest
+
+from conftest import golden, relerr, digest_errors, zero_grad_params
+from sin3dm_amd import testing as T
+
+pytestmark = pytest.mark.gpu
+
+TRAIN_CASES = [("mc32_a", 32, False, True, (1, 2), 2), ("mc32_odd", 32, False, True, (1, 2), 2),
+               ("mc32_raw", 32, True, True, (1, 2), 2), ("mc32_add", 32, False, False, (1, 2), 1),
+               ("mc32_3lev", 32, False, True, (1, 2, 2), 1)]
+
+
+def _model(mc, raw=False, ssn=True, cm=(1, 2), seed=0):
+    import torch
+    from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall, TriplaneUNetModelSmallRaw
+    cls = TriplaneUNetModelSmallRaw if raw else TriplaneUNetModelSmall
+    m = cls(12, mc, 12, channel_mult=cm, use_scale_shift_norm=ssn)
+    m.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc, rollout=not raw,
+                                                                 use_scale_shift_norm=ssn, channel_mult=cm), seed))
+    return m.to(torch.device("cuda:0"))
+
+
+def _diffusion():
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    return create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True)
+
+
+def _inputs(g, tag, B, noise_seed=401):
+    import torch
+    H, W, D = (int(v) for v in g[f"{tag}.hwd"])
+    dev = torch.device("cuda:0")
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1).to(dev)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), noise_seed)).to(dev)
+    return H, W, D, x0, noise
+
+
+def _offenders(named, g, prefix, k=6):
+    """The tensors with the largest norm / projection error, for the assertion message."""
+    names = [str(n) for n in g[f"{prefix}/names"]]
+    gn, gp = g[f"{prefix}/norm"], g[f"{prefix}/proj"]
+    rows = []
+    for i, n in enumerate(names):
+        a = np.asarray(named[n], dtype=np.float64).reshape(-1)
+        r = T.synthetic_tensor("digest/" + n, (a.size,), 7).astype(np.float64)
+        ref = max(float(gn[i]), 1e-2 * float(gn.max()))
+        rows.append((max(abs(np.linalg.norm(a) - gn[i]), abs(a @ r - gp[i])) / ref, n, float(np.linalg.norm(a)), float(gn[i])))
+    return sorted(rows, reverse=True)[:k]
+
+
+def test_device_repack_reproduces_host_packing():
+    """Attaching the flat parameter vector rebuilds the whole kernel-layout image on the device; the inference
+    forward must not change by a single bit."""
+    import torch
+    g = golden("unet_fwd")
+    for tag, mc, cm in (("mc32_a", 32, (1, 2)), ("mc64_b", 64, (1, 2)), ("mc32_3lev", 32, (1, 2, 2))):
+        m = _model(mc, cm=cm)
+        H, W, D = (int(v) for v in g[f"{tag}.hwd"])
+        x = torch.from_numpy(g[f"{tag}.x"]).cuda()
+        t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+        with torch.no_grad():
+            y0 = m(x, t, H=H, W=W, D=D).clone()
+            _ = m.flat_parameters                 # attach + device repack
+            y1 = m(x, t, H=H, W=W, D=D)
+        assert torch.equal(y0, y1), tag
+        assert relerr(y1.cpu().numpy(), g[f"{tag}.y"]) < 5e-6
+
+
+@pytest.mark.parametrize("tag,mc,raw,ssn,cm,B", TRAIN_CASES)
+def test_training_losses_and_grads(tag, mc, raw, ssn, cm, B):
+    import torch
+    g = golden("train_grads")
+    m = _model(mc, raw, ssn, cm)
+    diffusion = _diffusion()
+    H, W, D, x0, noise = _inputs(g, tag, B)
+    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    assert relerr(diffusion.q_sample_hip(x0, t, noise).cpu().numpy(), g[f"{tag}.x_t"]) < 1e-6
+    terms = diffusion.training_losses(m, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+    for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+        assert terms[k].shape == (B,)
+        assert relerr(terms[k].detach().cpu().numpy(), g[f"{tag}.{k}"]) < 2e-5, k
+    (terms["loss"] * torch.ones(B, device="cuda")).mean().backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+    assert all(np.isfinite(v).all() for v in grads.values())
+    w = digest_errors(grads, g, f"{tag}.grad")
+    assert w["norm"] < 2e-4 and w["proj"] < 2e-4 and w["head"] < 2e-3 and w["full"] < 2e-4, (w, _offenders(grads, g, f"{tag}.grad"))
+
+
+def test_fast_path_equals_autograd_and_is_repeatable():
+    """training_losses_and_grads (no autograd graph) gives the same flat gradient as loss.backward(), bit for bit,
+    and twice the same bits (all reductions have a fixed order)."""
+    import torch
+    g = golden("train_grads")
+    tag, mc, B = "mc32_a", 32, 2
+    m = _model(mc)
+    diffusion = _diffusion()
+    H, W, D, x0, noise = _inputs(g, tag, B)
+    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    w = torch.tensor([1.0, 0.5], device="cuda")
+    kw = dict(H=H, W=W, D=D)
+    terms, g1 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+    g1 = g1.clone()
+    _, g2 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+    assert torch.equal(g1, g2)
+    t2 = diffusion.training_losses(m, x0, t, model_kwargs=kw, noise=noise)
+    (t2["loss"] * w).mean().backward()
+    assert torch.equal(terms["loss"], t2["loss"].detach())
+    for name, view in m.split_flat(g1).items():
+        assert torch.equal(view, dict(m.named_parameters())[name].grad), name
+    # gradient accumulation keeps its meaning: a second backward adds
+    t3 = diffusion.training_losses(m, x0, t, model_kwargs=kw, noise=noise)
+    (t3["loss"] * w).mean().backward()
+    p = dict(m.named_parameters())["input_blocks.0.0.in_layers.2.conv_xy.weight"]
+    assert torch.allclose(p.grad, 2 * m.split_flat(g1)["input_blocks.0.0.in_layers.2.conv_xy.weight"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("wd_tag", ["wd0", "wd01"])
+def test_optimizer_steps(wd_tag):
+    """Three TrainLoop.run_step iterations (AdamW -> EMA -> linear anneal) with the fused flat optimizer."""
+    import torch
+    from sin3dm_amd.diffusion.train_util import FlatAdamW
+    g = golden("train_steps")
+    lr0, ema_rate, wd, anneal = (float(v) for v in g[f"{wd_tag}.hyper"])
+    mc, B, (H, W, D) = 32, 2, (10, 14, 6)
+    m = _model(mc)
+    diffusion = _diffusion()
+    init = {k: v.detach().clone() for k, v in m.named_parameters()}
+    opt = FlatAdamW(m, lr=lr0, weight_decay=wd, ema_rates=[ema_rate])
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1).cuda()
+    for step in range(3):
+        noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 500 + step)).cuda()
+        t = torch.tensor([[700, 3], [12, 999], [450, 451]][step], device="cuda")
+        terms, grads = diffusion.training_losses_and_grads(m, x0, t, torch.ones(B, device="cuda"), dict(H=H, W=W, D=D), noise=noise)
+        assert relerr(terms["loss"].cpu().numpy(), g[f"{wd_tag}.losses"][step]) < 2e-4, step
+        opt.step(grads)
+        opt.lr = lr0 * (1 - step / anneal)
+    skip = zero_grad_params()
+    dparam = {k: (p.detach() - init[k]).cpu().numpy() for k, p in m.named_parameters()}
+    dema = {k: (v - init[k]).cpu().numpy() for k, v in m.split_flat(opt.ema[0]).items()}
+    wp = digest_errors(dparam, g, f"{wd_tag}.dparam", skip)
+    we = digest_errors(dema, g, f"{wd_tag}.dema", skip)
+    # Adam's update is ~ lr * g/|g| per element: where a gradient element is within round-off of zero, 1e-4-level
+    # gradient differences (fp32, different summation order) flip a full +-lr step.  Those few elements bound the L2
+    # agreement of the parameter deltas at the percent level; the norms agree to 1e-3.
+    assert wp["norm"] < 5e-3 and wp["proj"] < 3e-2 and wp["full_l2"] < 3e-2, wp
+    assert we["norm"] < 5e-3 and we["proj"] < 3e-2, we
+
+
+def test_torch_optimizer_also_works():
+    """Drop-in use: a stock torch.optim.AdamW on model.parameters() (views of the flat vector) trains the HIP model."""
+    import torch
+    g = golden("train_grads")
+    tag, B = "mc32_a", 2
+    m = _model(32)
+    diffusion = _diffusion()
+    H, W, D, x0, noise = _inputs(g, tag, B)
+    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        terms = diffusion.training_losses(m, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+        loss = terms["loss"].mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < 0.8 * losses[0], losses          # same batch every step: the loss must fall
+    with torch.no_grad():                                 # and sampling sees the updated weights
+        y = m(x0, t, H=H, W=W, D=D)
+    assert torch.isfinite(y).all()
