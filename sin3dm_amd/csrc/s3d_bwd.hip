@@ -67,27 +67,40 @@ int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3]
 // dbias[p][co] = sum_b sum_r R[p][b][r][1][co]; optionally the per-sample sums over all planes (the gradient of
 // emb_out when it is added to h, use_scale_shift_norm=False, src/diffusion/unet_triplane.py:298-303).
 struct BiasArgs { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
-__global__ void k_bias_grad(BiasArgs a) {
-    const int co = blockIdx.x * blockDim.x + threadIdx.x;
-    if (co >= a.C) return;
+__global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
+    __shared__ float sm[16][64];
+    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6, co = blockIdx.x * 64 + cl;
+    float tot_p[3] = {0.f, 0.f, 0.f};
     for (int b = 0; b < a.B; ++b) {
         float tot = 0.f;
         for (int p = 0; p < 3; ++p) {
             float s = 0.f;
-            const float* R = a.R[p] + size_t(b) * a.h[p] * 3 * a.C + a.C + co;
-            for (int r = 0; r < a.h[p]; ++r) s += R[size_t(r) * 3 * a.C];
-            tot += s;
-            if (a.dbias[p]) { if (b == 0) a.dbias[p][co] = s; else a.dbias[p][co] += s; }
+            if (co < a.C) {
+                const float* R = a.R[p] + size_t(b) * a.h[p] * 3 * a.C + a.C + co;
+                for (int r = lane; r < a.h[p]; r += 16) s += R[size_t(r) * 3 * a.C];
+            }
+            __syncthreads();
+            sm[lane][cl] = s;
+            __syncthreads();
+            if (lane == 0) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += sm[k][cl];
+                tot += t; tot_p[p] += t;
+            }
         }
-        if (a.per_sample) a.per_sample[size_t(b) * a.per_sample_stride + co] = tot;
+        if (lane == 0 && co < a.C && a.per_sample) a.per_sample[size_t(b) * a.per_sample_stride + co] = tot;
     }
+    if (lane == 0 && co < a.C)
+        for (int p = 0; p < 3; ++p)
+            if (a.dbias[p]) a.dbias[p][co] = tot_p[p];
 }
 int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
                      int per_sample_stride, hipStream_t st) {
     BiasArgs a;
     for (int p = 0; p < 3; ++p) { a.R[p] = R[p]; a.dbias[p] = dbias ? dbias[p] : nullptr; a.h[p] = g.h[p]; }
     a.per_sample = per_sample; a.per_sample_stride = per_sample_stride; a.B = B; a.C = C;
-    hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 64)), dim3(1024), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -95,42 +108,60 @@ int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const
 // ------------------------------------------------------------------ weight gradient of the two mean-channel slots
 // row-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_r' v[b][r'][ci] * R[b][r'-dr+1][dc][co]
 // col-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_c' v[b][c'][ci] * Cs[b][c'-dc+1][dr][co]
+// One block = one 32(co) x 32(ci) tile of one slot with all nine taps as nine MFMA accumulators; the contraction
+// over (b, position) is split across the block's four waves and their partials are added through LDS in wave order.
 struct SlotJob { const float* v; const float* S; float* dW; int L, slot, col_varying; };
-struct SlotArgs { SlotJob job[6]; int B, C, cout, ctot; };
+struct SlotArgs { SlotJob job[6]; int B, C, cout, ctot, n_ci; };
 __global__ __launch_bounds__(256) void k_slot_wgrad(SlotArgs a) {
+    __shared__ float red[4][16][64];
     const SlotJob J = a.job[blockIdx.y];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.C * a.cout) return;
-    const int ci = idx % a.C, co = idx / a.C;
-    float acc[3][3];
+    const int tci = blockIdx.x % a.n_ci, tco = blockIdx.x / a.n_ci;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
+    const int co = tco * 32 + i, ci = tci * 32 + i, L = J.L;
+    f32x16 acc[3][3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[t][j] = 0.f;
-    for (int b = 0; b < a.B; ++b)
-        for (int pos = 0; pos < J.L; ++pos) {
-            const float v = J.v[(size_t(b) * J.L + pos) * a.C + ci];
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {                 // tap along the vector's own axis
-                const int q = pos - t + 1;
-                if (q < 0 || q >= J.L) continue;
-                const float* S = J.S + (size_t(b) * J.L + q) * 3 * a.cout + co;
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+    const int pairs = (L + 1) / 2, total = a.B * pairs;
+    for (int it = wid; it < total; it += 4) {
+        const int b = it / pairs, pos = (it % pairs) * 2 + kk;
+        const float bv = pos < L ? J.v[(size_t(b) * L + pos) * a.C + ci] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[t][j] = fmaf(v, S[j * a.cout], acc[t][j]);
+        for (int t = 0; t < 3; ++t) {
+            const int q = pos - t + 1;
+            const bool ok = pos < L && q >= 0 && q < L;
+            const float* S = J.S + (size_t(b) * L + (ok ? q : 0)) * 3 * a.cout + co;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float av = ok ? S[j * a.cout] : 0.f;
+                acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][j], 0, 0, 0);
             }
         }
-    float* d = J.dW + (size_t(co) * a.ctot + J.slot * a.C + ci) * 9;
+    }
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[t][j][r];
+            __syncthreads();
             const int dr = J.col_varying ? j : t, dc = J.col_varying ? t : j;
-            d[dr * 3 + dc] = acc[t][j];
+            for (int e = threadIdx.x; e < 1024; e += 256) {
+                const int r = e >> 6, l = e & 63;
+                const float v = red[0][r][l] + red[1][r][l] + red[2][r][l] + red[3][r][l];
+                const int oc = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ic = tci * 32 + (l & 31);
+                J.dW[(size_t(oc) * a.ctot + J.slot * a.C + ic) * 9 + dr * 3 + dc] = v;
+            }
         }
 }
 int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
+    S3D_CHECK(s.C % 32 == 0 && s.cout % 32 == 0, S3D_ERR_INVALID, "slot_wgrad: channels must be multiples of 32");
     SlotArgs a;
-    a.B = s.B; a.C = s.C; a.cout = s.cout; a.ctot = 3 * s.C;
+    a.B = s.B; a.C = s.C; a.cout = s.cout; a.ctot = 3 * s.C; a.n_ci = s.C / 32;
     for (int p = 0; p < 3; ++p) {
         const bool a_is_col = (p == 0);
         // row-varying vector (length h) and column-varying vector (length w) of this plane's conv
@@ -139,7 +170,7 @@ int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
         SlotJob& jc = a.job[2 * p + 1];
         jc.v = s.colvec[p]; jc.S = s.Cs[p]; jc.dW = s.dW[p]; jc.L = s.g.w[p]; jc.slot = a_is_col ? 1 : 2; jc.col_varying = 1;
     }
-    hipLaunchKernelGGL(k_slot_wgrad, dim3(cdiv(s.C * s.cout, 256), 6), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_slot_wgrad, dim3((s.cout / 32) * a.n_ci, 6), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -252,10 +283,10 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout) {
     long long tiles = 0;
     for (int p = 0; p < 3; ++p) tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC);
     const long long base = (long long)cdiv(cout, 64) * cdiv(cin, 64) * 3;
-    long long ks = (1024 + base - 1) / base;                         // aim for ~1000 blocks
+    long long ks = (512 + base - 1) / base;                          // aim for ~2 blocks per CU ...
     const long long per_plane = std::max<long long>(1, tiles * B / 3);
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
-    return int(std::min<long long>(ks, 256));
+    return int(std::min<long long>(ks, 64));                         // ... but bound the partial-sum traffic
 }
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
@@ -291,51 +322,85 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
 // With dz = dy*silu'(z), per (b, plane, channel):  A1 = sum_px dz,  A2 = sum_px dz*xh.  Then
 //   dshift = A1, dscale = gamma*A2 + beta*A1, dbeta = sum_b (1+s)A1, dgamma = sum_b (1+s)A2,
 //   dx = rstd * ( g*dz - mean_grp(g*dz) - xh * mean_grp(g*dz*xh) ),  g = gamma*(1+s).
-// dy here is the dense dgrad of the plane's own channels plus the broadcast gradients of its two axis means.
+// dy here is the dense dgrad of the plane's own channels plus the broadcast gradients of its two axis means
+// (rowadd[r] * rowscale + coladd[c] * colscale, the scales being 1/length of the averaged axis).
+// A thread owns one float4 of channels (cq = C/4 quads x pl pixel lanes per block), as in the forward kernel.
 struct GnBwdArgs {
     const float* x[3]; const float* dy[3]; float* dx[3];
-    const float* rowadd[3]; const float* coladd[3];      // [B][h][C], [B][w][C] (already divided by the mean length) or null
+    const float* rowadd[3]; const float* coladd[3];      // [B][h][C], [B][w][C] or null
+    float rowscale[3], colscale[3];
     const float* add[3];                                  // extra gradient path added to dx, or null
     const float* gamma[3]; const float* beta[3];
     const float* mr; const float* film; int film_stride;
     float* part;                                          // [B][3][nchunk][C][2]
     const float* coef;                                    // [B][3][C][2] = {mean_grp(g*dz), mean_grp(g*dz*xh)}
     int h[3], w[3];
-    int C, B, nchunk, silu;
+    int C, cq, pl, B, nchunk;
 };
 constexpr int kGnBwdChunks = 64;
-__device__ __forceinline__ float gn_bwd_dz(const GnBwdArgs& a, int p, int b, int r, int c, size_t pix, int ch, float mean, float rstd,
-                                           float gam, float bet, float sc, float sh, float& xh) {
-    const int C = a.C;
-    const float x = a.x[p][pix * C + ch];
-    float dy = a.dy[p][pix * C + ch];
-    if (a.rowadd[p]) dy += a.rowadd[p][(size_t(b) * a.h[p] + r) * C + ch];
-    if (a.coladd[p]) dy += a.coladd[p][(size_t(b) * a.w[p] + c) * C + ch];
-    xh = (x - mean) * rstd;
-    if (!a.silu) return dy;
-    const float z = (xh * gam + bet) * sc + sh;
+struct GnChan { float mean, rstd, gam, bet, sc, sh; };
+__device__ __forceinline__ GnChan gn_chan(const GnBwdArgs& a, int p, int b, int ch) {
+    const int cg = a.C / 32;
+    const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
+    GnChan c;
+    c.mean = mr[0]; c.rstd = mr[1]; c.gam = a.gamma[p][ch]; c.bet = a.beta[p][ch];
+    c.sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
+    c.sh = a.film ? a.film[size_t(b) * a.film_stride + a.C + ch] : 0.0f;
+    return c;
+}
+__device__ __forceinline__ float gn_dz(const GnChan& c, float x, float dy, float& xh) {
+    xh = (x - c.mean) * c.rstd;
+    const float z = (xh * c.gam + c.bet) * c.sc + c.sh;
     const float sg = sigmoid_f(z);
     return dy * sg * (1.0f + z * (1.0f - sg));
 }
+__device__ __forceinline__ float4 gn_dy4(const GnBwdArgs& a, int p, int b, int r, int c, size_t pix, int q) {
+    float4 dy = reinterpret_cast<const float4*>(a.dy[p])[pix * a.cq + q];
+    if (a.rowadd[p]) {
+        const float4 v = reinterpret_cast<const float4*>(a.rowadd[p])[(size_t(b) * a.h[p] + r) * a.cq + q];
+        const float s = a.rowscale[p];
+        dy.x = fmaf(v.x, s, dy.x); dy.y = fmaf(v.y, s, dy.y); dy.z = fmaf(v.z, s, dy.z); dy.w = fmaf(v.w, s, dy.w);
+    }
+    if (a.coladd[p]) {
+        const float4 v = reinterpret_cast<const float4*>(a.coladd[p])[(size_t(b) * a.w[p] + c) * a.cq + q];
+        const float s = a.colscale[p];
+        dy.x = fmaf(v.x, s, dy.x); dy.y = fmaf(v.y, s, dy.y); dy.z = fmaf(v.z, s, dy.z); dy.w = fmaf(v.w, s, dy.w);
+    }
+    return dy;
+}
 __global__ __launch_bounds__(256) void k_gn_bwd_partials(GnBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm_gn[];      // [pl][C][2]
     const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
-    const int h = a.h[p], w = a.w[p], C = a.C, cg = C / 32;
+    const int h = a.h[p], w = a.w[p], C = a.C;
     const long long npix = (long long)h * w;
     const long long p0 = npix * chunk / a.nchunk, p1 = npix * (chunk + 1) / a.nchunk;
-    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
-        const float mean = mr[0], rstd = mr[1], gam = a.gamma[p][ch], bet = a.beta[p][ch];
-        const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
-        const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
-        float a1 = 0.f, a2 = 0.f;
-        for (long long q = p0; q < p1; ++q) {
-            const int r = int(q / w), c = int(q % w);
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    GnChan ch[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ch[k] = gn_chan(a, p, b, 4 * q + k);
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    const float4* xs = reinterpret_cast<const float4*>(a.x[p]);
+    for (long long i = p0 + l; i < p1; i += a.pl) {
+        const int r = int(i / w), c = int(i % w);
+        const size_t pix = size_t(b) * npix + i;
+        const float4 x = xs[pix * a.cq + q];
+        const float4 dy = gn_dy4(a, p, b, r, c, pix, q);
+        const float xv[4] = {x.x, x.y, x.z, x.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             float xh;
-            const float dz = gn_bwd_dz(a, p, b, r, c, size_t(b) * npix + q, ch, mean, rstd, gam, bet, sc, sh, xh);
-            a1 += dz; a2 = fmaf(dz, xh, a2);
+            const float dz = gn_dz(ch[k], xv[k], dv[k], xh);
+            a1[k] += dz; a2[k] = fmaf(dz, xh, a2[k]);
         }
-        float* o = a.part + ((((size_t(b) * 3 + p) * a.nchunk + chunk) * C) + ch) * 2;
-        o[0] = a1; o[1] = a2;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sm_gn[(size_t(l) * C + 4 * q + k) * 2] = a1[k]; sm_gn[(size_t(l) * C + 4 * q + k) * 2 + 1] = a2[k]; }
+    __syncthreads();
+    float* o = a.part + (((size_t(b) * 3 + p) * a.nchunk + chunk) * C) * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int ll = 0; ll < a.pl; ++ll) s += sm_gn[size_t(ll) * C * 2 + i];
+        o[i] = s;
     }
 }
 // A[b][p][c][2] = sum over chunks (double) ; then group coefficients and the parameter / FiLM gradients
@@ -402,50 +467,58 @@ __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
         }
 }
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, long long begin1, long long begin2, long long total) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 items
     if (idx >= total * a.B) return;
     const int b = int(idx / total);
     long long r = idx % total;
     const int p = r >= begin2 ? 2 : (r >= begin1 ? 1 : 0);
     r -= p == 2 ? begin2 : (p == 1 ? begin1 : 0);
-    const int C = a.C, cg = C / 32;
-    const int ch = int(r % C);
-    const long long q = r / C;
+    const int q = int(r % a.cq);
+    const long long i = r / a.cq;
     const int w = a.w[p], h = a.h[p];
-    const int row = int(q / w), col = int(q % w);
-    const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
-    const float mean = mr[0], rstd = mr[1], gam = a.gamma[p][ch], bet = a.beta[p][ch];
-    const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
-    const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
-    const size_t pix = size_t(b) * h * w + q;
-    float xh;
-    const float dz = gn_bwd_dz(a, p, b, row, col, pix, ch, mean, rstd, gam, bet, sc, sh, xh);
-    const float* cf = a.coef + ((size_t(b) * 3 + p) * C + ch) * 2;
-    float dx = rstd * (gam * sc * dz - cf[0] - xh * cf[1]);
-    if (a.add[p]) dx += a.add[p][pix * C + ch];
-    a.dx[p][pix * C + ch] = dx;
+    const int row = int(i / w), col = int(i % w);
+    const size_t pix = size_t(b) * h * w + i;
+    const float4 x = reinterpret_cast<const float4*>(a.x[p])[pix * a.cq + q];
+    const float4 dy = gn_dy4(a, p, b, row, col, pix, q);
+    float4 ad = make_float4(0, 0, 0, 0);
+    if (a.add[p]) ad = reinterpret_cast<const float4*>(a.add[p])[pix * a.cq + q];
+    const float xv[4] = {x.x, x.y, x.z, x.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w}, av[4] = {ad.x, ad.y, ad.z, ad.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int chn = 4 * q + k;
+        const GnChan c = gn_chan(a, p, b, chn);
+        float xh;
+        const float dz = gn_dz(c, xv[k], dv[k], xh);
+        const float* cf = a.coef + ((size_t(b) * 3 + p) * a.C + chn) * 2;
+        o[k] = c.rstd * (c.gam * c.sc * dz - cf[0] - xh * cf[1]) + av[k];
+    }
+    reinterpret_cast<float4*>(a.dx[p])[pix * a.cq + q] = make_float4(o[0], o[1], o[2], o[3]);
 }
 size_t gn_bwd_ws_floats(int B, int C) { return size_t(B) * 3 * kGnBwdChunks * C * 2 + size_t(B) * 3 * C * 4; }
 int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     GnBwdArgs a;
     const Tri& x = s.x;
+    S3D_CHECK(x.C % 32 == 0 && x.C <= 1024, S3D_ERR_INVALID, "gn_act_bwd: C=%d", x.C);
     long long begin[4] = {0, 0, 0, 0};
+    a.C = x.C; a.cq = x.C / 4; a.pl = a.cq >= 256 ? 1 : 256 / a.cq;
     for (int p = 0; p < 3; ++p) {
         a.x[p] = x.p[p]; a.dy[p] = s.dy.p[p]; a.dx[p] = s.dx.p[p];
         a.rowadd[p] = s.rowadd ? s.rowadd[p] : nullptr; a.coladd[p] = s.coladd ? s.coladd[p] : nullptr;
+        a.rowscale[p] = 1.0f / float(x.g.w[p]); a.colscale[p] = 1.0f / float(x.g.h[p]);   // d(mean over w) / d(mean over h)
         a.add[p] = s.add ? s.add->p[p] : nullptr;
         a.gamma[p] = s.gamma[p]; a.beta[p] = s.beta[p];
         a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p];
-        begin[p + 1] = begin[p] + (long long)x.g.h[p] * x.g.w[p] * x.C;
+        begin[p + 1] = begin[p] + (long long)x.g.h[p] * x.g.w[p] * a.cq;
     }
     a.mr = s.stats.mr; a.film = s.film; a.film_stride = s.film_stride;
-    a.C = x.C; a.B = s.B; a.nchunk = kGnBwdChunks; a.silu = 1;
+    a.B = s.B; a.nchunk = kGnBwdChunks;
     float* part = s.ws;
     float* A = part + size_t(s.B) * 3 * kGnBwdChunks * x.C * 2;
     float* coef = A + size_t(s.B) * 3 * x.C * 2;
     a.part = part; a.coef = coef;
     if (!s.B || !begin[3]) return 0;
-    hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(std::min(256, x.C)), 0, st, a);
+    hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(a.cq * a.pl), size_t(a.pl) * x.C * 2 * sizeof(float), st, a);
     S3D_HIP(hipGetLastError());
     GnBwdFinArgs f;
     f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride;
@@ -470,62 +543,85 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
 // and v[px][c] an NHWC plane:
 //   outer[p][o][c] = sum_{b,px} s[o]*v[c] ;  ssum[p][o] = sum s[o] ;  vsum[p][c] = sum v[c] ;
 //   optional dv[px][c] = sum_o Wt[p][o][c]*s[px][o]                                      (out.2's dgrad)
-// Two-stage: per-chunk partials, then k_small_reduce adds them in order.
-constexpr int kSmallChunks = 64, kSmallMaxS = 16;
+// Two-stage: per-chunk partials (a thread owns a float4 of channels and every pl-th pixel of the chunk; the pixel
+// lanes are added through LDS in lane order), then k_small_reduce adds the chunks in order.
+constexpr int kSmallChunks = 256, kSmallMaxS = 12;
 struct SmallArgs {
     const float* s;                 // composed [B][S][H+D][W+D]
     const float* v[3];              // NHWC [B][h][w][C]
     const float* Wt;                // [3][S][C] or null
     float* dv[3];                   // NHWC or null
     float* part;                    // [3][chunks][S+1][C] (row S = vsum) followed by [3][chunks][S] (ssum)
-    int H, W, D, S, C, B;
+    int H, W, D, S, C, cq, pl, B;
 };
 __device__ __forceinline__ size_t composed_index(int p, int H, int W, int D, int S, int b, int o, int r, int c) {
     const int Y = p == 2 ? H + c : r, X = p == 0 ? c : (p == 1 ? W + c : r);
     return ((size_t(b) * S + o) * (H + D) + Y) * (W + D) + X;
 }
 __global__ __launch_bounds__(256) void k_small_outer(SmallArgs a) {
-    __shared__ float ss[kSmallMaxS];
+    extern __shared__ __attribute__((aligned(16))) float sm_so[];       // [pl][S+1][C] then [pl][S]
+    constexpr int SM = kSmallMaxS;
+    const int S = a.S;
     const int chunk = blockIdx.x, p = blockIdx.y;
     const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
     const long long npix = (long long)a.B * h * w;
     const long long p0 = npix * chunk / kSmallChunks, p1 = npix * (chunk + 1) / kSmallChunks;
-    const int S = a.S, C = a.C;
-    // each thread owns channels tid, tid+256, ... ; accumulators for up to 2 channels per thread (C <= 512)
-    float acc[2][kSmallMaxS + 1];
-    for (int k = 0; k < 2; ++k) for (int o = 0; o <= kSmallMaxS; ++o) acc[k][o] = 0.f;
-    float ssum = 0.f;                                   // thread o < S accumulates sum s[o]
-    for (long long q = p0; q < p1; ++q) {
-        const int b = int(q / ((long long)h * w));
-        const long long pq = q % ((long long)h * w);
-        const int r = int(pq / w), c = int(pq % w);
-        __syncthreads();
-        if (int(threadIdx.x) < S) {
-            const float sv = a.s[composed_index(p, a.H, a.W, a.D, S, b, threadIdx.x, r, c)];
-            ss[threadIdx.x] = sv; ssum += sv;
-        }
-        __syncthreads();
-        for (int k = 0; k < 2; ++k) {
-            const int ch = threadIdx.x + k * 256;
-            if (ch >= C) break;
-            const float v = a.v[p][size_t(q) * C + ch];
-            float dv = 0.f;
-            for (int o = 0; o < S; ++o) {
-                acc[k][o] = fmaf(ss[o], v, acc[k][o]);
-                if (a.Wt) dv = fmaf(a.Wt[(size_t(p) * S + o) * C + ch], ss[o], dv);
-            }
-            acc[k][S] += v;
-            if (a.dv[p]) a.dv[p][size_t(q) * C + ch] = dv;
+    const int C = a.C, q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    float acc[SM][4], vs[4] = {0, 0, 0, 0}, wt[SM][4], ssum[SM];
+#pragma unroll
+    for (int o = 0; o < SM; ++o) {
+        ssum[o] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[o][k] = 0.f;
+            wt[o][k] = (a.Wt && o < S) ? a.Wt[(size_t(p) * S + o) * C + 4 * q + k] : 0.f;
         }
     }
+    const size_t ostride = size_t(a.H + a.D) * (a.W + a.D);
+    for (long long i = p0 + l; i < p1; i += a.pl) {
+        const int b = int(i / ((long long)h * w));
+        const long long pq = i % ((long long)h * w);
+        const int r = int(pq / w), c = int(pq % w);
+        float sv[SM];
+        const size_t base = composed_index(p, a.H, a.W, a.D, S, b, 0, r, c);
+#pragma unroll
+        for (int o = 0; o < SM; ++o) sv[o] = o < S ? a.s[base + o * ostride] : 0.f;
+        const float4 v = reinterpret_cast<const float4*>(a.v[p])[size_t(i) * a.cq + q];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float dv[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int o = 0; o < SM; ++o) {
+            ssum[o] += sv[o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { acc[o][k] = fmaf(sv[o], vv[k], acc[o][k]); dv[k] = fmaf(wt[o][k], sv[o], dv[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vs[k] += vv[k];
+        if (a.dv[p]) reinterpret_cast<float4*>(a.dv[p])[size_t(i) * a.cq + q] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    }
+    float* sms = sm_so + size_t(a.pl) * (S + 1) * C;
+#pragma unroll
+    for (int o = 0; o < SM; ++o)
+        if (o < S) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm_so[(size_t(l) * (S + 1) + o) * C + 4 * q + k] = acc[o][k];
+            if (q == 0) sms[l * S + o] = ssum[o];
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm_so[(size_t(l) * (S + 1) + S) * C + 4 * q + k] = vs[k];
+    __syncthreads();
     float* part = a.part + (size_t(p) * kSmallChunks + chunk) * (S + 1) * C;
-    for (int k = 0; k < 2; ++k) {
-        const int ch = threadIdx.x + k * 256;
-        if (ch >= C) break;
-        for (int o = 0; o <= S; ++o) part[size_t(o) * C + ch] = acc[k][o];
+    for (int i = threadIdx.x; i < (S + 1) * C; i += blockDim.x) {
+        float s = 0.f;
+        for (int ll = 0; ll < a.pl; ++ll) s += sm_so[size_t(ll) * (S + 1) * C + i];
+        part[i] = s;
     }
     float* sp = a.part + size_t(3) * kSmallChunks * (S + 1) * C + (size_t(p) * kSmallChunks + chunk) * S;
-    if (int(threadIdx.x) < S) sp[threadIdx.x] = ssum;
+    if (int(threadIdx.x) < S) {
+        float s = 0.f;
+        for (int ll = 0; ll < a.pl; ++ll) s += sms[ll * S + threadIdx.x];
+        sp[threadIdx.x] = s;
+    }
 }
 struct SmallRedArgs {
     const float* part; int S, C;
@@ -551,11 +647,14 @@ __global__ void k_small_reduce(SmallRedArgs a) {
 }
 size_t small_outer_ws_floats(int S, int C) { return size_t(3) * kSmallChunks * ((S + 1) * C + S); }
 int launch_small_outer(const SmallOuter& s, hipStream_t st) {
-    S3D_CHECK(s.S <= kSmallMaxS && s.C <= 512, S3D_ERR_UNSUPPORTED, "small_outer: S=%d C=%d", s.S, s.C);
+    S3D_CHECK(s.S >= 1 && s.S <= kSmallMaxS && s.C % 4 == 0 && s.C <= 1024, S3D_ERR_UNSUPPORTED,
+              "training supports in/out_channels <= %d (the Sin3DM triplane feature width), got %d (C=%d)", kSmallMaxS, s.S, s.C);
     SmallArgs a;
     a.s = s.s; a.Wt = s.Wt; a.part = s.ws; a.H = s.H; a.W = s.W; a.D = s.D; a.S = s.S; a.C = s.C; a.B = s.B;
+    a.cq = s.C / 4; a.pl = a.cq >= 256 ? 1 : 256 / a.cq;
     for (int p = 0; p < 3; ++p) { a.v[p] = s.v.p[p]; a.dv[p] = s.dv ? s.dv->p[p] : nullptr; }
-    hipLaunchKernelGGL(k_small_outer, dim3(kSmallChunks, 3), dim3(256), 0, st, a);
+    const size_t shm = size_t(a.pl) * ((s.S + 1) * s.C + s.S) * sizeof(float);
+    hipLaunchKernelGGL(k_small_outer, dim3(kSmallChunks, 3), dim3(a.cq * a.pl), shm, st, a);
     S3D_HIP(hipGetLastError());
     SmallRedArgs r;
     r.part = s.ws; r.S = s.S; r.C = s.C; r.outer_transposed = s.outer_transposed;
@@ -688,19 +787,28 @@ __global__ void k_linear_bwd_w(const float* __restrict__ dy, int dy_stride, cons
     dW[idx] = s;
     if (i == 0) db[o] = sb;
 }
-// dx[b][i] = (sum_o dy[b][o] * W[o][i]) * (in_mode == 1 ? silu'(in[b][i]) : 1)
-__global__ void k_linear_bwd_x(const float* __restrict__ dy, int dy_stride, const float* __restrict__ W,
-                               const float* __restrict__ in, int B, int I, int O, int in_mode, float* __restrict__ dx) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * I) return;
-    const int i = idx % I, b = idx / I;
+// dx[b][i] = (sum_o dy[b][o] * W[o][i]) * (in_mode == 1 ? silu'(in[b][i]) : 1); block = (b, 32 inputs) x 8 output lanes
+__global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ dy, int dy_stride, const float* __restrict__ W,
+                                                      const float* __restrict__ in, int B, int I, int O, int in_mode,
+                                                      float* __restrict__ dx) {
+    __shared__ float sm[8][32];
+    const int il = threadIdx.x & 31, ol = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + il, b = blockIdx.y;
     float s = 0.f;
-    for (int o = 0; o < O; ++o) s = fmaf(dy[size_t(b) * dy_stride + o], W[size_t(o) * I + i], s);
-    if (in_mode == 1) {
-        const float v = in[idx], sg = 1.0f / (1.0f + expf(-v));
-        s *= sg * (1.0f + v * (1.0f - sg));
+    if (i < I)
+        for (int o = ol; o < O; o += 8) s = fmaf(dy[size_t(b) * dy_stride + o], W[size_t(o) * I + i], s);
+    sm[ol][il] = s;
+    __syncthreads();
+    if (ol == 0 && i < I) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][il];
+        if (in_mode == 1) {
+            const float v = in[size_t(b) * I + i], sg = 1.0f / (1.0f + expf(-v));
+            t *= sg * (1.0f + v * (1.0f - sg));
+        }
+        dx[size_t(b) * I + i] = t;
     }
-    dx[idx] = s;
 }
 int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
                       float* db, float* dx, hipStream_t st) {
@@ -710,7 +818,7 @@ int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, in
         S3D_HIP(hipGetLastError());
     }
     if (dx) {
-        hipLaunchKernelGGL(k_linear_bwd_x, dim3(cdiv(B * I, 256)), dim3(256), 0, st, dy, dy_stride, W, in, B, I, O, in_mode, dx);
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3(cdiv(I, 32), B), dim3(256), 0, st, dy, dy_stride, W, in, B, I, O, in_mode, dx);
         S3D_HIP(hipGetLastError());
     }
     return 0;

@@ -99,14 +99,9 @@ struct Bwd {
                     jc.in = Cs[p]; jc.wgt = m->tdev(wt.rcol_T[p]); jc.out = d_colvec[p]; jc.h = 1; jc.w = g.w[p];
                 }
                 S3D_TRY(launch_conv(CONV_1x3_VEC, ca, st));
-                // d(mean over an axis of length n) -> 1/n per element of that axis
-                S3D_TRY(launch_scale(d_rowvec[0], (long long)B * g.h[0] * cin, 1.0f / g.w[1], st));   // rowmean[1]
-                S3D_TRY(launch_scale(d_rowvec[1], (long long)B * g.h[1] * cin, 1.0f / g.w[0], st));   // rowmean[0]
-                S3D_TRY(launch_scale(d_rowvec[2], (long long)B * g.h[2] * cin, 1.0f / g.h[0], st));   // colmean[0]
-                S3D_TRY(launch_scale(d_colvec[0], (long long)B * g.w[0] * cin, 1.0f / g.w[2], st));   // rowmean[2]
-                S3D_TRY(launch_scale(d_colvec[1], (long long)B * g.w[1] * cin, 1.0f / g.h[2], st));   // colmean[2]
-                S3D_TRY(launch_scale(d_colvec[2], (long long)B * g.w[2] * cin, 1.0f / g.h[1], st));   // colmean[1]
             }
+            // each vector is the gradient of one axis mean of another plane; the 1/length factor is applied where it is
+            // broadcast-added (launch_gn_act_bwd: rowscale = 1/w, colscale = 1/h of the receiving plane)
             rowadd[1] = d_rowvec[0]; rowadd[0] = d_rowvec[1]; coladd[0] = d_rowvec[2];
             rowadd[2] = d_colvec[0]; coladd[2] = d_colvec[1]; coladd[1] = d_colvec[2];
         } else if (rowadd) {
