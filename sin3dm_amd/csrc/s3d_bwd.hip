@@ -126,20 +126,36 @@ __global__ __launch_bounds__(256) void k_slot_wgrad(SlotArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
     const int pairs = (L + 1) / 2, total = a.B * pairs;
-    for (int it = wid; it < total; it += 4) {
+    // one-deep software pipeline: the ten operand loads of step n+1 are in flight during the nine MFMAs of step n
+    float bv = 0.f, av[3][3];
+    auto load = [&](int it, float& b_out, float (&a_out)[3][3]) {
         const int b = it / pairs, pos = (it % pairs) * 2 + kk;
-        const float bv = pos < L ? J.v[(size_t(b) * L + pos) * a.C + ci] : 0.f;
+        const bool in = it < total && pos < L;
+        b_out = in ? J.v[(size_t(b) * L + pos) * a.C + ci] : 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int q = pos - t + 1;
-            const bool ok = pos < L && q >= 0 && q < L;
+            const bool ok = in && q >= 0 && q < L;
             const float* S = J.S + (size_t(b) * L + (ok ? q : 0)) * 3 * a.cout + co;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float av = ok ? S[j * a.cout] : 0.f;
-                acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t][j], 0, 0, 0);
-            }
+            for (int j = 0; j < 3; ++j) a_out[t][j] = ok ? S[j * a.cout] : 0.f;
         }
+    };
+    load(wid, bv, av);
+    for (int it = wid; it < total; it += 4) {
+        float nb, na[3][3];
+        load(it + 4, nb, na);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bv = nb;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) av[t][j] = na[t][j];
     }
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -184,61 +200,89 @@ int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
 // One block = 64 co x 64 ci x all taps for a slice of the pixel tiles (split-K); partials are added in slice order
 // by k_wgrad_reduce, which also scatters into the reference's OIHW layout.
 constexpr int WG_TR = 4, WG_TC = 16;                 // pixel tile
-template <int TAPS>
+// TAPS: 9 (3x3) or 1; TROWS: kernel rows handled by one block (3 = all nine taps, 1 = one row of three taps: three
+// times the blocks and a third of the accumulators, for layers too small to fill the chip otherwise)
+template <int TAPS, int TROWS>
 struct WgSmem {
     static constexpr int HALO = TAPS == 9 ? 1 : 0;
-    static constexpr int AR = WG_TR + 2 * HALO, AC = WG_TC + 2 * HALO;
+    static constexpr int AR = WG_TR + (TROWS == 3 ? 2 * HALO : 0), AC = WG_TC + 2 * HALO;
     float dy[2][WG_TR * WG_TC][32];
     float a[2][AR * AC][32];
 };
 struct WgJob { const float* dy; const float* a; float* part; int h, w, tiles_x, tiles; int block_begin; };
 struct WgArgs { WgJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci; };
 
-template <int TAPS>
+template <int TAPS, int TROWS>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
-    using SM = WgSmem<TAPS>;
+    using SM = WgSmem<TAPS, TROWS>;
     __shared__ __attribute__((aligned(16))) SM sm;
     constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = TAPS == 9 ? 3 : 1;
+    constexpr int NT = TAPS == 9 ? 3 * TROWS : 1;                     // taps of this block
+    constexpr int NDY = (2 * WG_TR * WG_TC * 8) / 256, NA = (2 * AR * AC * 8 + 255) / 256;
     int p = 0;
     while (p < 2 && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
     const WgJob& J = args.job[p];
     int local = blockIdx.x - J.block_begin;
+    int dr0 = 0;
+    if (TAPS == 9 && TROWS == 1) { dr0 = local % 3; local /= 3; }
     const int ks = local % args.ksplit; local /= args.ksplit;
     const int tci = local % args.n_ci, tco = local / args.n_ci;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, kk = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
     const int co0 = tco * 64, ci0 = tci * 64;
     const bool wave_on = co0 + wm * 32 < args.cout && ci0 + wn * 32 < args.cin;
-    f32x16 acc[TAPS];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const long long total = (long long)J.tiles * args.B;
     const long long t_begin = total * ks / args.ksplit, t_end = total * (ks + 1) / args.ksplit;
-    for (long long tt = t_begin; tt < t_end; ++tt) {
+    // the a-tile's first row relative to the dy tile: all three kernel rows need rows -1..TR, a single row dr0 needs dr0-1..
+    const int arow0 = TROWS == 3 ? -HALO : dr0 - HALO;
+    float4 rdy[NDY], ra[NA];
+    auto load_tile = [&](long long tt) {
         const int b = int(tt / J.tiles), tile = int(tt % J.tiles);
         const int r0 = (tile / J.tiles_x) * WG_TR, c0 = (tile % J.tiles_x) * WG_TC;
-        __syncthreads();
-        // stage dy tile: [2 panels][64 px][32]
-        for (int it = tid; it < 2 * WG_TR * WG_TC * 8; it += 256) {
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int it = k * 256 + tid;
             const int q = it & 7, px = (it >> 3) % (WG_TR * WG_TC), pan = it / (8 * WG_TR * WG_TC);
             const int r = r0 + px / WG_TC, c = c0 + px % WG_TC, ch = co0 + pan * 32 + q * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (r < J.h && c < J.w && ch < args.cout)
-                v = *reinterpret_cast<const float4*>(J.dy + ((size_t(b) * J.h + r) * J.w + c) * args.cout + ch);
-            *reinterpret_cast<float4*>(&sm.dy[pan][px][q * 4]) = v;
+            const bool ok = r < J.h && c < J.w && ch < args.cout;
+            rdy[k] = ok ? *reinterpret_cast<const float4*>(J.dy + ((size_t(b) * J.h + r) * J.w + c) * args.cout + ch) : make_float4(0, 0, 0, 0);
         }
-        for (int it = tid; it < 2 * AR * AC * 8; it += 256) {
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int it = k * 256 + tid;
             const int q = it & 7, px = (it >> 3) % (AR * AC), pan = it / (8 * AR * AC);
-            const int r = r0 - HALO + px / AC, c = c0 - HALO + px % AC, ch = ci0 + pan * 32 + q * 4;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (r >= 0 && r < J.h && c >= 0 && c < J.w && ch < args.cin)
-                v = *reinterpret_cast<const float4*>(J.a + ((size_t(b) * J.h + r) * J.w + c) * args.a_cstride + ch);
-            *reinterpret_cast<float4*>(&sm.a[pan][px][q * 4]) = v;
+            const int r = r0 + arow0 + px / AC, c = c0 - HALO + px % AC, ch = ci0 + pan * 32 + q * 4;
+            const bool ok = pan < 2 && r >= 0 && r < J.h && c >= 0 && c < J.w && ch < args.cin;
+            ra[k] = ok ? *reinterpret_cast<const float4*>(J.a + ((size_t(b) * J.h + r) * J.w + c) * args.a_cstride + ch) : make_float4(0, 0, 0, 0);
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int it = k * 256 + tid;
+            const int q = it & 7, px = (it >> 3) % (WG_TR * WG_TC), pan = it / (8 * WG_TR * WG_TC);
+            *reinterpret_cast<float4*>(&sm.dy[pan][px][q * 4]) = rdy[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int it = k * 256 + tid;
+            const int q = it & 7, px = (it >> 3) % (AR * AC), pan = it / (8 * AR * AC);
+            if (pan < 2) *reinterpret_cast<float4*>(&sm.a[pan][px][q * 4]) = ra[k];
+        }
+    };
+    if (t_begin < t_end) load_tile(t_begin);
+    for (long long tt = t_begin; tt < t_end; ++tt) {
         __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tt + 1 < t_end) load_tile(tt + 1);            // in flight while the matrix cores work on this tile
+        __builtin_amdgcn_sched_barrier(0);
         if (!wave_on) continue;
 #pragma unroll
         for (int r = 0; r < WG_TR; ++r)
@@ -246,8 +290,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
             for (int c = 0; c < WG_TC; c += 2) {
                 const float av = sm.dy[wm][r * WG_TC + c + kk][i];
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int dr = t / KW, dc = t % KW;
+                for (int t = 0; t < NT; ++t) {
+                    const int dr = TROWS == 3 ? t / KW : 0, dc = t % KW;
                     const float bv = sm.a[wn][(r + dr) * AC + c + kk + dc][i];
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                 }
@@ -259,9 +303,9 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = ci0 + wn * 32 + i;
-        float* d = part + (size_t(co) * args.cin + ci) * TAPS;
+        float* d = part + (size_t(co) * args.cin + ci) * TAPS + (TAPS == 9 ? dr0 * 3 : 0);
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) d[t] = acc[t][r];
+        for (int t = 0; t < NT; ++t) d[t] = acc[t][r];
     }
 }
 
@@ -296,17 +340,20 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     WgArgs a;
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
     a.n_co = cdiv(w.cout, 64); a.n_ci = cdiv(w.cin, 64);
+    // small layers: one kernel row per block (3x the blocks, a third of the registers -> more waves per SIMD)
+    const bool split_rows = w.taps == 9 && a.n_co * a.n_ci * a.ksplit * 3 < 768;
     int blocks = 0;
     for (int p = 0; p < 3; ++p) {
         WgJob& J = a.job[p];
         J.dy = w.dy.p[p]; J.a = w.a.p[p]; J.part = w.part[p]; J.h = w.dy.g.h[p]; J.w = w.dy.g.w[p];
         J.tiles_x = cdiv(J.w, WG_TC); J.tiles = J.tiles_x * cdiv(J.h, WG_TR);
         J.block_begin = blocks;
-        blocks += a.n_co * a.n_ci * a.ksplit;
+        blocks += a.n_co * a.n_ci * a.ksplit * (split_rows ? 3 : 1);
     }
     if (!blocks || !w.B) return 0;
-    if (w.taps == 9) hipLaunchKernelGGL(k_wgrad_mfma<9>, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_wgrad_mfma<1>, dim3(blocks), dim3(256), 0, st, a);
+    if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 3>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad_mfma<1, 1>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     WgRedArgs r;
     for (int p = 0; p < 3; ++p) { r.part[p] = w.part[p]; r.dW[p] = w.dW[p]; }

@@ -22,7 +22,7 @@ import numpy as np
 import torch as th
 import torch.distributed as dist
 
-from .. import _lib
+from .. import _lib, parallel
 from .resample import LossAwareSampler, UniformSampler
 
 
@@ -107,7 +107,7 @@ class TrainLoop:
             self.resume_step = parse_resume_step_from_filename(resume_checkpoint)
             self.model.load_state_dict(th.load(resume_checkpoint, map_location="cpu"))
         if self.world > 1:                           # identical start on every rank (the role of sync_params)
-            dist.broadcast(self.model.flat_parameters, src=0)
+            parallel.broadcast_flat_(self.model.flat_parameters, src=0)
             self.model.mark_parameters_changed()
         self.opt = FlatAdamW(model, lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
         if self.resume_step:
@@ -153,9 +153,7 @@ class TrainLoop:
         micro = batch.to(dev)
         t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
         losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
-        if self.world > 1:                            # loss = mean over the GLOBAL batch: average the rank gradients
-            dist.all_reduce(grad)
-            grad.mul_(1.0 / self.world)
+        parallel.average_flat_(grad)                  # loss = mean over the GLOBAL batch: one all-reduce per step
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
         if self.step % 10 == 0:

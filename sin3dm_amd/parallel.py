@@ -66,3 +66,21 @@ def gather_objects(obj):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, obj)
     return out
+
+
+# ---- data-parallel training: replicas with one exchange per step
+def broadcast_flat_(flat, src=0):
+    """Identical start on every rank: overwrite `flat` with rank `src`'s copy (the role of the reference's dead
+    sync_params, src/utils/dist_util.py:62-68)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+def average_flat_(flat):
+    """Mean over ranks of a flat gradient vector, in place: ONE all-reduce per training step (RCCL over xGMI on GPUs:
+    28 MB at 64 channels, 112 MB at 128).  loss = mean over the GLOBAL batch => average the per-rank gradients."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat)
+        flat.mul_(1.0 / dist.get_world_size())
+    return flat

@@ -52,3 +52,35 @@ def test_sample_cli_ddim10_voxels(tmp_path):
     assert d["feat_xy"].shape == (12, 46, 96) and d["feat_yz"].shape == (12, 96, 46)
     vox = np.load(os.path.join(os.path.dirname(paths[0]), "r32_voxel.npz"))["voxel"]
     assert vox.shape == (15, 32, 15)                                    # y extent 1.5x: floor(32 * 1.44 / 3.0) = 15
+
+
+def test_train_cli_then_sample(tmp_path):
+    """train.py's diffusion stage on an existing encoding, then sample.py from the checkpoint it wrote; a resumed
+    TrainLoop continues from the saved optimizer / EMA state."""
+    from sin3dm_amd import train
+    from sin3dm_amd.utils import parser_util as pu
+    enc = make_experiment(str(tmp_path / "src"), hwd=(12, 16, 10), mc=32)
+    enc_log = pu.encoding_log_dir(enc)
+    tag = str(tmp_path / "run")
+    train.main(["--tag", tag, "--enc_log", enc_log, "--model_channels", "32", "--diff_batch_size", "2", "--diff_n_iters", "6",
+                "--save_interval", "3", "--log_interval", "2", "--ema_rate", "0.9"], confirm=lambda _: "y")
+    ddir = pu.diffusion_log_dir(tag)
+    files = sorted(os.listdir(ddir))
+    assert "ema_0.9_000003.pt" in files and "ema_0.9_000006.pt" in files and "opt000006.pt" in files and "progress.jsonl" in files
+    sd = torch.load(os.path.join(ddir, "ema_0.9_000006.pt"))
+    init = T.unet_param_shapes(model_channels=32)
+    assert list(sd) and {k: tuple(v.shape) for k, v in sd.items()} == dict(init)
+    opt = torch.load(os.path.join(ddir, "opt000006.pt"))
+    assert len(opt["state"]) == len(sd) and float(opt["state"][0]["step"]) == 6.0
+    logs = [json.loads(l) for l in open(os.path.join(ddir, "progress.jsonl"))]
+    assert logs and all(np.isfinite(l["loss"]) for l in logs if "loss" in l)
+    assert logs[-1]["lr"] < 5e-4                                       # linear anneal
+    # the checkpoint is what sample.py expects
+    from sin3dm_amd.diffusion.script_util import create_model_and_diffusion_from_args
+    args = pu.sample_args(["--tag", tag, "--n_samples", "1"])
+    model, diffusion = create_model_and_diffusion_from_args(args)
+    model.load_state_dict(torch.load(pu.diffusion_model_path(tag, 0.9, 6), map_location="cpu"))
+    model.to("cuda:0").eval()
+    with torch.no_grad():
+        y = model(torch.randn(1, 12, 22, 26, device="cuda:0"), torch.tensor([10], device="cuda:0"), H=12, W=16, D=10)
+    assert torch.isfinite(y).all()

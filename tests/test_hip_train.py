@@ -165,7 +165,7 @@ def test_torch_optimizer_also_works():
         loss = terms["loss"].mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < 0.8 * losses[0], losses          # same batch every step: the loss must fall
     with torch.no_grad():                                 # and sampling sees the updated weights
         y = m(x0, t, H=H, W=W, D=D)

@@ -71,3 +71,56 @@ def test_shard_helpers():
             assert sorted(i for p in parts for i in p) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert list(parallel.batches(list(range(5)), 2)) == [[0, 1], [2, 3], [4]]
+
+
+TRAIN_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["S3D_REPO"])
+import numpy as np, torch
+from sin3dm_amd import parallel
+from sin3dm_amd.diffusion.resample import LossSecondMomentResampler
+rank, local, world = parallel.init(backend="gloo")
+# data-parallel step on a toy objective: loss_b = 0.5*|p - x_b|^2, global batch of 4 split 2 / 2
+x = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6) * 0.1
+p = torch.full((6,), float(rank + 1))                  # ranks start different ...
+parallel.broadcast_flat_(p, src=0)                     # ... and are made identical (rank 0's copy)
+mine = x[rank * 2:(rank + 1) * 2]
+g = (p[None] - mine).mean(0)                           # gradient of the LOCAL mean
+parallel.average_flat_(g)                              # -> gradient of the GLOBAL mean
+p -= 0.5 * g
+# the loss-aware timestep sampler sees every rank's (t, loss) pairs in rank order
+class D: num_timesteps = 4
+s = LossSecondMomentResampler(D(), history_per_term=2)
+s.update_with_local_losses(torch.tensor([rank, 3]), torch.tensor([1.0 + rank, 5.0 + rank]))
+out = parallel.gather_objects({"p": p.tolist(), "g": g.tolist(), "counts": s._loss_counts.tolist(), "hist": s._loss_history.tolist()})
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+parallel.barrier()
+"""
+
+
+def test_two_rank_gloo_data_parallel_step(tmp_path):
+    import json
+    import torch
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    # what ONE process with the whole batch of 4 computes
+    x = torch.arange(4 * 6, dtype=torch.float32).reshape(4, 6) * 0.1
+    p = torch.full((6,), 1.0)
+    g = (p[None] - x).mean(0)
+    p = p - 0.5 * g
+    for r in res:
+        assert torch.allclose(torch.tensor(r["g"]), g, atol=1e-6)
+        assert torch.allclose(torch.tensor(r["p"]), p, atol=1e-6)
+        assert r["counts"] == [1, 1, 0, 2]                        # t=0 (rank 0), t=1 (rank 1), t=3 twice
+        assert r["hist"][3] == [5.0, 6.0]                         # rank order
+    assert res[0] == res[1]
