@@ -170,3 +170,32 @@ def test_torch_optimizer_also_works():
     with torch.no_grad():                                 # and sampling sees the updated weights
         y = m(x0, t, H=H, W=W, D=D)
     assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("mc,hwd,B", [(64, (12, 8, 10), 2), (64, (46, 64, 46), 1), (128, (20, 24, 12), 1)])
+def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
+    """Wider models (2 and 4 channels per GroupNorm group, 64-wide MFMA tiles with several K slices) against the
+    CPU oracle's autograd (oracle/torch_port.py, itself pinned to the reference's gradients)."""
+    import torch
+    import torch_port as tp
+    H, W, D = hwd
+    shapes = T.unet_param_shapes(model_channels=mc)
+    m = _model(mc)
+    diffusion = _diffusion()
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 401))
+    t = torch.tensor([700, 3][:B])
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 0).items()}
+    terms_ref, _ = tp.training_losses(sd, x0, t, noise, oracle.schedule_tables_named(1000), H, W, D, model_channels=mc)
+    terms_ref["loss"].mean().backward()
+    terms, g = diffusion.training_losses_and_grads(m, x0.cuda(), t.cuda(), torch.ones(B, device="cuda"), dict(H=H, W=W, D=D),
+                                                   noise=noise.cuda())
+    assert relerr(terms["loss"].cpu().numpy(), terms_ref["loss"].detach().numpy()) < 2e-5
+    gmax = max(float(v.grad.norm()) for v in sd.values())
+    worst = []
+    for name, view in m.split_flat(g).items():
+        ref = sd[name].grad
+        err = float((view.cpu() - ref).norm()) / max(float(ref.norm()), 1e-2 * gmax)
+        worst.append((err, name))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 5e-4, worst[:5]
