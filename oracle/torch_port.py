@@ -134,10 +134,85 @@ def adamw_ema_step(params, grads, m, v, ema, step, lr, wd, ema_rate, b1=0.9, b2=
     """One torch.optim.AdamW step (decoupled decay, bias-corrected) followed by update_ema (src/diffusion/nn.py:55-65),
     in place on lists of tensors; `step` counts from 1."""
     c1, c2 = 1 - b1 ** step, 1 - b2 ** step
-    for p, g, mi, vi, e in zip(params, grads, m, v, ema):
+    for p, g, mi, vi, e in zip(params, grads, m, v, ema if ema else [None] * len(params)):
         p.mul_(1 - lr * wd)
         mi.mul_(b1).add_(g, alpha=1 - b1)
         vi.mul_(b2).addcmul_(g, g, value=1 - b2)
         denom = (vi.sqrt() / math.sqrt(c2)).add_(eps)
         p.addcdiv_(mi, denom, value=-lr / c1)
-        e.mul_(ema_rate).add_(p, alpha=1 - ema_rate)
+        if e is not None:
+            e.mul_(ema_rate).add_(p, alpha=1 - ema_rate)
+
+
+# ---------------------------------------------------------------------------------------------- auto-encoder tier
+def _inorm(x, w=None, b=None, eps=1e-5):
+    return F.instance_norm(x, weight=w, bias=b, eps=eps)
+
+
+def ae_encode(sd, vol, geo_dim=4):
+    """AutoEncoderGroupSkip.encode, src/encoding/networks.py:164-180: Conv3d(k4,s2,p1) -> axis means -> InstanceNorm2d
+    -> tanh(0.5 x).  vol: [1, 1+tex_channels, 2H, 2W, 2D]."""
+    geo = F.conv3d(vol[:, :1], sd["geo_encoder.weight"], sd["geo_encoder.bias"], stride=2, padding=1)
+    tex = F.conv3d(vol, sd["tex_encoder.weight"], sd["tex_encoder.bias"], stride=2, padding=1)
+    f = torch.cat([geo, tex], dim=1)
+    return [(_inorm(f.mean(dim=d)) * 0.5).tanh() for d in (4, 3, 2)]
+
+
+def ae_plane_block(sd, prefix, fm):
+    """TriplaneGroupResnetBlock(ks=5, input_norm=False, input_act=False), src/encoding/blocks.py:189-256: the grouped
+    conv is three independent per-plane convs (rows p*up:(p+1)*up of the weight)."""
+    out = []
+    up = sd[prefix + ".in_layers.0.weight"].shape[0] // 3
+    for p, (name, x) in enumerate(zip(PLANES, fm)):
+        rows = slice(p * up, (p + 1) * up)
+        h = F.conv2d(x, sd[prefix + ".in_layers.0.weight"][rows], sd[prefix + ".in_layers.0.bias"][rows], padding=2)
+        h = _inorm(h, sd[f"{prefix}.norm_{name}.weight"], sd[f"{prefix}.norm_{name}.bias"], eps=1e-6)
+        h = F.conv2d(silu(h), sd[prefix + ".out_layers.1.weight"][rows], sd[prefix + ".out_layers.1.bias"][rows], padding=2)
+        out.append(h + F.conv2d(x, sd[prefix + ".shortcut.weight"][rows], sd[prefix + ".shortcut.bias"][rows]))
+    return out
+
+
+def _mlp(sd, prefix, x, n_hidden_layers=4):
+    """DecoderMLPSkipConcat, src/encoding/blocks.py:65-91."""
+    n = n_hidden_layers // 2
+    h = x
+    for i in range(n + 1):
+        h = F.relu(F.linear(h, sd[f"{prefix}.first_layers.{2 * i}.weight"], sd[f"{prefix}.first_layers.{2 * i}.bias"]))
+    h = torch.cat([x, h], dim=-1)
+    for i in range(n):
+        h = F.relu(F.linear(h, sd[f"{prefix}.second_layers.{2 * i}.weight"], sd[f"{prefix}.second_layers.{2 * i}.bias"]))
+    return F.linear(h, sd[f"{prefix}.second_layers.{2 * n}.weight"], sd[f"{prefix}.second_layers.{2 * n}.bias"])
+
+
+def ae_decode(sd, pts, fm, aabb, geo_dim=4):
+    """AutoEncoderGroupSkip.decode, src/encoding/networks.py:192-220."""
+    x = 2 * (pts - aabb[:3]) / (aabb[3:] - aabb[:3]) - 1
+
+    def sample(plane, xy):
+        g = xy.view(1, 1, -1, 2).flip(-1)
+        return F.grid_sample(plane, g, align_corners=False, padding_mode="border")[0, :, 0, :].transpose(0, 1)
+
+    coords = ([0, 1], [0, 2], [1, 2])
+    geo = ae_plane_block(sd, "geo_convs", [f[:, :geo_dim] for f in fm])
+    tex = ae_plane_block(sd, "tex_convs", [f[:, geo_dim:] for f in fm])
+    h_geo = sum(sample(geo[i], x[..., coords[i]]) for i in range(3))
+    h_tex = sum(sample(tex[i], x[..., coords[i]]) for i in range(3))
+    return torch.cat([_mlp(sd, "geo_decoder", h_geo), _mlp(sd, "tex_decoder", h_tex).sigmoid()], dim=1)
+
+
+def ae_losses(pred, sdf, tex, sdf_threshold, tex_threshold_ratio=0.999, tex_weight=1.0):
+    """ShapeAutoEncoder._forward_batch, src/encoding/model.py:186-237 (weightedl1 sdf loss, l1 texture loss on the
+    points within the truncation band)."""
+    ps = pred[..., :1]
+    weight = 1 + 0.5 * torch.sign(sdf) * torch.sign(sdf - ps)
+    sdf_loss = ((ps - sdf).abs() * weight).mean()
+    mask = sdf.squeeze(1).abs() < sdf_threshold * tex_threshold_ratio
+    tex_loss = F.l1_loss(pred[..., 1:][mask], tex[mask]) * tex_weight
+    return {"sdf_loss": sdf_loss, "tex_loss": tex_loss}
+
+
+def ae_param_groups(names):
+    """geo_parameters / tex_parameters of AutoEncoderGroupSkip (networks.py:146-150) as name lists."""
+    geo = [n for n in names if n.startswith(("geo_encoder", "geo_convs", "geo_decoder"))]
+    tex = [n for n in names if n.startswith(("tex_encoder", "tex_convs", "tex_decoder"))]
+    return geo, tex

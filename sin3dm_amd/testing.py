@@ -89,10 +89,15 @@ def unet_param_shapes(in_channels=12, model_channels=64, out_channels=12, num_re
 
 
 def ae_param_shapes(geo_feat_channels=4, tex_feat_channels=8, feat_channel_up=64,
-                    mlp_hidden_channels=256, mlp_hidden_layers=4, tex_channels=3):
-    """name -> shape for the decode side of AutoEncoderGroupSkip (encoder convs excluded)."""
+                    mlp_hidden_channels=256, mlp_hidden_layers=4, tex_channels=3, with_encoder=False):
+    """name -> shape for AutoEncoderGroupSkip: the decode side, plus the two Conv3d encoders when with_encoder."""
     sh = OrderedDict()
     up, hid = feat_channel_up, mlp_hidden_channels
+    if with_encoder:
+        sh["geo_encoder.weight"] = (geo_feat_channels, 1, 4, 4, 4)
+        sh["geo_encoder.bias"] = (geo_feat_channels,)
+        sh["tex_encoder.weight"] = (tex_feat_channels, tex_channels + 1, 4, 4, 4)
+        sh["tex_encoder.bias"] = (tex_feat_channels,)
 
     def block(prefix, cin):
         sh[prefix + ".in_layers.0.weight"] = (3 * up, cin, 5, 5)

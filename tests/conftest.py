@@ -63,9 +63,10 @@ def digest_errors(named, g, prefix, exclude=()):
     return worst
 
 
-def zero_grad_params(tag="mc32_a"):
-    """Parameters whose gradient is analytically zero (a conv bias feeding a GroupNorm): what AdamW does with their
-    round-off-noise gradients is not comparable between implementations."""
-    g = golden("train_grads")
-    n, names = g[f"{tag}.grad/norm"], g[f"{tag}.grad/names"]
+def zero_grad_params(tag="mc32_a", file="train_grads"):
+    """Parameters whose gradient is analytically zero (a conv bias feeding a Group/InstanceNorm): what AdamW does with
+    their round-off-noise gradients is not comparable between implementations."""
+    g = golden(file)
+    prefix = f"{tag}.grad" if tag else "grad"
+    n, names = g[f"{prefix}/norm"], g[f"{prefix}/names"]
     return {str(k) for k, v in zip(names, n) if v < 1e-6 * float(np.max(n))}

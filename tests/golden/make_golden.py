@@ -388,10 +388,94 @@ def gen_train():
     torch.set_grad_enabled(False)
 
 
+def ae_losses(pred, sdf, tex, sdf_threshold, tex_threshold_ratio=0.999, tex_weight=1.0):
+    """ShapeAutoEncoder._forward_batch with the default sdf_loss="weightedl1", tex_loss="l1", data_type "sdftex",
+    sdf_renorm=0 (src/encoding/model.py:186-237) — restated here because encoding.model does not import without
+    tensorboardX/open3d; the network forward/backward below is the reference's own."""
+    pred_sdf = pred[..., :1]
+    weight = 1 + 0.5 * torch.sign(sdf) * torch.sign(sdf - pred_sdf)
+    sdf_loss = ((pred_sdf - sdf).abs() * weight).mean()
+    mask = sdf.squeeze(1).abs() < sdf_threshold * tex_threshold_ratio
+    tex_loss = torch.nn.functional.l1_loss(pred[..., 1:][mask], tex[mask]) * tex_weight
+    return {"sdf_loss": sdf_loss, "tex_loss": tex_loss}
+
+
+def gen_ae_train():
+    """Auto-encoder stage: encode (networks.py:164-180), forward + losses + backward, and three optimizer steps as
+    ShapeAutoEncoder.train runs them (model.py:129-139, 178-184, 239-258: AdamW with two lr groups + ExponentialLR)."""
+    from encoding.networks import AutoEncoderGroupSkip
+    torch.set_grad_enabled(True)
+    out = {}
+    H, W, D, N = 12, 16, 10, 192
+    shapes = T.ae_param_shapes(with_encoder=True)
+    thr = 0.05
+
+    def make():
+        net = AutoEncoderGroupSkip(4, 8, 64, 256, 4)
+        sd = T.synthetic_state_dict(shapes, 5)
+        missing, unexpected = net.load_state_dict(sd, strict=False)
+        assert not unexpected and missing == ["aabb"], (missing, unexpected)
+        aabb = torch.tensor([-0.7, -1.0, -0.45, 0.7, 1.0, 0.45])
+        net.reset_aabb(aabb)
+        net.train()
+        return net, aabb
+
+    def batch(seed):
+        g = np.random.Generator(np.random.PCG64(seed))
+        aabb = np.asarray([0.7, 1.0, 0.45], np.float32)
+        pts = torch.from_numpy(g.uniform(-1.1, 1.1, size=(N, 3)).astype(np.float32) * aabb)
+        sdf = torch.from_numpy(np.clip(g.normal(0, 0.04, size=(N, 1)), -thr, thr).astype(np.float32))
+        tex = torch.from_numpy(g.uniform(0, 1, size=(N, 3)).astype(np.float32))
+        return pts, sdf, tex
+
+    vol = torch.tanh(rnd((1, 4, 2 * H, 2 * W, 2 * D), 1200))
+    vol[:, 1:] = 0.5 * vol[:, 1:] + 0.5
+    net, aabb = make()
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, aabb = make()
+    fm = net.encode(vol)
+    pts, sdf, tex = batch(1300)
+    pred = net(vol, pts)
+    losses = ae_losses(pred, sdf, tex, thr)
+    net.zero_grad()
+    sum(losses.values()).backward()
+    out["hwdn"] = np.asarray([H, W, D, N])
+    out["aabb"], out["thr"] = aabb, np.asarray(thr)
+    out["pts"], out["sdf"], out["tex"] = pts, sdf, tex
+    out["xy"], out["xz"], out["yz"] = [f.detach() for f in fm]
+    out["pred"] = pred.detach()
+    out["sdf_loss"], out["tex_loss"] = losses["sdf_loss"].detach(), losses["tex_loss"].detach()
+    grad_digest({k: p.grad for k, p in net.named_parameters()}, "grad", out, full_max=512,
+                full_names=("geo_encoder.weight", "tex_encoder.weight", "geo_convs.shortcut.weight", "tex_convs.in_layers.0.weight"))
+
+    # three training iterations: AdamW(two groups: geo lr*split, tex lr; default weight_decay 0.01) + ExponentialLR
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, aabb = make()
+    lr, split, decay = 5e-3, 0.2, 0.1 ** (1 / 10)
+    opt = torch.optim.AdamW([{"params": net.geo_parameters(), "lr": lr * split}, {"params": net.tex_parameters(), "lr": lr}], lr)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, decay)
+    init = {k: p.detach().clone() for k, p in net.named_parameters()}
+    ls = []
+    for step in range(3):
+        pts, sdf, tex = batch(1400 + step)
+        pred = net(vol, pts)
+        losses = ae_losses(pred, sdf, tex, thr)
+        opt.zero_grad()
+        sum(losses.values()).backward()
+        opt.step()
+        sched.step()
+        ls.append([float(losses["sdf_loss"]), float(losses["tex_loss"])])
+    out["steps.losses"] = np.asarray(ls)
+    out["steps.hyper"] = np.asarray([lr, split, decay])
+    grad_digest({k: p.detach() - init[k] for k, p in net.named_parameters()}, "steps.dparam", out, full_max=64)
+    save("ae_train", **out)
+    torch.set_grad_enabled(False)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
-                     ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train)):
+                     ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train), ("ae_train", gen_ae_train)):
         if not only or name in only:
             fn()

@@ -242,3 +242,53 @@ def test_torch_port_optimizer_steps(oracle, wd_tag):
     # Adam turns a near-zero gradient element into a +-lr step: single elements may flip, the L2 error stays small
     assert wp["norm"] < 1e-3 and wp["proj"] < 2e-3 and wp["full_l2"] < 5e-3, wp
     assert we["norm"] < 1e-3 and we["proj"] < 2e-3, we
+
+
+def test_torch_port_ae_training(oracle):
+    """auto-encoder tier oracle: encode, forward, losses, every gradient and three AdamW/ExponentialLR steps against
+    the reference's AutoEncoderGroupSkip under autograd."""
+    import torch
+    import torch_port as tp
+    g = golden("ae_train")
+    H, W, D, N = (int(v) for v in g["hwdn"])
+    shapes = T.ae_param_shapes(with_encoder=True)
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 5).items()}
+    vol = torch.tanh(torch.from_numpy(T.synthetic_noise((1, 4, 2 * H, 2 * W, 2 * D), 1200)))
+    vol[:, 1:] = 0.5 * vol[:, 1:] + 0.5
+    aabb, thr = torch.from_numpy(g["aabb"]), float(g["thr"])
+    fm = tp.ae_encode(sd, vol)
+    for f, k in zip(fm, ("xy", "xz", "yz")):
+        assert relerr(f.detach().numpy(), g[k]) < 1e-5
+    pts, sdf, tex = (torch.from_numpy(g[k]) for k in ("pts", "sdf", "tex"))
+    pred = tp.ae_decode(sd, pts, fm, aabb)
+    assert relerr(pred.detach().numpy(), g["pred"]) < 1e-5
+    losses = tp.ae_losses(pred, sdf, tex, thr)
+    assert abs(float(losses["sdf_loss"]) - float(g["sdf_loss"])) < 1e-6 and abs(float(losses["tex_loss"]) - float(g["tex_loss"])) < 1e-6
+    sum(losses.values()).backward()
+    w = digest_errors({k: v.grad.numpy() for k, v in sd.items()}, g, "grad")
+    assert w["norm"] < 1e-4 and w["proj"] < 2e-4 and w["full"] < 2e-4, w
+    # three steps: AdamW (weight_decay 0.01 = torch default), lr groups geo = lr*split / tex = lr, ExponentialLR
+    lr, split, decay = (float(v) for v in g["steps.hyper"])
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 5).items()}
+    init = {k: v.detach().clone() for k, v in sd.items()}
+    geo, tex_names = tp.ae_param_groups(list(sd))
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+    for step in range(3):
+        rng = np.random.Generator(np.random.PCG64(1400 + step))
+        ext = np.asarray([0.7, 1.0, 0.45], np.float32)
+        p = torch.from_numpy(rng.uniform(-1.1, 1.1, size=(N, 3)).astype(np.float32) * ext)
+        s = torch.from_numpy(np.clip(rng.normal(0, 0.04, size=(N, 1)), -thr, thr).astype(np.float32))
+        c = torch.from_numpy(rng.uniform(0, 1, size=(N, 3)).astype(np.float32))
+        for v in sd.values():
+            v.grad = None
+        ls = tp.ae_losses(tp.ae_decode(sd, p, tp.ae_encode(sd, vol), aabb), s, c, thr)
+        assert abs(float(ls["sdf_loss"]) - g["steps.losses"][step][0]) < 2e-5
+        sum(ls.values()).backward()
+        with torch.no_grad():
+            for names, glr in ((geo, lr * split), (tex_names, lr)):
+                tp.adamw_ema_step([sd[k] for k in names], [sd[k].grad for k in names], [state[k][0] for k in names],
+                                  [state[k][1] for k in names], [], step + 1, glr * decay ** step, 0.01, 0.0)
+    skip = zero_grad_params(None, "ae_train")
+    assert skip == {"geo_convs.in_layers.0.bias", "tex_convs.in_layers.0.bias", "geo_encoder.bias", "tex_encoder.bias"}  # feed an InstanceNorm
+    wp = digest_errors({k: (sd[k].detach() - init[k]).numpy() for k in sd}, g, "steps.dparam", skip)
+    assert wp["norm"] < 2e-3 and wp["proj"] < 1e-2, wp
