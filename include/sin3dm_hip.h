@@ -213,6 +213,42 @@ S3D_API int s3d_train_adamw_ema(float* params, const float* grads, float* exp_av
                                 const float* ema_rates, int n_ema, int64_t numel, float lr, float beta1, float beta2,
                                 float eps, float weight_decay, int step, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Auto-encoder training tier: AutoEncoderGroupSkip encode / decode / losses and their
+ * gradients (src/encoding/networks.py:122-220, src/encoding/model.py:178-237).  Reuses s3d_decoder_cfg.
+ * Parameters: one caller-owned flat fp32 device vector, tensors in s3d_ae_param_info() order and PyTorch layouts:
+ * [geo_encoder, geo_convs, geo_decoder | tex_encoder, tex_convs, tex_decoder] — the two halves are the reference's two
+ * AdamW parameter groups (networks.py:146-150); use s3d_train_adamw_ema on each half with its learning rate.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct s3d_ae s3d_ae;
+typedef struct {
+    int32_t sdf_loss;            /* 0 = l1, 1 = weightedl1 (default) */
+    int32_t tex_loss;            /* 0 = l1 (default), 1 = l2, 2 = huber(delta 0.1) */
+    float sdf_threshold;         /* truncation of the sdf samples */
+    float tex_threshold_ratio;   /* texture loss on points with |sdf| < sdf_threshold * ratio (0.999) */
+    float tex_weight;            /* 1.0 */
+} s3d_ae_loss_cfg;
+
+S3D_API int s3d_ae_create(const s3d_decoder_cfg* cfg, s3d_ae** out);
+S3D_API void s3d_ae_destroy(s3d_ae* a);
+S3D_API int s3d_ae_num_params(const s3d_ae* a);
+S3D_API int s3d_ae_param_info(const s3d_ae* a, int i, const char** name, int64_t shape[5], int* ndim, int64_t* offset);
+/* total floats; *tex_group_begin = first float of the tex_* parameter group */
+S3D_API int64_t s3d_ae_param_numel(const s3d_ae* a, int64_t* tex_group_begin);
+S3D_API int s3d_ae_attach(s3d_ae* a, float* params, int64_t numel);
+S3D_API int s3d_ae_repack(s3d_ae* a, void* stream);              /* after every change of the attached vector */
+/* The training volume [1,C,2H,2W,2D] (device, C = 1 + tex_channels: sdf, texture): reduced once to the three
+ * projections the encoder needs; the volume itself is not kept. */
+S3D_API int s3d_ae_set_volume(s3d_ae* a, const float* vol, int C, int X2, int Y2, int Z2, void* stream);
+/* net.encode(vol): xy [1,Cg+Ct,H,W], xz [1,Cg+Ct,H,D], yz [1,Cg+Ct,W,D] */
+S3D_API int s3d_ae_encode(s3d_ae* a, float* xy, float* xz, float* yz, void* stream);
+/* net(vol, pts): pred [N, 1+tex_channels] (texture through the sigmoid) */
+S3D_API int s3d_ae_forward(s3d_ae* a, const float* pts, int64_t N, const float aabb[6], float* pred, void* stream);
+/* _forward_batch + backward: losses[2] = {sdf_loss, tex_loss} (device), pred optional, grads = d(sdf_loss+tex_loss)/d params
+ * (every element overwritten).  pts [N,3], sdf [N,1], tex [N,tex_channels] device. */
+S3D_API int s3d_ae_loss_grads(s3d_ae* a, const float* pts, const float* sdf, const float* tex, int64_t N, const float aabb[6],
+                              const s3d_ae_loss_cfg* cfg, float* losses, float* pred, float* grads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,11 @@ class Profile(C.Structure):
                 ("forwards", C.c_int64)]
 
 
+class AeLossCfg(C.Structure):
+    _fields_ = [("sdf_loss", C.c_int32), ("tex_loss", C.c_int32), ("sdf_threshold", C.c_float),
+                ("tex_threshold_ratio", C.c_float), ("tex_weight", C.c_float)]
+
+
 class DecoderCfg(C.Structure):
     _fields_ = [("geo_feat_channels", C.c_int32), ("tex_feat_channels", C.c_int32), ("feat_channel_up", C.c_int32),
                 ("mlp_hidden_channels", C.c_int32), ("mlp_hidden_layers", C.c_int32), ("tex_channels", C.c_int32)]
@@ -80,6 +85,19 @@ SIGNATURES = {
                                             C.c_void_p]),
     "s3d_decoder_grid_dims": (C.c_int, [c_fp, C.c_int, C.POINTER(C.c_int)]),
     "s3d_decoder_decode_grid": (C.c_int, [C.c_void_p, C.c_int, c_fp, C.c_void_p, C.c_void_p]),
+    # auto-encoder training tier
+    "s3d_ae_create": (C.c_int, [C.POINTER(DecoderCfg), C.POINTER(C.c_void_p)]),
+    "s3d_ae_destroy": (None, [C.c_void_p]),
+    "s3d_ae_num_params": (C.c_int, [C.c_void_p]),
+    "s3d_ae_param_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), c_i64p, C.POINTER(C.c_int), c_i64p]),
+    "s3d_ae_param_numel": (C.c_int64, [C.c_void_p, c_i64p]),
+    "s3d_ae_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "s3d_ae_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "s3d_ae_set_volume": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "s3d_ae_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "s3d_ae_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, c_fp, C.c_void_p, C.c_void_p]),
+    "s3d_ae_loss_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, c_fp, C.POINTER(AeLossCfg),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     # training tier
     "s3d_unet_param_numel": (C.c_int64, [C.c_void_p]),
     "s3d_unet_param_offset": (C.c_int, [C.c_void_p, C.c_int, c_i64p]),

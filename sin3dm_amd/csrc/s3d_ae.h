@@ -1,0 +1,51 @@
+// s3d_ae.h — launchers of the auto-encoder training tier (s3d_ae_kernels.hip, s3d_decoder.hip) used by s3d_ae.hip.
+#pragma once
+#include "s3d_common.h"
+
+namespace s3d {
+
+// the input volume reduced to three 2-D projections (see s3d_ae_kernels.hip): P[p] [2h][2w][4 taps][C]
+struct EncDesc {
+    const float* P[3];
+    Geo g;                 // feature-map plane sizes (h, w per plane)
+    float inv_len[3];      // 1 / length of the averaged axis (D, W, H)
+    int C, CO;             // input channels of the volume, encoder feature channels (geo + tex)
+};
+int launch_project(const float* vol, int C, int X2, int Y2, int Z2, float* const P[3], hipStream_t st);
+int launch_enc_pack(const float* wgeo, const float* wtex, int geo, int tex, int C, float* Wp, hipStream_t st);
+int launch_enc_fwd(const EncDesc& e, const float* Wp, const float* bias, float* const pre[3], hipStream_t st);
+int launch_enc_norm(bool backward, float* const x[3], float* const y[3], float* mr, float* const dy[3], float* const dx[3],
+                    const Geo& g, int CO, hipStream_t st);
+size_t enc_wgrad_ws_floats(int C, int CO);
+int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, float* ws, float* dwgeo, float* dbgeo, float* dwtex,
+                     float* dbtex, hipStream_t st);
+
+int launch_slice_pad_nhwc(const float* in, float* out, long long hw, int CT, int c0, int cin, hipStream_t st);
+int launch_unslice_nhwc(const float* dx, float* dfeat, long long hw, int CT, int c0, int cin, hipStream_t st);
+int launch_mr_from_partials(const double* part, int nchunks, int C, double count, float eps, float* mr, hipStream_t st);
+// InstanceNorm2d(affine, eps) + SiLU of one NHWC plane (s3d_decoder.hip); part: kInNormChunks*C*2 doubles
+constexpr int kInNormChunks = 64;
+int launch_inorm_silu(const float* x, double* part, const float* gamma, const float* beta, float* y, int hw, int C, float eps,
+                      hipStream_t st);
+
+struct PointSet { const float* pts; long long N, Np; float aabb[6]; };   // Np = N rounded up to the GEMM row tile
+int launch_gather(const PointSet& ps, const float* const feat[2][3], const int ph[3], const int pw[3], int C, int nnets,
+                  float* const X[2], hipStream_t st);
+int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
+                   const float* const dX[2], hipStream_t st);
+
+int launch_relu(float* x, long long n, hipStream_t st);
+int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, hipStream_t st);
+int launch_add_slice(const float* a, const float* b, int bstride, int coff, float* out, long long rows, int C, hipStream_t st);
+size_t colsum_ws_floats(int C);
+int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st);
+int launch_last_fwd(const float* h, const float* W, const float* b, int I, int O, int sigm, float* pred, int pstride, int ooff,
+                    long long N, hipStream_t st);
+size_t last_bwd_ws_floats(int I, int O);
+int launch_last_bwd(const float* dout, int dstride, int ooff, const float* W, const float* h, int I, int O, long long Np, float* dh,
+                    float* ws, float* dW, float* db, hipStream_t st);
+// losses[3] = {sdf_loss, tex_loss, #points inside the texture band}; dout [Np][1+TC] or null; ws: 192 floats
+int launch_ae_loss(const float* pred, const float* sdf, const float* tex, long long N, long long Np, int TC, int sdf_mode, int tex_mode,
+                   float band, float tex_weight, float* ws, float* losses, float* dout, hipStream_t st);
+
+}  // namespace s3d

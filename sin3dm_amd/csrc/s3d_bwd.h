@@ -24,6 +24,8 @@ struct WgradArgs {
     float* part[3];    // split-K partials, wgrad_part_floats() each
     float* dW[3];      // OIHW [cout][ctot][taps]; own channels [0, cin) are written
     int B, cin, cout, ctot, taps, ksplit;
+    int cin_store = 0;   // > 0: only input channels [0, cin_store) are written (the rest are zero padding of `a`)
+    int nplanes = 3;     // jobs actually present in dy/a/part/dW
 };
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout);
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps);
@@ -39,6 +41,7 @@ struct GnActBwd {
     const float* film; float* dfilm; int film_stride;
     float* ws;                                                // gn_bwd_ws_floats(B, C)
     int B;
+    int ngroups = 32;                                         // GroupNorm32; C for an InstanceNorm
 };
 size_t gn_bwd_ws_floats(int B, int C);
 int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st);

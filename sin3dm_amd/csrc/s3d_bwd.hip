@@ -204,27 +204,28 @@ constexpr int WG_TR = 4, WG_TC = 16;                 // pixel tile
 // times the blocks and a third of the accumulators, for layers too small to fill the chip otherwise)
 template <int TAPS, int TROWS>
 struct WgSmem {
-    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int KW = TAPS == 25 ? 5 : (TAPS == 9 ? 3 : 1), HALO = KW / 2;
     static constexpr int AR = WG_TR + (TROWS == 3 ? 2 * HALO : 0), AC = WG_TC + 2 * HALO;
     float dy[2][WG_TR * WG_TC][32];
     float a[2][AR * AC][32];
 };
 struct WgJob { const float* dy; const float* a; float* part; int h, w, tiles_x, tiles; int block_begin; };
-struct WgArgs { WgJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci; };
+struct WgArgs { WgJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci, njobs; };
 
 template <int TAPS, int TROWS>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
     using SM = WgSmem<TAPS, TROWS>;
     __shared__ __attribute__((aligned(16))) SM sm;
-    constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = TAPS == 9 ? 3 : 1;
-    constexpr int NT = TAPS == 9 ? 3 * TROWS : 1;                     // taps of this block
+    constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = SM::KW;
+    static_assert(TROWS == 1 || TAPS == 9, "all kernel rows in one block only for 3x3");
+    constexpr int NT = TAPS == 1 ? 1 : KW * TROWS;                    // taps of this block
     constexpr int NDY = (2 * WG_TR * WG_TC * 8) / 256, NA = (2 * AR * AC * 8 + 255) / 256;
     int p = 0;
-    while (p < 2 && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
+    while (p + 1 < args.njobs && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
     const WgJob& J = args.job[p];
     int local = blockIdx.x - J.block_begin;
     int dr0 = 0;
-    if (TAPS == 9 && TROWS == 1) { dr0 = local % 3; local /= 3; }
+    if (TAPS > 1 && TROWS == 1) { dr0 = local % KW; local /= KW; }
     const int ks = local % args.ksplit; local /= args.ksplit;
     const int tci = local % args.n_ci, tco = local / args.n_ci;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, kk = lane >> 5;
@@ -303,13 +304,13 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = ci0 + wn * 32 + i;
-        float* d = part + (size_t(co) * args.cin + ci) * TAPS + (TAPS == 9 ? dr0 * 3 : 0);
+        float* d = part + (size_t(co) * args.cin + ci) * TAPS + dr0 * KW;
 #pragma unroll
         for (int t = 0; t < NT; ++t) d[t] = acc[t][r];
     }
 }
 
-struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps; };
+struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
 __global__ void k_wgrad_reduce(WgRedArgs a) {
     const long long n = (long long)a.cout * a.cin * a.taps;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,7 +321,7 @@ __global__ void k_wgrad_reduce(WgRedArgs a) {
     const int t = int(idx % a.taps);
     const long long r = idx / a.taps;
     const int ci = int(r % a.cin), co = int(r / a.cin);
-    a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
+    if (ci < a.cin_store) a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
 }
 
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout) {
@@ -335,31 +336,35 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout) {
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
 int launch_wgrad(const WgradArgs& w, hipStream_t st) {
-    S3D_CHECK(w.taps == 9 || w.taps == 1, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
+    S3D_CHECK(w.taps == 9 || w.taps == 1 || w.taps == 25, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
     S3D_CHECK(w.cin % 32 == 0 && w.cout % 32 == 0, S3D_ERR_INVALID, "wgrad: channels must be multiples of 32");
     WgArgs a;
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
     a.n_co = cdiv(w.cout, 64); a.n_ci = cdiv(w.cin, 64);
     // small layers: one kernel row per block (3x the blocks, a third of the registers -> more waves per SIMD)
-    const bool split_rows = w.taps == 9 && a.n_co * a.n_ci * a.ksplit * 3 < 768;
+    const bool split_rows = w.taps == 25 || (w.taps == 9 && a.n_co * a.n_ci * a.ksplit * 3 < 768);
+    const int row_blocks = w.taps == 25 ? 5 : 3;
     int blocks = 0;
-    for (int p = 0; p < 3; ++p) {
+    a.njobs = w.nplanes;
+    for (int p = 0; p < w.nplanes; ++p) {
         WgJob& J = a.job[p];
         J.dy = w.dy.p[p]; J.a = w.a.p[p]; J.part = w.part[p]; J.h = w.dy.g.h[p]; J.w = w.dy.g.w[p];
         J.tiles_x = cdiv(J.w, WG_TC); J.tiles = J.tiles_x * cdiv(J.h, WG_TR);
         J.block_begin = blocks;
-        blocks += a.n_co * a.n_ci * a.ksplit * (split_rows ? 3 : 1);
+        blocks += a.n_co * a.n_ci * a.ksplit * (split_rows ? row_blocks : 1);
     }
     if (!blocks || !w.B) return 0;
-    if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1>), dim3(blocks), dim3(256), 0, st, a);
+    if (w.taps == 25) hipLaunchKernelGGL((k_wgrad_mfma<25, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1>), dim3(blocks), dim3(256), 0, st, a);
     else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 3>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_mfma<1, 1>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     WgRedArgs r;
-    for (int p = 0; p < 3; ++p) { r.part[p] = w.part[p]; r.dW[p] = w.dW[p]; }
+    for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
     r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.taps = w.taps;
+    r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin;
     const long long n = (long long)w.cout * w.cin * w.taps;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256), 3), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256), w.nplanes), dim3(256), 0, st, r);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -382,13 +387,13 @@ struct GnBwdArgs {
     float* part;                                          // [B][3][nchunk][C][2]
     const float* coef;                                    // [B][3][C][2] = {mean_grp(g*dz), mean_grp(g*dz*xh)}
     int h[3], w[3];
-    int C, cq, pl, B, nchunk;
+    int C, cq, pl, B, nchunk, ngroups;
 };
 constexpr int kGnBwdChunks = 64;
 struct GnChan { float mean, rstd, gam, bet, sc, sh; };
 __device__ __forceinline__ GnChan gn_chan(const GnBwdArgs& a, int p, int b, int ch) {
-    const int cg = a.C / 32;
-    const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + ch / cg) * 2;
+    const int cg = a.C / a.ngroups;
+    const float* mr = a.mr + ((size_t(b) * 3 + p) * a.ngroups + ch / cg) * 2;
     GnChan c;
     c.mean = mr[0]; c.rstd = mr[1]; c.gam = a.gamma[p][ch]; c.bet = a.beta[p][ch];
     c.sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
@@ -457,7 +462,7 @@ struct GnBwdFinArgs {
     float* dgamma[3]; float* dbeta[3];
     const float* film; float* dfilm; int film_stride;    // dfilm [B][film_stride]: dscale at [0,C), dshift at [C,2C)
     double count[3];
-    int C, B, nchunk;
+    int C, B, nchunk, ngroups;
 };
 __global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over B*3*C
@@ -471,10 +476,10 @@ __global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
     a.A[size_t(idx) * 2] = float(s1); a.A[size_t(idx) * 2 + 1] = float(s2);
 }
 __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
-    const int C = a.C, cg = C / 32;
+    const int C = a.C, G = a.ngroups, cg = C / G;
     // (1) group coefficients
-    for (int idx = threadIdx.x; idx < a.B * 3 * 32; idx += blockDim.x) {
-        const int g = idx % 32, bp = idx / 32, b = bp / 3, p = bp % 3;
+    for (int idx = threadIdx.x; idx < a.B * 3 * G; idx += blockDim.x) {
+        const int g = idx % G, bp = idx / G, b = bp / 3, p = bp % 3;
         double g1 = 0, g2 = 0;
         for (int k = 0; k < cg; ++k) {
             const int ch = g * cg + k;
@@ -559,7 +564,8 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
         begin[p + 1] = begin[p] + (long long)x.g.h[p] * x.g.w[p] * a.cq;
     }
     a.mr = s.stats.mr; a.film = s.film; a.film_stride = s.film_stride;
-    a.B = s.B; a.nchunk = kGnBwdChunks;
+    a.B = s.B; a.nchunk = kGnBwdChunks; a.ngroups = s.ngroups;
+    S3D_CHECK(s.ngroups >= 1 && x.C % s.ngroups == 0, S3D_ERR_INVALID, "gn_act_bwd: %d groups for %d channels", s.ngroups, x.C);
     float* part = s.ws;
     float* A = part + size_t(s.B) * 3 * kGnBwdChunks * x.C * 2;
     float* coef = A + size_t(s.B) * 3 * x.C * 2;
@@ -571,9 +577,9 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride;
     for (int p = 0; p < 3; ++p) {
         f.gamma[p] = s.gamma[p]; f.beta[p] = s.beta[p]; f.dgamma[p] = s.dgamma[p]; f.dbeta[p] = s.dbeta[p];
-        f.count[p] = double(x.C / 32) * x.g.h[p] * x.g.w[p];
+        f.count[p] = double(x.C / s.ngroups) * x.g.h[p] * x.g.w[p];
     }
-    f.C = x.C; f.B = s.B; f.nchunk = kGnBwdChunks;
+    f.C = x.C; f.B = s.B; f.nchunk = kGnBwdChunks; f.ngroups = s.ngroups;
     hipLaunchKernelGGL(k_gn_bwd_sum, dim3(cdiv(s.B * 3 * x.C, 256)), dim3(256), 0, st, f);
     S3D_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_gn_bwd_coefs, dim3(1), dim3(1024), 0, st, f);

@@ -20,7 +20,7 @@
 #include <cmath>
 #include <memory>
 
-#include "s3d_common.h"
+#include "s3d_ae.h"
 
 namespace s3d {
 
@@ -89,6 +89,17 @@ __global__ void k_inorm_silu(const float* __restrict__ x, const double* __restri
         o.x = o.x / (1.f + expf(-o.x)); o.y = o.y / (1.f + expf(-o.y)); o.z = o.z / (1.f + expf(-o.z)); o.w = o.w / (1.f + expf(-o.w));
         reinterpret_cast<float4*>(y)[i] = o;
     }
+}
+
+int launch_inorm_silu(const float* x, double* part, const float* gamma, const float* beta, float* y, int hw, int C, float eps,
+                      hipStream_t st) {
+    static_assert(kInNormChunks == kInChunks, "chunk count");
+    const int cq = C / 4, pl = std::max(1, 256 / cq);
+    hipLaunchKernelGGL(k_chan_partials, dim3(kInChunks), dim3(cq * pl), size_t(pl) * C * 2 * sizeof(double), st, x, part, hw, C);
+    hipLaunchKernelGGL(k_inorm_silu, dim3(std::min(1024, (hw * cq + 255) / 256)), dim3(256), size_t(2) * C * sizeof(float), st, x, part,
+                       gamma, beta, y, hw, C, eps);
+    S3D_HIP(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------ fused gather + MLP

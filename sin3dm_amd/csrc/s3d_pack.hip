@@ -9,7 +9,6 @@
 
 namespace s3d {
 
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_RANK1, PK_RANK1_BWD };
 
 __device__ __forceinline__ bool var_tap(int var, int o) {
     // taps of the summed-out axis that stay inside the image, by edge variant (0 interior, 1 first, 2 last, 3 single)
@@ -47,6 +46,18 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             const int co = int(i % cout); long long r = i / cout;
             const int c = int(r % cin), t = int(r / cin);
             dst[i] = W[((size_t)co * ctot + c) * taps + (taps - 1 - t)];
+            break;
+        }
+        case PK_DENSE_PAD: {                     // like PK_DENSE with the input channels zero-padded to d.slot per row
+            const int c = int(i % cin); long long r = i / cin;
+            const int co = int(r % cout), t = int(r / cout);
+            dst[((size_t)t * cout + co) * d.slot + c] = W[((size_t)co * ctot + c) * taps + t];
+            break;
+        }
+        case PK_DENSE_T_PAD: {                   // like PK_DENSE_T with the (transposed operator's) outputs padded to d.slot
+            const int co = int(i % cout); long long r = i / cout;
+            const int c = int(r % cin), t = int(r / cin);
+            dst[((size_t)t * d.slot + c) * cout + co] = W[((size_t)co * ctot + c) * taps + (taps - 1 - t)];
             break;
         }
         case PK_WINO:
@@ -209,6 +220,13 @@ int build_pack_plan(s3d_unet* m) {
     S3D_TRY(m->tbuf.reserve(std::max<size_t>(P.tsize, 64) * sizeof(float)));
     S3D_HIP(hipMemset(m->tbuf.p, 0, P.tsize * sizeof(float)));       // the Winograd images are zero-padded to 32 outputs
     S3D_TRY(upload(m->descs_dev, m->descs.data(), m->descs.size() * sizeof(PackDesc)));
+    return 0;
+}
+
+int launch_repack_generic(const PackDesc* descs_dev, int ndesc, int blocks, const float* flat, float* wbuf, float* tbuf, hipStream_t st) {
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(k_repack, dim3(blocks), dim3(256), 0, st, descs_dev, ndesc, flat, wbuf, tbuf);
+    S3D_HIP(hipGetLastError());
     return 0;
 }
 

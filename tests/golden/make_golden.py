@@ -420,6 +420,25 @@ def gen_ae_train():
         net.train()
         return net, aabb
 
+    def relu_margin(net, vol, pts):
+        """smallest |pre-activation| over the hidden ReLUs of both MLPs and their gradient-carrying inputs: a batch whose
+        margin is at round-off level has an ill-defined gradient (relu'(0+-eps)) and cannot pin an implementation"""
+        margins = []
+        hooks = [m.register_forward_hook(lambda mod, i, o: margins.append(float(i[0].abs().min())))
+                 for m in net.modules() if isinstance(m, torch.nn.ReLU)]
+        with torch.no_grad():
+            net(vol, pts)
+        for h in hooks:
+            h.remove()
+        return min(margins)
+
+    def pick_batch(net, vol, seed0):
+        for seed in range(seed0, seed0 + 50):
+            b = batch(seed)
+            if relu_margin(net, vol, b[0]) > 2e-6:          # ~10x the fp32 differences between implementations
+                return seed, b
+        raise RuntimeError("no well-conditioned batch found")
+
     def batch(seed):
         g = np.random.Generator(np.random.PCG64(seed))
         aabb = np.asarray([0.7, 1.0, 0.45], np.float32)
@@ -434,7 +453,8 @@ def gen_ae_train():
     with contextlib.redirect_stdout(io.StringIO()):
         net, aabb = make()
     fm = net.encode(vol)
-    pts, sdf, tex = batch(1300)
+    seed, (pts, sdf, tex) = pick_batch(net, vol, 1300)
+    out["seed"] = np.asarray(seed)
     pred = net(vol, pts)
     losses = ae_losses(pred, sdf, tex, thr)
     net.zero_grad()
@@ -455,9 +475,10 @@ def gen_ae_train():
     opt = torch.optim.AdamW([{"params": net.geo_parameters(), "lr": lr * split}, {"params": net.tex_parameters(), "lr": lr}], lr)
     sched = torch.optim.lr_scheduler.ExponentialLR(opt, decay)
     init = {k: p.detach().clone() for k, p in net.named_parameters()}
-    ls = []
+    ls, seeds = [], []
     for step in range(3):
-        pts, sdf, tex = batch(1400 + step)
+        seed, (pts, sdf, tex) = pick_batch(net, vol, 1400 + 50 * step)
+        seeds.append(seed)
         pred = net(vol, pts)
         losses = ae_losses(pred, sdf, tex, thr)
         opt.zero_grad()
@@ -466,6 +487,7 @@ def gen_ae_train():
         sched.step()
         ls.append([float(losses["sdf_loss"]), float(losses["tex_loss"])])
     out["steps.losses"] = np.asarray(ls)
+    out["steps.seeds"] = np.asarray(seeds)
     out["steps.hyper"] = np.asarray([lr, split, decay])
     grad_digest({k: p.detach() - init[k] for k, p in net.named_parameters()}, "steps.dparam", out, full_max=64)
     save("ae_train", **out)

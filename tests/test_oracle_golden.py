@@ -274,7 +274,7 @@ def test_torch_port_ae_training(oracle):
     geo, tex_names = tp.ae_param_groups(list(sd))
     state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
     for step in range(3):
-        rng = np.random.Generator(np.random.PCG64(1400 + step))
+        rng = np.random.Generator(np.random.PCG64(int(g["steps.seeds"][step])))
         ext = np.asarray([0.7, 1.0, 0.45], np.float32)
         p = torch.from_numpy(rng.uniform(-1.1, 1.1, size=(N, 3)).astype(np.float32) * ext)
         s = torch.from_numpy(np.clip(rng.normal(0, 0.04, size=(N, 1)), -thr, thr).astype(np.float32))
