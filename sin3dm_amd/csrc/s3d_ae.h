@@ -35,7 +35,9 @@ int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3]
                    const float* const dX[2], hipStream_t st);
 
 int launch_relu(float* x, long long n, hipStream_t st);
-int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, hipStream_t st);
+// dpre = dact[:, coff:coff+C] * (act > 0) and colsum[C] = its column sums (ws: colsum_ws_floats(C))
+int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,
+                    float* colsum, hipStream_t st);
 int launch_add_slice(const float* a, const float* b, int bstride, int coff, float* out, long long rows, int C, hipStream_t st);
 size_t colsum_ws_floats(int C);
 int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st);

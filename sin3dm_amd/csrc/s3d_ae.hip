@@ -150,10 +150,10 @@ struct AeRun {
     float* G(size_t off) const { return grads ? grads + off : reinterpret_cast<float*>(uintptr_t(256)); }
 
     int conv(ConvKind kind, int cin, int cout, const Geo& g, float* const in[3], const float* const wgt[3], const float* const bias[3],
-             float* const res[3], float* const out[3], int njobs = 3) {
+             float* const res[3], float* const out[3], int njobs = 3, bool relu = false) {
         if (meas()) return 0;
         ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = 1; ca.cin = cin; ca.cout = cout; ca.njobs = njobs;
+        ca.B = 1; ca.cin = cin; ca.cout = cout; ca.njobs = njobs; ca.relu = relu ? 1 : 0;
         for (int p = 0; p < njobs; ++p) {
             ConvJob& J = ca.job[p];
             J.in = in[p]; J.wgt = wgt[p]; J.bias = bias ? bias[p] : nullptr; J.res = res ? res[p] : nullptr; J.out = out[p];
@@ -167,7 +167,7 @@ struct AeRun {
         w.dy.C = cout; w.a.C = a_cstride; w.dy.g = w.a.g = g;
         for (int p = 0; p < 3; ++p) { w.dy.p[p] = p < nplanes ? dy[p] : nullptr; w.a.p[p] = p < nplanes ? act[p] : nullptr; }
         w.B = 1; w.cin = cin; w.cout = cout; w.ctot = cin_store; w.taps = taps; w.cin_store = cin_store; w.nplanes = nplanes;
-        w.ksplit = wgrad_ksplit(g, 1, cin, cout);
+        w.ksplit = wgrad_ksplit(g, 1, cin, cout, taps);
         for (int p = 0; p < nplanes; ++p) { w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps)); w.dW[p] = dW[p]; }
         if (meas()) return 0;
         return launch_wgrad(w, st);
@@ -247,9 +247,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         const float *w[3], *b[3];
         float *i3[3], *o3[3];
         for (int n = 0; n < 2; ++n) { w[n] = R.F(a->net[n].f_mw[l]); b[n] = R.F(a->net[n].f_mb[l]); i3[n] = in[n]; o3[n] = out[n]; }
-        S3D_TRY(R.conv(CONV_1x1, a->net[0].I[l], a->net[0].O[l], gp, i3, w, b, nullptr, o3, 2));
-        if (!meas) for (int n = 0; n < 2; ++n) S3D_TRY(launch_relu(out[n], Np * a->net[n].O[l], st));
-        return 0;
+        return R.conv(CONV_1x1, a->net[0].I[l], a->net[0].O[l], gp, i3, w, b, nullptr, o3, 2, /*relu=*/true);
     };
     if (!meas) {
         const float* fp[2][3];
@@ -306,10 +304,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
                                {0, H[n][0], X0[n], up, dXa, dH, hid, 0}};
         for (const Step& s : steps) {
             const int I = N_.I[s.l], O = N_.O[s.l];
-            if (!meas) {
-                S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, st));
-                S3D_TRY(launch_colsum(dP, Np, O, cws, R.G(N_.f_mb[s.l]), st));
-            }
+            if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws, R.G(N_.f_mb[s.l]), st));
             Geo g1; for (int p = 0; p < 3; ++p) { g1.h[p] = p == 0 ? int(Np / 64) : 0; g1.w[p] = p == 0 ? 64 : 0; }
             float* dy3[3] = {dP, nullptr, nullptr}; float* a3[3] = {s.in, nullptr, nullptr}; float* dw3[3] = {R.G(N_.f_mw[s.l]), nullptr, nullptr};
             S3D_TRY(R.wgrad(1, I, I, O, g1, dy3, s.in_stride, a3, dw3, 1));

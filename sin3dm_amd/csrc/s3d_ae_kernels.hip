@@ -180,7 +180,7 @@ int launch_enc_norm(bool backward, float* const x[3], float* const y[3], float* 
 // Stage 1: block = (pixel chunk, plane), thread = j (16*4*C = 256 for C = 4), CO accumulators per thread.
 // Stage 2 (k_enc_wgrad_reduce): add chunks in order, un-permute the taps, add the three planes, write Conv3d layouts.
 constexpr int kEncChunks = 64, kEncMaxCO = 12;
-struct EncWgArgs { const float* P[3]; const float* dpre[3]; float* part; int h[3], w[3]; int C, CO, J; };
+struct EncWgArgs { const float* P[3]; const float* dpre[3]; float* part; float* bpart; int h[3], w[3]; int C, CO, J; };
 __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
     __shared__ float sd[kEncMaxCO];
     const int chunk = blockIdx.x, p = blockIdx.y;
@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
     float acc[kEncMaxCO];
 #pragma unroll
     for (int c = 0; c < kEncMaxCO; ++c) acc[c] = 0.f;
+    float bsum = 0.f;                                        // threads < CO: sum of dpre over the chunk (bias gradient)
     for (int i = p0; i < p1; ++i) {
         __syncthreads();
-        if (int(threadIdx.x) < CO) sd[threadIdx.x] = a.dpre[p][size_t(i) * CO + threadIdx.x];
+        if (int(threadIdx.x) < CO) { sd[threadIdx.x] = a.dpre[p][size_t(i) * CO + threadIdx.x]; bsum += sd[threadIdx.x]; }
         __syncthreads();
         const int x = i / w, y = i % w, X = 2 * x + ka - 1, Y = 2 * y + kb - 1;
         if (!active || X < 0 || X >= 2 * h || Y < 0 || Y >= 2 * w) continue;
@@ -202,12 +203,13 @@ __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
 #pragma unroll
         for (int c = 0; c < kEncMaxCO; ++c) if (c < CO) acc[c] = fmaf(sd[c], v, acc[c]);
     }
+    if (blockIdx.z == 0 && int(threadIdx.x) < CO) a.bpart[(size_t(p) * kEncChunks + chunk) * CO + threadIdx.x] = bsum;
     if (!active) return;
     float* o = a.part + ((size_t(p) * kEncChunks + chunk) * CO) * a.J + j;
 #pragma unroll
     for (int c = 0; c < kEncMaxCO; ++c) if (c < CO) o[size_t(c) * a.J] = acc[c];
 }
-struct EncWgRedArgs { const float* part; const float* dpre[3]; float* dwgeo; float* dwtex; float* dbgeo; float* dbtex; float inv_len[3]; int hw[3]; int geo, tex, C, J; };
+struct EncWgRedArgs { const float* part; const float* bpart; float* dwgeo; float* dwtex; float* dbgeo; float* dbtex; float inv_len[3]; int hw[3]; int geo, tex, C, J; };
 __global__ void k_enc_wgrad_reduce(EncWgRedArgs a) {
     const int CO = a.geo + a.tex, C = a.C;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over CO * C * 64 Conv3d weight elements, then CO biases
@@ -226,22 +228,23 @@ __global__ void k_enc_wgrad_reduce(EncWgRedArgs a) {
     } else if (idx < CO * C * 64 + CO) {
         const int co = idx - CO * C * 64;
         double tot = 0;
-        for (int p = 0; p < 3; ++p) for (int i = 0; i < a.hw[p]; ++i) tot += a.dpre[p][size_t(i) * CO + co];
+        for (int p = 0; p < 3; ++p) for (int k = 0; k < kEncChunks; ++k) tot += a.bpart[(size_t(p) * kEncChunks + k) * CO + co];
         if (co < a.geo) a.dbgeo[co] = float(tot); else a.dbtex[co - a.geo] = float(tot);
     }
 }
-size_t enc_wgrad_ws_floats(int C, int CO) { return size_t(3) * kEncChunks * CO * 16 * 4 * C; }
+size_t enc_wgrad_ws_floats(int C, int CO) { return size_t(3) * kEncChunks * CO * (16 * 4 * C + 1); }
 int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, float* ws, float* dwgeo, float* dbgeo, float* dwtex,
                      float* dbtex, hipStream_t st) {
     S3D_CHECK(e.CO <= kEncMaxCO, S3D_ERR_UNSUPPORTED, "encoder: %d feature channels (max %d)", e.CO, kEncMaxCO);
     EncWgArgs a;
     a.part = ws; a.C = e.C; a.CO = e.CO; a.J = 16 * 4 * e.C;
+    a.bpart = ws + size_t(3) * kEncChunks * e.CO * a.J;
     for (int p = 0; p < 3; ++p) { a.P[p] = e.P[p]; a.dpre[p] = dpre[p]; a.h[p] = e.g.h[p]; a.w[p] = e.g.w[p]; }
     hipLaunchKernelGGL(k_enc_wgrad, dim3(kEncChunks, 3, cdiv(a.J, 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     EncWgRedArgs r;
-    r.part = ws; r.dwgeo = dwgeo; r.dwtex = dwtex; r.dbgeo = dbgeo; r.dbtex = dbtex; r.geo = geo; r.tex = tex; r.C = e.C; r.J = a.J;
-    for (int p = 0; p < 3; ++p) { r.dpre[p] = dpre[p]; r.inv_len[p] = e.inv_len[p]; r.hw[p] = e.g.h[p] * e.g.w[p]; }
+    r.part = ws; r.bpart = a.bpart; r.dwgeo = dwgeo; r.dwtex = dwtex; r.dbgeo = dbgeo; r.dbtex = dbtex; r.geo = geo; r.tex = tex; r.C = e.C; r.J = a.J;
+    for (int p = 0; p < 3; ++p) { r.inv_len[p] = e.inv_len[p]; r.hw[p] = e.g.h[p] * e.g.w[p]; }
     hipLaunchKernelGGL(k_enc_wgrad_reduce, dim3(cdiv(e.CO * e.C * 64 + e.CO, 256)), dim3(256), 0, st, r);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -396,18 +399,47 @@ int launch_relu(float* x, long long n, hipStream_t st) {
     S3D_HIP(hipGetLastError());
     return 0;
 }
-// dpre[n][c] = dact[n][coff + c] * (act[n][c] > 0)   (dact row stride dstride)
-__global__ void k_relu_bwd(const float* __restrict__ dact, int dstride, int coff, const float* __restrict__ act, float* __restrict__ dpre,
-                           long long rows, int C) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * C) return;
-    const int c = int(i % C);
-    const long long n = i / C;
-    dpre[i] = act[i] > 0.f ? dact[n * dstride + coff + c] : 0.f;
+// dpre[n][c] = dact[n][coff + c] * (act[n][c] > 0)   (dact row stride dstride), and the column sums of dpre (the bias
+// gradient) in the same pass: per-chunk partials here, added in chunk order by k_colsum_fin
+constexpr int kColChunks = 256;
+__global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dact, int dstride, int coff, const float* __restrict__ act,
+                                                  float* __restrict__ dpre, long long rows, int C, float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float sm_rb[];      // [pl][C]
+    const int cq = C / 4, pl = blockDim.x / cq;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const long long r0 = rows * blockIdx.x / kColChunks, r1 = rows * (blockIdx.x + 1) / kColChunks;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (long long n = r0 + l; n < r1; n += pl) {
+        const float4 a = reinterpret_cast<const float4*>(act)[n * cq + q];
+        const float4 d = *reinterpret_cast<const float4*>(dact + n * dstride + coff + 4 * q);
+        float4 o;
+        o.x = a.x > 0.f ? d.x : 0.f; o.y = a.y > 0.f ? d.y : 0.f; o.z = a.z > 0.f ? d.z : 0.f; o.w = a.w > 0.f ? d.w : 0.f;
+        reinterpret_cast<float4*>(dpre)[n * cq + q] = o;
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    reinterpret_cast<float4*>(sm_rb)[l * cq + q] = s;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int ll = 0; ll < pl; ++ll) t += sm_rb[ll * C + c];
+        part[size_t(blockIdx.x) * C + c] = t;
+    }
 }
-int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, hipStream_t st) {
+__global__ void k_colsum_fin(const float* __restrict__ part, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0;
+    for (int k = 0; k < kColChunks; ++k) s += part[size_t(k) * C + c];
+    out[c] = float(s);
+}
+int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,
+                    float* colsum, hipStream_t st) {
     if (!rows) return 0;
-    hipLaunchKernelGGL(k_relu_bwd, dim3(cdivll(rows * C, 256)), dim3(256), 0, st, dact, dstride, coff, act, dpre, rows, C);
+    S3D_CHECK(C % 4 == 0 && C <= 1024 && dstride % 4 == 0 && coff % 4 == 0, S3D_ERR_INVALID, "relu_bwd: C=%d stride=%d off=%d", C, dstride, coff);
+    const int cq = C / 4, pl = std::max(1, 256 / cq);
+    hipLaunchKernelGGL(k_relu_bwd, dim3(kColChunks), dim3(cq * pl), size_t(pl) * C * sizeof(float), st, dact, dstride, coff, act, dpre, rows, C, ws);
+    S3D_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(64), 0, st, ws, colsum, C);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -425,7 +457,6 @@ int launch_add_slice(const float* a, const float* b, int bstride, int coff, floa
     return 0;
 }
 // column sums of a [rows][C] matrix (bias gradients): two-stage, fixed order
-constexpr int kColChunks = 128;
 __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x, float* __restrict__ part, long long rows, int C) {
     const long long r0 = rows * blockIdx.x / kColChunks, r1 = rows * (blockIdx.x + 1) / kColChunks;
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -433,13 +464,6 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
         for (long long r = r0; r < r1; ++r) s += x[r * C + c];
         part[size_t(blockIdx.x) * C + c] = s;
     }
-}
-__global__ void k_colsum_fin(const float* __restrict__ part, float* __restrict__ out, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0;
-    for (int k = 0; k < kColChunks; ++k) s += part[size_t(k) * C + c];
-    out[c] = float(s);
 }
 size_t colsum_ws_floats(int C) { return size_t(kColChunks) * C; }
 int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st) {
@@ -478,7 +502,7 @@ int launch_last_fwd(const float* h, const float* W, const float* b, int I, int O
 }
 // backward: dh[n][i] = sum_o dout[n][o] * W[o][i] ; dW[o][i] = sum_n dout[n][o] * h[n][i] ; db[o] = sum_n dout[n][o]
 // dout [Np][4-wide rows: column ooff + o]; rows >= N carry zero.  dW/db: per-chunk partials then ordered sum.
-constexpr int kLastChunks = 128;
+constexpr int kLastChunks = 512;
 __global__ __launch_bounds__(256) void k_last_bwd(const float* __restrict__ dout, int dstride, int ooff, const float* __restrict__ W,
                                                   const float* __restrict__ h, int I, int O, long long Np, float* __restrict__ dh,
                                                   float* __restrict__ part) {

@@ -27,7 +27,7 @@ struct WgradArgs {
     int cin_store = 0;   // > 0: only input channels [0, cin_store) are written (the rest are zero padding of `a`)
     int nplanes = 3;     // jobs actually present in dy/a/part/dW
 };
-int wgrad_ksplit(const Geo& g, int B, int cin, int cout);
+int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps);
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps);
 int launch_wgrad(const WgradArgs& w, hipStream_t st);
 

@@ -202,24 +202,28 @@ int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
 constexpr int WG_TR = 4, WG_TC = 16;                 // pixel tile
 // TAPS: 9 (3x3) or 1; TROWS: kernel rows handled by one block (3 = all nine taps, 1 = one row of three taps: three
 // times the blocks and a third of the accumulators, for layers too small to fill the chip otherwise)
-template <int TAPS, int TROWS>
+template <int TAPS, int TROWS, int WT>
 struct WgSmem {
     static constexpr int KW = TAPS == 25 ? 5 : (TAPS == 9 ? 3 : 1), HALO = KW / 2;
     static constexpr int AR = WG_TR + (TROWS == 3 ? 2 * HALO : 0), AC = WG_TC + 2 * HALO;
-    float dy[2][WG_TR * WG_TC][32];
-    float a[2][AR * AC][32];
+    float dy[2 * WT][WG_TR * WG_TC][32];
+    float a[2 * WT][AR * AC][32];
 };
 struct WgJob { const float* dy; const float* a; float* part; int h, w, tiles_x, tiles; int block_begin; };
 struct WgArgs { WgJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci, njobs; };
 
-template <int TAPS, int TROWS>
+// WT: 32x32 MFMA tiles per wave in each direction (block tile = 64*WT co x 64*WT ci).  The 1x1 case (the decoder MLPs'
+// weight gradients, K = 65 536 points) uses WT = 2: with a single tap every staged element feeds only one MFMA per
+// output tile, so the larger block tile halves the staging traffic per flop.
+template <int TAPS, int TROWS, int WT>
 __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
-    using SM = WgSmem<TAPS, TROWS>;
+    using SM = WgSmem<TAPS, TROWS, WT>;
     __shared__ __attribute__((aligned(16))) SM sm;
-    constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = SM::KW;
+    constexpr int HALO = SM::HALO, AR = SM::AR, AC = SM::AC, KW = SM::KW, NP = 2 * WT, BT = 64 * WT;
     static_assert(TROWS == 1 || TAPS == 9, "all kernel rows in one block only for 3x3");
+    static_assert(WT == 1 || TAPS == 1, "wide tiles only for 1x1");
     constexpr int NT = TAPS == 1 ? 1 : KW * TROWS;                    // taps of this block
-    constexpr int NDY = (2 * WG_TR * WG_TC * 8) / 256, NA = (2 * AR * AC * 8 + 255) / 256;
+    constexpr int NDY = (NP * WG_TR * WG_TC * 8) / 256, NA = (NP * AR * AC * 8 + 255) / 256;
     int p = 0;
     while (p + 1 < args.njobs && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
     const WgJob& J = args.job[p];
@@ -230,13 +234,16 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
     const int tci = local % args.n_ci, tco = local / args.n_ci;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, kk = lane >> 5;
     const int wm = wid >> 1, wn = wid & 1;
-    const int co0 = tco * 64, ci0 = tci * 64;
-    const bool wave_on = co0 + wm * 32 < args.cout && ci0 + wn * 32 < args.cin;
-    f32x16 acc[NT];
+    const int co0 = tco * BT, ci0 = tci * BT;
+    f32x16 acc[NT][WT][WT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int m = 0; m < WT; ++m)
+#pragma unroll
+            for (int n = 0; n < WT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][m][n][r] = 0.f;
 
     const long long total = (long long)J.tiles * args.B;
     const long long t_begin = total * ks / args.ksplit, t_end = total * (ks + 1) / args.ksplit;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
             const int it = k * 256 + tid;
             const int q = it & 7, px = (it >> 3) % (AR * AC), pan = it / (8 * AR * AC);
             const int r = r0 + arow0 + px / AC, c = c0 - HALO + px % AC, ch = ci0 + pan * 32 + q * 4;
-            const bool ok = pan < 2 && r >= 0 && r < J.h && c >= 0 && c < J.w && ch < args.cin;
+            const bool ok = pan < NP && r >= 0 && r < J.h && c >= 0 && c < J.w && ch < args.cin;
             ra[k] = ok ? *reinterpret_cast<const float4*>(J.a + ((size_t(b) * J.h + r) * J.w + c) * args.a_cstride + ch) : make_float4(0, 0, 0, 0);
         }
     };
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
         for (int k = 0; k < NA; ++k) {
             const int it = k * 256 + tid;
             const int q = it & 7, px = (it >> 3) % (AR * AC), pan = it / (8 * AR * AC);
-            if (pan < 2) *reinterpret_cast<float4*>(&sm.a[pan][px][q * 4]) = ra[k];
+            if (pan < NP) *reinterpret_cast<float4*>(&sm.a[pan][px][q * 4]) = ra[k];
         }
     };
     if (t_begin < t_end) load_tile(t_begin);
@@ -284,30 +291,39 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
         __syncthreads();
         if (tt + 1 < t_end) load_tile(tt + 1);            // in flight while the matrix cores work on this tile
         __builtin_amdgcn_sched_barrier(0);
-        if (!wave_on) continue;
 #pragma unroll
         for (int r = 0; r < WG_TR; ++r)
 #pragma unroll 2
             for (int c = 0; c < WG_TC; c += 2) {
-                const float av = sm.dy[wm][r * WG_TC + c + kk][i];
+                float av[WT];
+#pragma unroll
+                for (int m = 0; m < WT; ++m) av[m] = sm.dy[wm * WT + m][r * WG_TC + c + kk][i];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int dr = TROWS == 3 ? t / KW : 0, dc = t % KW;
-                    const float bv = sm.a[wn][(r + dr) * AC + c + kk + dc][i];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < WT; ++n) {
+                        const float bv = sm.a[wn * WT + n][(r + dr) * AC + c + kk + dc][i];
+#pragma unroll
+                        for (int m = 0; m < WT; ++m) acc[t][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[t][m][n], 0, 0, 0);
+                    }
                 }
             }
     }
-    if (!wave_on) return;
     // partial [ks][co][ci][TAPS]
     float* part = J.part + size_t(ks) * args.cout * args.cin * TAPS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = ci0 + wn * 32 + i;
-        float* d = part + (size_t(co) * args.cin + ci) * TAPS + dr0 * KW;
+    for (int m = 0; m < WT; ++m)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) d[t] = acc[t][r];
-    }
+        for (int n = 0; n < WT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * WT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk, ci = ci0 + (wn * WT + n) * 32 + i;
+                if (co >= args.cout || ci >= args.cin) continue;
+                float* d = part + (size_t(co) * args.cin + ci) * TAPS + dr0 * KW;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) d[t] = acc[t][m][n][r];
+            }
 }
 
 struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
@@ -324,12 +340,14 @@ __global__ void k_wgrad_reduce(WgRedArgs a) {
     if (ci < a.cin_store) a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
 }
 
-int wgrad_ksplit(const Geo& g, int B, int cin, int cout) {
+int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     long long tiles = 0;
-    for (int p = 0; p < 3; ++p) tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC);
-    const long long base = (long long)cdiv(cout, 64) * cdiv(cin, 64) * 3;
+    int planes = 0;
+    for (int p = 0; p < 3; ++p) { tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC); planes += g.h[p] > 0; }
+    const int bt = taps == 1 ? 128 : 64;
+    const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1);
     long long ks = (512 + base - 1) / base;                          // aim for ~2 blocks per CU ...
-    const long long per_plane = std::max<long long>(1, tiles * B / 3);
+    const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
     return int(std::min<long long>(ks, 64));                         // ... but bound the partial-sum traffic
 }
@@ -340,7 +358,8 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     S3D_CHECK(w.cin % 32 == 0 && w.cout % 32 == 0, S3D_ERR_INVALID, "wgrad: channels must be multiples of 32");
     WgArgs a;
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
-    a.n_co = cdiv(w.cout, 64); a.n_ci = cdiv(w.cin, 64);
+    const int bt = w.taps == 1 ? 128 : 64;                           // block tile (see WT)
+    a.n_co = cdiv(w.cout, bt); a.n_ci = cdiv(w.cin, bt);
     // small layers: one kernel row per block (3x the blocks, a third of the registers -> more waves per SIMD)
     const bool split_rows = w.taps == 25 || (w.taps == 9 && a.n_co * a.n_ci * a.ksplit * 3 < 768);
     const int row_blocks = w.taps == 25 ? 5 : 3;
@@ -354,10 +373,10 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
         blocks += a.n_co * a.n_ci * a.ksplit * (split_rows ? row_blocks : 1);
     }
     if (!blocks || !w.B) return 0;
-    if (w.taps == 25) hipLaunchKernelGGL((k_wgrad_mfma<25, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 3>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad_mfma<1, 1>), dim3(blocks), dim3(256), 0, st, a);
+    if (w.taps == 25) hipLaunchKernelGGL((k_wgrad_mfma<25, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 3, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     WgRedArgs r;
     for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }

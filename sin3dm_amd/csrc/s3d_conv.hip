@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
 #pragma unroll
                 for (int ks = 1; ks < KS; ++ks) v += acc[ks][mt][nt][r];
                 v += addv[mt][r];
+                if (args.relu) v = fmaxf(v, 0.f);
                 if (ok[mt][r]) {
                     p_out[oidx[mt][r]] = v;
                     gs += v; gss = fmaf(v, v, gss);
@@ -296,6 +297,7 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
             if (J.rcol) v += J.rcol[((size_t(b) * J.w + x) * 4 + edge_variant(y, J.h)) * args.cout + co];
             if (J.rrow) v += J.rrow[((size_t(b) * J.h + y) * 4 + edge_variant(x, J.w)) * args.cout + co];
             if (J.res) v += J.res[i];
+            if (args.relu) v = fmaxf(v, 0.f);
             J.out[i] = v;
         }
     }

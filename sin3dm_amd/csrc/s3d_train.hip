@@ -110,7 +110,7 @@ struct Bwd {
         // (3) dense weight gradient of the own channels
         WgradArgs w;
         w.dy = dy; w.a = a; w.B = B; w.cin = cin; w.cout = cout; w.ctot = cw.rollout ? 3 * cin : cin; w.taps = taps;
-        w.ksplit = wgrad_ksplit(g, B, cin, cout);
+        w.ksplit = wgrad_ksplit(g, B, cin, cout, taps);
         for (int p = 0; p < 3; ++p) {
             w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps));
             w.dW[p] = dW[p];

@@ -1,14 +1,16 @@
-"""Training CLI with the reference's flags and on-disk layout (src/train.py) — diffusion stage.
+"""Training CLI with the reference's flags and on-disk layout (src/train.py): auto-encoder stage, then diffusion stage.
 
-    python -m sin3dm_amd.train --tag EXP --enc_log PATH/TO/encoding [--diff_batch_size 32 --diff_n_iters 25000 ...]
-    python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.train --tag EXP --enc_log ... --diff_batch_size 4
+    python -m sin3dm_amd.train --tag EXP --data_path shape.npz [--only_enc] [--enc_n_iters 25000 --diff_n_iters 25000 ...]
+    python -m sin3dm_amd.train --tag EXP --enc_log PATH/TO/encoding            # reuse an existing encoding
+    python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.train --tag EXP --data_path ... --diff_batch_size 4
 
-Reads <enc_log>/{args.json,feat.npz} (the triplane latent written by the reference's auto-encoder stage), trains the
-triplane diffusion UNet on the MI355X (sin3dm_amd/diffusion/train_util.py) and writes EXP/diffusion/{args.json,
+Stage 1 (src/train.py:8-29): ShapeAutoEncoder.train on the preprocessed shape, then EXP/encoding/{args.json, feat.npz,
+model/ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it, the others wait.
+Stage 2 (:32-75): the triplane diffusion UNet (sin3dm_amd/diffusion/train_util.py) -> EXP/diffusion/{args.json,
 ema_<rate>_<step>.pt, opt<step>.pt, progress.jsonl} — the files sample.py of either implementation reads.
-Multi-GPU: --diff_batch_size is PER GPU (the reference's 32 = 8 x 4); gradients are averaged with one all-reduce
-per step.  The auto-encoder stage (src/train.py:8-29, ShapeAutoEncoder.train) is the next tier:
-without --enc_log this CLI stops with a message instead of training it.
+Multi-GPU: --diff_batch_size is PER GPU (the reference's 32 = 8 x 4); gradients are averaged with one all-reduce per
+step.  The reference's reconstruction mesh export after stage 1 (decode_texmesh: PyMCubes/xatlas/nvdiffrast) is out of
+scope.
 """
 from __future__ import annotations
 
@@ -17,7 +19,22 @@ import os
 from . import parallel
 from .utils import dist_util
 from .utils.common_util import seed_all
-from .utils.parser_util import diffusion_log_dir, encoding_feat_path, train_args
+from .utils.parser_util import diffusion_log_dir, encoding_feat_path, encoding_log_dir, train_args
+
+
+def train_ae(args):
+    """Reference: src/train.py:8-29."""
+    from .encoding.model import ShapeAutoEncoder
+    from .utils.triplane_util import save_triplane_data
+
+    print("[Training autoencoder]")
+    assert args.data_path is not None
+    ae = ShapeAutoEncoder(encoding_log_dir(args.tag), args, device=dist_util.dev())
+    ae.train(args.data_path)
+    fm = ae.encode()
+    print("feat maps shape:", [tuple(f.shape) for f in fm])
+    fm = [f.squeeze(0).detach().cpu().numpy() for f in fm]
+    save_triplane_data(encoding_feat_path(args.tag), fm[0], fm[1], fm[2])
 
 
 def train_diffusion(args, rank=0):
@@ -51,11 +68,12 @@ def main(argv=None, confirm=input):
     seed_all(0 + rank)                               # per-rank timestep / noise streams; weights are broadcast from rank 0
     dist_util.setup_dist(local if world > 1 else args.gpu_id)
     parallel.init(device=dist_util.dev())
-    if args.only_enc or args.enc_log is None:
-        raise NotImplementedError(
-            "the auto-encoder stage (ShapeAutoEncoder.train) is not implemented on this path yet (SURVEY.md §8f rank 3): "
-            "train it with the reference and pass its folder as --enc_log")
-    train_diffusion(args, rank)
+    if args.enc_log is None:
+        if rank == 0:
+            train_ae(args)
+        parallel.barrier()
+    if not args.only_enc:
+        train_diffusion(args, rank)
     parallel.barrier()
 
 
