@@ -84,3 +84,30 @@ def test_train_cli_then_sample(tmp_path):
     with torch.no_grad():
         y = model(torch.randn(1, 12, 22, 26, device="cuda:0"), torch.tensor([10], device="cuda:0"), H=12, W=16, D=10)
     assert torch.isfinite(y).all()
+
+
+def test_train_cli_autoencoder_stage(tmp_path):
+    """train.py --only_enc on a synthetic preprocessed shape: writes the encoding/ folder sample.py and the diffusion
+    stage read (args.json, feat.npz, model/ckpt_final.pth)."""
+    from sin3dm_amd import train
+    from sin3dm_amd.utils import parser_util as pu
+    R = (16, 24, 12)
+    ext = np.asarray([0.6, 0.9, 0.45])
+    ax = [np.linspace(-1, 1, r) * s for r, s in zip(R, ext)]
+    grid = np.stack(np.meshgrid(*ax, indexing="ij"), -1).astype(np.float32)
+    f = lambda p: ((np.linalg.norm(p / ext, axis=-1) - 0.6) * 0.3).astype(np.float32)
+    c = lambda p: (0.5 + 0.5 * np.sin(3 * p)).astype(np.float32)
+    near = (np.random.Generator(np.random.PCG64(4)).uniform(-1, 1, size=(3000, 3)) * ext).astype(np.float32)
+    data = str(tmp_path / "shape.npz")
+    np.savez(data, aabb=np.concatenate([-ext, ext]).astype(np.float32), threshold=0.05, pts_grid=grid, sdf_grid=f(grid), tex_grid=c(grid),
+             pts_near_surf=near, sdf_near_surf=f(near), tex_near_surf=c(near), pts_on_surf=near[:300], tex_on_surf=c(near[:300]))
+    tag = str(tmp_path / "run")
+    train.main(["--tag", tag, "--data_path", data, "--only_enc", "--fm_reso", "24", "--enc_n_iters", "30", "--enc_batch_size", "1024"],
+               confirm=lambda _: "y")
+    enc = pu.encoding_log_dir(tag)
+    assert os.path.exists(os.path.join(enc, "args.json")) and os.path.exists(os.path.join(enc, "model", "ckpt_final.pth"))
+    d = np.load(pu.encoding_feat_path(tag))
+    assert d["feat_xy"].shape == (12, 16, 24) and d["feat_xz"].shape == (12, 16, 12) and d["feat_yz"].shape == (12, 24, 12)
+    assert all(np.isfinite(d[k]).all() and np.abs(d[k]).max() <= 1.0 for k in d.files)          # tanh range
+    ck = torch.load(os.path.join(enc, "model", "ckpt_final.pth"), weights_only=False)
+    assert ck["featmap_size"] == [16, 24, 12] and set(ck["net"]) >= {"geo_encoder.weight", "tex_decoder.second_layers.4.bias", "aabb"}
