@@ -129,3 +129,41 @@ def test_train_loop_reduces_the_loss(tmp_path):
     fm = ae.encode()
     a = ae.decode_batch(fm, ae.pts_grid[:777]); b = ae2.decode_batch(fm, ae.pts_grid[:777])
     assert torch.equal(a, b)
+
+
+def test_full_size_directional_derivative():
+    """128^3 feature maps, 65 536 points (the training configuration): gradient vs a central finite difference of
+    sdf_loss + tex_loss along a random direction of the smooth (non-bias-before-norm) parameters."""
+    import torch
+    H = W = D = 128
+    N = 65536
+    net = _net()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    vol = torch.rand((1, 4, 2 * H, 2 * W, 2 * D), device="cuda", generator=g)
+    vol[:, :1] = vol[:, :1] * 0.2 - 0.1
+    pts = torch.rand((N, 3), device="cuda", generator=g) * 2 - 1
+    sdf = torch.rand((N, 1), device="cuda", generator=g) * 0.1 - 0.05
+    tex = torch.rand((N, 3), device="cuda", generator=g)
+    cfg = _loss_cfg(0.05)
+    flat = net.flat_parameters
+
+    def loss_and_grad():
+        losses, _, grad = net.loss_and_grads(vol, pts, sdf, tex, cfg)
+        return float(losses.double().sum()), grad
+
+    L0, grad = loss_and_grad()
+    grad = grad.clone()
+    assert torch.isfinite(grad).all()
+    r = torch.randn(flat.shape, device="cuda", generator=g)
+    v = grad / grad.norm() + r / r.norm()                      # half along the gradient, half random
+    gv = float((grad.double() * v.double()).sum())
+    eps = 1e-3 * L0 / abs(gv)                                  # small (0.1 % of the loss): the L1 losses and ReLUs have kinks
+    base = flat.clone()
+    vals = []
+    for s in (+1.0, -1.0):
+        flat.copy_(base + s * eps * v)
+        net.mark_parameters_changed()
+        vals.append(loss_and_grad()[0])
+    flat.copy_(base); net.mark_parameters_changed()
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gv) < 5e-2 * abs(gv), (fd, gv, L0, eps)

@@ -199,3 +199,40 @@ def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
         worst.append((err, name))
     worst.sort(reverse=True)
     assert worst[0][0] < 5e-4, worst[:5]
+
+
+def test_full_size_directional_derivative():
+    """BASELINE config 4 per GPU (64-ch UNet, towerruins (92,128,92), batch 2 here): the gradient of the whole step agrees
+    with a central finite difference of the loss along a random parameter direction — a size-independent check that
+    needs no reference output."""
+    import torch
+    mc, (H, W, D), B = 64, (92, 128, 92), 2
+    m = _model(mc)
+    diffusion = _diffusion()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x0 = torch.rand((B, 12, H + D, W + D), device="cuda", generator=g) * 2 - 1
+    noise = torch.randn((B, 12, H + D, W + D), device="cuda", generator=g)
+    t = torch.tensor([650, 40], device="cuda")
+    w = torch.ones(B, device="cuda")
+    kw = dict(H=H, W=W, D=D)
+    flat = m.flat_parameters
+
+    def loss_and_grad():
+        terms, grad = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+        return float(terms["loss"].double().mean()), grad
+
+    L0, grad = loss_and_grad()
+    grad = grad.clone()
+    r = torch.randn(flat.shape, device="cuda", generator=g)
+    v = grad / grad.norm() + r / r.norm()                      # half along the gradient, half random
+    gv = float((grad.double() * v.double()).sum())
+    eps = 2e-3 * L0 / abs(gv)                                  # moves the loss by ~0.2 %
+    base = flat.clone()
+    vals = []
+    for s in (+1.0, -1.0):
+        flat.copy_(base + s * eps * v)
+        m.mark_parameters_changed()
+        vals.append(loss_and_grad()[0])
+    flat.copy_(base); m.mark_parameters_changed()
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - gv) < 2e-2 * abs(gv), (fd, gv, L0, eps)
