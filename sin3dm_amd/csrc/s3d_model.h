@@ -85,6 +85,8 @@ struct s3d_unet {
     std::vector<ResBlockW> in_blocks, out_blocks;
 
     Arena arena;
+    long long inf_key[4] = {-1, -1, -1, -1};             // (B,H,W,D) of the last measured inference forward ...
+    size_t inf_high = 0;                                 // ... and the workspace it needs
 
     // training tier: caller-owned flat master parameters (reference layouts, specs order, tightly packed), the
     // device-side repack plan and the activation tape of the last forward_train

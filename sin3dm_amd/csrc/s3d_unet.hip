@@ -345,15 +345,23 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
     if (!m->packed) S3D_TRY(pack_all(m));
     m->tape.valid = false;                    // the workspace is shared with the training tape
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows)
-    m->arena.measuring = true;
-    m->arena.high = 0;
-    int rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
-    m->arena.measuring = false;
-    if (rc) return rc;
-    if (m->arena.high > m->arena.buf.cap) {
-        S3D_HIP(hipStreamSynchronize(st));
-        S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+    // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows).  The walk is pure host
+    // work and depends only on the shapes: skipped when they repeat (every step of a sampling loop).
+    const long long key[4] = {B, H, W, D};
+    const bool same = m->inf_key[0] == key[0] && m->inf_key[1] == key[1] && m->inf_key[2] == key[2] && m->inf_key[3] == key[3];
+    int rc = 0;
+    if (!same || m->inf_high > m->arena.buf.cap) {
+        m->arena.measuring = true;
+        m->arena.high = 0;
+        rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
+        m->arena.measuring = false;
+        if (rc) return rc;
+        m->inf_high = m->arena.high;
+        for (int k = 0; k < 4; ++k) m->inf_key[k] = key[k];
+        if (m->arena.high > m->arena.buf.cap) {
+            S3D_HIP(hipStreamSynchronize(st));
+            S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+        }
     }
     m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
     ++m->fwd_count;

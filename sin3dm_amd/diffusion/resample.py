@@ -27,7 +27,11 @@ class ScheduleSampler:
         p = w / np.sum(w)
         idx = np.random.choice(len(p), size=(batch_size,), p=p)
         weights = 1 / (len(p) * p[idx])
-        return th.from_numpy(idx).long().to(device), th.from_numpy(weights).float().to(device)
+        t, w = th.from_numpy(idx).long(), th.from_numpy(weights).float()
+        if th.device(device).type == "cuda":
+            # pinned + non_blocking: a pageable host-to-device copy would drain the GPU queue in every training step
+            return t.pin_memory().to(device, non_blocking=True), w.pin_memory().to(device, non_blocking=True)
+        return t.to(device), w.to(device)
 
 
 class UniformSampler(ScheduleSampler):

@@ -61,7 +61,11 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        # the device copy of the timestep map is shared by all wrappers of this diffusion: building it per step would be
+        # a pageable host-to-device copy, i.e. a host/GPU synchronisation in every denoising step
+        if not hasattr(self, "_map_cache"):
+            self._map_cache = {}
+        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, self._map_cache)
 
     def _step(self, mode, model, *args, **kwargs):
         return super()._step(mode, self._wrap_model(model), *args, **kwargs)
@@ -73,12 +77,12 @@ class SpacedDiffusion(GaussianDiffusion):
 class _WrappedModel:
     """Maps respaced indices back to original ones before calling the denoiser (:116-128)."""
 
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps, map_cache=None):
         self.model = model
         self.timestep_map = timestep_map
         self.rescale_timesteps = rescale_timesteps
         self.original_num_steps = original_num_steps
-        self._maps = {}
+        self._maps = map_cache if map_cache is not None else {}
 
     def parameters(self):
         return self.model.parameters()

@@ -67,6 +67,7 @@ class _TriplaneUNetBase(nn.Module):
 
         self._handle = None
         self._synced = None
+        self._plist = None
         self._flat = None           # training: flat master parameters on the device (see _ensure_flat)
         self._flat_layout = None    # [(name, offset, numel, shape)]
         self._flat_dirty = False
@@ -105,18 +106,25 @@ class _TriplaneUNetBase(nn.Module):
             cfg = self._cfg()
             _lib.check(lib.s3d_unet_create(C.byref(cfg), C.byref(h)))
             self._handle = h
-        params = dict(self.named_parameters())
-        stamp = tuple((p.data_ptr(), p._version) for p in params.values())
+        # cheap change detection (this runs in every denoising step): in-place updates bump ._version, and anything that
+        # re-homes the tensors (.to / .cuda / .float) goes through _apply below, which drops the cached state
+        if self._plist is None:
+            named = dict(self.named_parameters())
+            self._plist = [named[n] for n in self._param_names]
+        stamp = tuple(p._version for p in self._plist)
         if self._flat is not None:
-            if self._flat_intact(params):
-                if stamp != self._synced or self._flat_dirty:      # parameters changed on the device: repack there
-                    with th.cuda.device(self._flat.device):
-                        _lib.check(lib.s3d_unet_repack(self._handle, _lib.stream_ptr()))
-                    self._synced, self._flat_dirty = stamp, False
-                return lib
-            self._flat = None                                       # .to(...) re-homed the parameters: start over
-            self._synced = None
+            if stamp != self._synced or self._flat_dirty:          # parameters changed on the device: repack there
+                params = dict(self.named_parameters())
+                if not self._flat_intact(params):                   # somebody re-assigned .data: start over
+                    self._flat = None
+                    self._synced = None
+                    return self._ensure_handle()
+                with th.cuda.device(self._flat.device):
+                    _lib.check(lib.s3d_unet_repack(self._handle, _lib.stream_ptr()))
+                self._synced, self._flat_dirty = stamp, False
+            return lib
         if stamp != self._synced:
+            params = dict(self.named_parameters())
             for name in self._param_names:
                 host = params[name].detach().to("cpu", th.float32).contiguous()
                 shape = (C.c_int64 * host.dim())(*host.shape)
@@ -124,6 +132,13 @@ class _TriplaneUNetBase(nn.Module):
                                                   host.dim()))
             self._synced = stamp
         return lib
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)      # .to(), .cuda(), .float(): the parameter storage moves
+        self._synced = None
+        self._flat = None
+        self._plist = None
+        return out
 
     # ------------------------------------------------------------------ training tier: flat parameters
     def _flat_intact(self, params):
@@ -163,7 +178,10 @@ class _TriplaneUNetBase(nn.Module):
             _lib.check(lib.s3d_unet_train_attach(self._handle, _lib.ptr(flat), total))
             _lib.check(lib.s3d_unet_repack(self._handle, _lib.stream_ptr()))
         self._flat, self._flat_layout = flat, layout
-        self._synced = tuple((p.data_ptr(), p._version) for p in dict(self.named_parameters()).values())
+        self._plist = None
+        named = dict(self.named_parameters())
+        self._plist = [named[n] for n in self._param_names]
+        self._synced = tuple(p._version for p in self._plist)
         self._flat_dirty = False
         return lib
 
