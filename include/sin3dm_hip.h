@@ -249,6 +249,24 @@ S3D_API int s3d_ae_forward(s3d_ae* a, const float* pts, int64_t N, const float a
 S3D_API int s3d_ae_loss_grads(s3d_ae* a, const float* pts, const float* sdf, const float* tex, int64_t N, const float aabb[6],
                               const s3d_ae_loss_cfg* cfg, float* losses, float* pred, float* grads, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Iso-surface extraction: marching cubes on the device, replacing
+ * `mcubes.marching_cubes(np.pad(grid, 1, constant_values=pad_value), iso)` and `v -= 1`
+ * (src/encoding/utils3d.py:196-203).  Two calls because the output size is data dependent.
+ * grid: value of vertex (x,y,z) at grid[((x*Y + y)*Z + z) * stride] (stride 4 reads the sdf channel of a
+ * decode_grid output in place; its other channels can be interpolated onto the vertices as attributes).
+ * Vertex coordinates are grid-index coordinates of the unpadded grid; triangles index the vertex array; normals
+ * (right-hand rule) point from values < iso to values > iso.  Parity with PyMCubes is unpinned.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct s3d_mc s3d_mc;
+S3D_API int s3d_mc_create(s3d_mc** out);
+S3D_API void s3d_mc_destroy(s3d_mc* m);
+/* pass 1: classify and scan; synchronises `stream` to return the counts.  pad = 1 surrounds the grid with pad_value. */
+S3D_API int s3d_mc_count(s3d_mc* m, const float* grid, int X, int Y, int Z, int stride, float iso, int pad, float pad_value,
+                         int64_t* n_verts, int64_t* n_tris, void* stream);
+/* pass 2: verts [n_verts][3], attrs [n_verts][n_attr] or null (channels 1..n_attr of the grid), tris [n_tris][3] */
+S3D_API int s3d_mc_extract(s3d_mc* m, float* verts, float* attrs, int n_attr, int32_t* tris, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

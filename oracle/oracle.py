@@ -237,3 +237,21 @@ def ae_plane_block(sd, prefix, planes, up):
     op = (c_fp * 3)(*[o.ctypes.data_as(c_fp) for o in outs])
     lib().orc_ae_plane_block(C.byref(pr.c), prefix.encode(), ip, ph, pw, cin, up, op)
     return outs
+
+
+def marching_cubes(grid, iso=0.0, pad_value=1.0):
+    """Checker of the device marching cubes (PyMCubes parity unpinned, see sin3dm_oracle.c).  grid: [X,Y,Z] or
+    [X,Y,Z,S] (value in channel 0).  -> (verts [nv,3] float32 index coordinates, tris [nt,3] int32)."""
+    g = np.ascontiguousarray(grid, np.float32)
+    X, Y, Z = g.shape[:3]
+    stride = g.shape[3] if g.ndim == 4 else 1
+    nv, nt = C.c_int64(), C.c_int64()
+    pad, pv = int(pad_value is not None), float(pad_value if pad_value is not None else 0.0)
+    f = lib().orc_marching_cubes
+    f.restype = C.c_int
+    args = (g.ctypes.data_as(c_fp), X, Y, Z, stride, C.c_float(iso), pad, C.c_float(pv))
+    f(*args, None, None, C.byref(nv), C.byref(nt))
+    verts = np.empty((nv.value, 3), np.float32)
+    tris = np.empty((nt.value, 3), np.int32)
+    f(*args, verts.ctypes.data_as(c_fp), tris.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nv), C.byref(nt))
+    return verts, tris

@@ -706,3 +706,57 @@ ORC_API void orc_triplane_resblock(const orc_params* pr, const char* prefix, con
     tri_free(&o);
 }
 ORC_API int orc_has_param(const orc_params* pr, const char* name) { return has_param(pr, name); }
+
+/* ------------------------------------------------------------------------------------------------
+ * Marching cubes (the checker of sin3dm_amd/csrc/s3d_mc.hip).  Stands for `mcubes.marching_cubes(np.pad(grid, 1,
+ * constant_values=pad_value), iso)` followed by `v -= 1` (src/encoding/utils3d.py:196-203).  PyMCubes is not in this
+ * environment: PARITY WITH IT IS UNPINNED.  The case table is generated by tools/gen_mc_tables.py; vertices are emitted
+ * per cut edge in (axis, vertex index) order and triangles per cell in index order, which is also the device order.
+ * ------------------------------------------------------------------------------------------------ */
+#include "../sin3dm_amd/csrc/s3d_mc_tables.h"
+static float mc_s(const float* v, int X, int Y, int Z, int stride, int pad, float padv, int x, int y, int z) {
+    x -= pad; y -= pad; z -= pad;
+    if (x < 0 || y < 0 || z < 0 || x >= X || y >= Y || z >= Z) return padv;
+    return v[(((size_t)x * Y + y) * Z + z) * stride];
+}
+/* two-call protocol: verts == NULL counts only.  Returns 0. */
+ORC_API int orc_marching_cubes(const float* v, int X, int Y, int Z, int stride, float iso, int pad, float padv,
+                               float* verts, int32_t* tris, int64_t* n_verts, int64_t* n_tris) {
+    const int Xp = X + 2 * pad, Yp = Y + 2 * pad, Zp = Z + 2 * pad;
+    const int64_t NV = (int64_t)Xp * Yp * Zp;
+    int32_t* vid = (int32_t*)malloc(sizeof(int32_t) * 3 * NV);
+    int64_t nv = 0, nt = 0;
+    for (int axis = 0; axis < 3; ++axis)
+        for (int64_t i = 0; i < NV; ++i) {
+            const int z = (int)(i % Zp), y = (int)((i / Zp) % Yp), x = (int)(i / ((int64_t)Zp * Yp));
+            const int x1 = x + (axis == 0), y1 = y + (axis == 1), z1 = z + (axis == 2);
+            vid[axis * NV + i] = -1;
+            if (x1 >= Xp || y1 >= Yp || z1 >= Zp) continue;
+            const float v0 = mc_s(v, X, Y, Z, stride, pad, padv, x, y, z), v1 = mc_s(v, X, Y, Z, stride, pad, padv, x1, y1, z1);
+            if ((v0 < iso) == (v1 < iso)) continue;
+            if (verts) {
+                const float t = (iso - v0) / (v1 - v0);
+                float p[3] = {(float)(x - pad), (float)(y - pad), (float)(z - pad)};
+                p[axis] += t;
+                verts[nv * 3] = p[0]; verts[nv * 3 + 1] = p[1]; verts[nv * 3 + 2] = p[2];
+            }
+            vid[axis * NV + i] = (int32_t)nv++;
+        }
+    for (int64_t i = 0; i < NV; ++i) {
+        const int z = (int)(i % Zp), y = (int)((i / Zp) % Yp), x = (int)(i / ((int64_t)Zp * Yp));
+        if (x + 1 >= Xp || y + 1 >= Yp || z + 1 >= Zp) continue;
+        int cs = 0;
+        for (int c = 0; c < 8; ++c) cs |= (mc_s(v, X, Y, Z, stride, pad, padv, x + (c & 1), y + ((c >> 1) & 1), z + ((c >> 2) & 1)) < iso) << c;
+        for (int k = 0; k < 3 * MC_NTRI[cs]; ++k) {
+            if (tris) {
+                const int e = MC_TRI[cs][k], c0 = MC_EDGE[e][0], axis = MC_EDGE_AXIS[e];
+                const int64_t lin = ((int64_t)(x + (c0 & 1)) * Yp + (y + ((c0 >> 1) & 1))) * Zp + (z + ((c0 >> 2) & 1));
+                tris[nt * 3 + k] = vid[axis * NV + lin];
+            }
+        }
+        nt += MC_NTRI[cs];
+    }
+    free(vid);
+    *n_verts = nv; *n_tris = nt;
+    return 0;
+}

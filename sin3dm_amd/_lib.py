@@ -85,6 +85,12 @@ SIGNATURES = {
                                             C.c_void_p]),
     "s3d_decoder_grid_dims": (C.c_int, [c_fp, C.c_int, C.POINTER(C.c_int)]),
     "s3d_decoder_decode_grid": (C.c_int, [C.c_void_p, C.c_int, c_fp, C.c_void_p, C.c_void_p]),
+    # iso-surface extraction
+    "s3d_mc_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "s3d_mc_destroy": (None, [C.c_void_p]),
+    "s3d_mc_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
+                               c_i64p, c_i64p, C.c_void_p]),
+    "s3d_mc_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     # auto-encoder training tier
     "s3d_ae_create": (C.c_int, [C.POINTER(DecoderCfg), C.POINTER(C.c_void_p)]),
     "s3d_ae_destroy": (None, [C.c_void_p]),

@@ -121,6 +121,24 @@ class ShapeAutoEncoder:
         np.savez_compressed(os.path.join(save_dir, f"r{reso}_voxel.npz"), voxel=vox)
         return vox
 
+    @torch.no_grad()
+    def decode_mesh(self, save_dir, triplane_feat, reso, name="object.obj"):
+        """Iso-surface of the decoded SDF as a vertex-coloured OBJ: decode_grid -> marching cubes on the device
+        (sdfgrid_to_mesh, utils3d.py:196-203: pad with +1, level 0) -> world coordinates.  The reference's decode_texmesh
+        (:362-473) continues with a connected-component filter, decimation, a UV atlas and texture baking
+        (point_cloud_utils / open3d / xatlas / nvdiffrast): out of scope; the decoded colour is interpolated onto the
+        vertices instead."""
+        from .isosurface import export_obj, grid_to_world, marching_cubes
+        H, W = triplane_feat[0].shape[-2:]
+        D = triplane_feat[1].shape[-1]
+        aabb = self._resize_aabb((H, W, D))
+        grid = self.decode_grid(triplane_feat, reso, aabb=aabb)                  # [Nx, Ny, Nz, 1+3], colours clamped
+        verts, tris, cols = marching_cubes(grid, 0.0, 1.0, n_attr=grid.shape[-1] - 1)
+        verts = grid_to_world(verts, grid.shape[:3], aabb)
+        path = os.path.join(save_dir, name)
+        export_obj(path, verts, tris, cols)
+        return verts, tris, cols
+
     # ------------------------------------------------------------------ training (reference :51-139, 178-258)
     def _load_data(self, path, sdf_renorm=False):
         """The preprocessed .npz of one shape: grid + near-surface samples (reference :51-112)."""

@@ -6,8 +6,8 @@
 Reads EXP/encoding/{args.json,feat.npz}, EXP/diffusion/{args.json,ema_<rate>_<iters>.pt} and the AE checkpoint
 EXP/encoding/model/ckpt_final.pth written by the reference's train.py; writes EXP/<output>/NNN/feat.npz (and
 r<reso>_voxel.npz with --vox).  Multi-GPU: sample indices are striped over the ranks (sin3dm_amd/parallel.py).
-Mesh/texture export (PyMCubes, xatlas, nvdiffrast) is out of scope: without --vox the decode
-stage stops after writing feat.npz.
+Without --vox the decode stage extracts the iso-surface on the device (marching cubes) and writes a vertex-coloured
+object.obj; the reference's UV atlas / baked texture (xatlas, nvdiffrast) is out of scope.
 """
 from __future__ import annotations
 
@@ -62,14 +62,16 @@ def decode(args, paths):
     from .encoding.model import ShapeAutoEncoder
     from .utils.triplane_util import load_triplane_data
 
-    if not args.vox:
-        print("decode: mesh/texture export needs PyMCubes/xatlas/nvdiffrast (out of scope); pass --vox for voxels")
-        return
     ae = ShapeAutoEncoder(encoding_log_dir(args.tag), args, device=dist_util.dev())
     ae.load_ckpt("final")
     for path in paths:
         fm = [f.unsqueeze(0) for f in load_triplane_data(path, device=dist_util.dev(), compose=False)]
-        ae.decode_voxel(os.path.dirname(path), fm, args.reso)
+        if args.vox:
+            ae.decode_voxel(os.path.dirname(path), fm, args.reso)
+        else:
+            # iso-surface on the device, vertex-coloured object.obj (the UV-atlas / baked-texture export of the reference
+            # needs xatlas + nvdiffrast and stays out of scope)
+            ae.decode_mesh(os.path.dirname(path), fm, args.reso)
 
 
 def main(argv=None):

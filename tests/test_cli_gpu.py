@@ -111,3 +111,18 @@ def test_train_cli_autoencoder_stage(tmp_path):
     assert all(np.isfinite(d[k]).all() and np.abs(d[k]).max() <= 1.0 for k in d.files)          # tanh range
     ck = torch.load(os.path.join(enc, "model", "ckpt_final.pth"), weights_only=False)
     assert ck["featmap_size"] == [16, 24, 12] and set(ck["net"]) >= {"geo_encoder.weight", "tex_decoder.second_layers.4.bias", "aabb"}
+
+
+def test_sample_cli_writes_mesh(tmp_path):
+    """default decode (no --vox): object.obj from the device marching cubes, closed and inside the aabb"""
+    from sin3dm_amd import sample
+    tag = make_experiment(str(tmp_path))
+    paths = sample.main(["--tag", tag, "--n_samples", "1", "--use_ddim", "True", "--timestep_respacing", "5", "--reso", "48"])
+    obj = os.path.join(os.path.dirname(paths[0]), "object.obj")
+    v = np.asarray([[float(x) for x in l.split()[1:]] for l in open(obj) if l.startswith("v ")])
+    f = np.asarray([[int(x) for x in l.split()[1:]] for l in open(obj) if l.startswith("f ")])
+    assert v.shape[1] == 6 and len(f) > 0 and f.min() >= 1 and f.max() <= len(v)
+    assert (v[:, 3:] >= 0).all() and (v[:, 3:] <= 1).all()
+    lo, hi = np.asarray([-0.72, -1.0, -0.72]), np.asarray([0.72, 1.0, 0.72])
+    cell = (hi - lo).max() / 48
+    assert (v[:, :3] >= lo - cell).all() and (v[:, :3] <= hi + cell).all()
