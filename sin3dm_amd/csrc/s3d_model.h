@@ -93,6 +93,9 @@ struct s3d_unet {
     float* flat = nullptr;
     int64_t flat_numel = 0;
     std::vector<size_t> flat_off;
+    std::map<std::string, size_t> flat_index;            // parameter name -> offset in the flat vector
+    long long train_key[4] = {-1, -1, -1, -1};           // (B,H,W,D) of the last measured forward+backward
+    size_t train_high = 0;
     DevBuf tbuf, descs_dev;
     std::vector<PackDesc> descs;
     int pack_blocks = 0;

@@ -23,9 +23,9 @@ struct Bwd {
     bool meas() { return m->arena.measuring; }
 
     float* G(const std::string& name) {
-        for (size_t i = 0; i < m->specs.size(); ++i)
-            if (m->specs[i].name == name) return grads ? grads + m->flat_off[i] : reinterpret_cast<float*>(uintptr_t(256));
-        return nullptr;
+        auto it = m->flat_index.find(name);
+        if (it == m->flat_index.end()) return nullptr;
+        return grads ? grads + it->second : reinterpret_cast<float*>(uintptr_t(256));
     }
     Tri alloc_tri(int C, const Geo& g) {
         Tri t; t.C = C; t.g = g;
@@ -304,8 +304,9 @@ int s3d_unet_train_attach(s3d_unet* m, float* params, int64_t numel) {
               (long long)numel, (long long)s3d_unet_param_numel(m));
     S3D_CHECK(m->cfg.model_channels * 2 * m->cfg.channel_mult[0] <= 1024, S3D_ERR_UNSUPPORTED, "training: model too wide");
     m->flat_off.resize(m->specs.size());
+    m->flat_index.clear();
     size_t off = 0;
-    for (size_t i = 0; i < m->specs.size(); ++i) { m->flat_off[i] = off; off += m->specs[i].numel(); }
+    for (size_t i = 0; i < m->specs.size(); ++i) { m->flat_off[i] = off; m->flat_index[m->specs[i].name] = off; off += m->specs[i].numel(); }
     // the packed layout comes from the host packer; its values are then always rebuilt from `params` on the device
     if (!m->packed) {
         for (const auto& sp : m->specs)
@@ -328,17 +329,25 @@ int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, int B, i
     S3D_CHECK(m->flat, S3D_ERR_INVALID, "forward_train: call s3d_unet_train_attach first");
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "forward_train: B,H,W,D must be >= 1");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // measure forward + backward together: the workspace must not move between the two
-    m->arena.measuring = true;
-    m->arena.high = 0;
-    int rc = run_forward(m, x, t, B, H, W, D, out, st, &m->tape);
-    if (!rc) rc = run_backward(m, nullptr, nullptr, st);
-    m->arena.measuring = false;
-    m->tape.valid = false;
-    if (rc) return rc;
-    if (m->arena.high > m->arena.buf.cap) {
-        S3D_HIP(hipStreamSynchronize(st));
-        S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+    // measure forward + backward together: the workspace must not move between the two.  Pure host work that depends
+    // only on the shapes: skipped when they repeat (every step of a training run).
+    const long long key[4] = {B, H, W, D};
+    const bool same = m->train_key[0] == key[0] && m->train_key[1] == key[1] && m->train_key[2] == key[2] && m->train_key[3] == key[3];
+    int rc = 0;
+    if (!same || m->train_high > m->arena.buf.cap) {
+        m->arena.measuring = true;
+        m->arena.high = 0;
+        rc = run_forward(m, x, t, B, H, W, D, out, st, &m->tape);
+        if (!rc) rc = run_backward(m, nullptr, nullptr, st);
+        m->arena.measuring = false;
+        m->tape.valid = false;
+        if (rc) return rc;
+        m->train_high = m->arena.high;
+        for (int k = 0; k < 4; ++k) m->train_key[k] = key[k];
+        if (m->arena.high > m->arena.buf.cap) {
+            S3D_HIP(hipStreamSynchronize(st));
+            S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+        }
     }
     rc = run_forward(m, x, t, B, H, W, D, out, st, &m->tape);
     if (rc) m->tape.valid = false;
