@@ -27,24 +27,34 @@ struct EdgeArgs {
     int begin[7];             // block prefix over the 6 (plane, row|col) jobs, per sample
 };
 __global__ __launch_bounds__(256) void k_edge_sums(EdgeArgs a) {
+    // one block per (sample, line); a thread owns a float4 of channels and every pl-th interior element of the line
+    extern __shared__ __attribute__((aligned(16))) float sm_es[];       // [pl][C]
     const int per = a.begin[6];
     const int b = blockIdx.x / per;
     int r = blockIdx.x % per, v = 0;
     while (r >= a.begin[v + 1]) ++v;
     r -= a.begin[v];
     const int p = v >> 1, is_col = v & 1;
-    const int h = a.h[p], w = a.w[p], C = a.C;
+    const int h = a.h[p], w = a.w[p], C = a.C, cq = C / 4;
     const int n = is_col ? h : w;                     // length of the summed axis
-    const size_t stride = is_col ? size_t(w) * C : size_t(C);
-    const float* base = a.dy[p] + size_t(b) * h * w * C + (is_col ? size_t(r) * C : size_t(r) * w * C);
+    const size_t stride = (is_col ? size_t(w) * C : size_t(C)) / 4;
+    const float4* base = reinterpret_cast<const float4*>(a.dy[p] + size_t(b) * h * w * C + (is_col ? size_t(r) * C : size_t(r) * w * C));
     float* out = (is_col ? a.Cs[p] + (size_t(b) * w + r) * 3 * C : a.R[p] + (size_t(b) * h + r) * 3 * C);
+    const int pl = blockDim.x / cq, q = threadIdx.x % cq, l = threadIdx.x / cq;
+    float4 mid = make_float4(0, 0, 0, 0);
+    for (int k = 1 + l; k < n - 1; k += pl) {
+        const float4 t = base[size_t(k) * stride + q];
+        mid.x += t.x; mid.y += t.y; mid.z += t.z; mid.w += t.w;
+    }
+    reinterpret_cast<float4*>(sm_es)[l * cq + q] = mid;
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float first = base[c];
-        const float last = base[size_t(n - 1) * stride + c];
-        float mid = 0.f;
-        for (int k = 1; k < n - 1; ++k) mid += base[size_t(k) * stride + c];
+        float m = 0.f;
+        for (int ll = 0; ll < pl; ++ll) m += sm_es[ll * C + c];
+        const float first = reinterpret_cast<const float*>(base)[c];
+        const float last = reinterpret_cast<const float*>(base + size_t(n - 1) * stride)[c];
         float s0, s1, s2;
-        if (n >= 2) { s0 = mid + last; s2 = first + mid; s1 = first + mid + last; }
+        if (n >= 2) { s0 = m + last; s2 = first + m; s1 = first + m + last; }
         else { s0 = 0.f; s2 = 0.f; s1 = first; }
         out[c] = s0; out[C + c] = s1; out[2 * C + c] = s2;
     }
@@ -52,13 +62,15 @@ __global__ __launch_bounds__(256) void k_edge_sums(EdgeArgs a) {
 int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st) {
     EdgeArgs a;
     a.B = B; a.C = dy.C; a.begin[0] = 0;
+    S3D_CHECK(dy.C % 4 == 0 && dy.C <= 1024, S3D_ERR_INVALID, "edge_sums: C=%d", dy.C);
     for (int p = 0; p < 3; ++p) {
         a.dy[p] = dy.p[p]; a.R[p] = R[p]; a.Cs[p] = Cs[p]; a.h[p] = dy.g.h[p]; a.w[p] = dy.g.w[p];
         a.begin[2 * p + 1] = a.begin[2 * p] + dy.g.h[p];
         a.begin[2 * p + 2] = a.begin[2 * p + 1] + dy.g.w[p];
     }
     if (!B || !a.begin[6]) return 0;
-    hipLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(std::min(256, dy.C)), 0, st, a);
+    const int cq = dy.C / 4, pl = std::max(1, 256 / cq);
+    hipLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(cq * pl), size_t(pl) * dy.C * sizeof(float), st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -68,28 +80,42 @@ int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3]
 // emb_out when it is added to h, use_scale_shift_norm=False, src/diffusion/unet_triplane.py:298-303).
 struct BiasArgs { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
 __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
-    __shared__ float sm[16][64];
+    // 64 channels x 16 row lanes.  All (sample, plane) partial sums are accumulated first (independent loads in flight),
+    // then reduced over the lanes through LDS, four samples at a time.
+    __shared__ float sm[12][16][64];
     const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6, co = blockIdx.x * 64 + cl;
     float tot_p[3] = {0.f, 0.f, 0.f};
-    for (int b = 0; b < a.B; ++b) {
-        float tot = 0.f;
-        for (int p = 0; p < 3; ++p) {
-            float s = 0.f;
-            if (co < a.C) {
-                const float* R = a.R[p] + size_t(b) * a.h[p] * 3 * a.C + a.C + co;
-                for (int r = lane; r < a.h[p]; r += 16) s += R[size_t(r) * 3 * a.C];
-            }
-            __syncthreads();
-            sm[lane][cl] = s;
-            __syncthreads();
-            if (lane == 0) {
-                float t = 0.f;
+    for (int b0 = 0; b0 < a.B; b0 += 4) {
+        const int nb = min(4, a.B - b0);
+        float s[4][3];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) t += sm[k][cl];
-                tot += t; tot_p[p] += t;
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                float acc = 0.f;
+                if (bb < nb && co < a.C) {
+                    const float* R = a.R[p] + size_t(b0 + bb) * a.h[p] * 3 * a.C + a.C + co;
+                    for (int r = lane; r < a.h[p]; r += 16) acc += R[size_t(r) * 3 * a.C];
+                }
+                s[bb][p] = acc;
             }
-        }
-        if (lane == 0 && co < a.C && a.per_sample) a.per_sample[size_t(b) * a.per_sample_stride + co] = tot;
+        __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) sm[bb * 3 + p][lane][cl] = s[bb][p];
+        __syncthreads();
+        if (lane == 0 && co < a.C)
+            for (int bb = 0; bb < nb; ++bb) {
+                float tot = 0.f;
+                for (int p = 0; p < 3; ++p) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t += sm[bb * 3 + p][k][cl];
+                    tot += t; tot_p[p] += t;
+                }
+                if (a.per_sample) a.per_sample[size_t(b0 + bb) * a.per_sample_stride + co] = tot;
+            }
     }
     if (lane == 0 && co < a.C)
         for (int p = 0; p < 3; ++p)
@@ -404,7 +430,7 @@ struct GnBwdArgs {
     const float* gamma[3]; const float* beta[3];
     const float* mr; const float* film; int film_stride;
     float* part;                                          // [B][3][nchunk][C][2]
-    const float* coef;                                    // [B][3][C][2] = {mean_grp(g*dz), mean_grp(g*dz*xh)}
+    const float* coef;                                    // [B][3][C][8]: per-channel constants of the apply pass (k_gn_bwd_coefs)
     int h[3], w[3];
     int C, cq, pl, B, nchunk, ngroups;
 };
@@ -480,6 +506,7 @@ struct GnBwdFinArgs {
     const float* gamma[3]; const float* beta[3];
     float* dgamma[3]; float* dbeta[3];
     const float* film; float* dfilm; int film_stride;    // dfilm [B][film_stride]: dscale at [0,C), dshift at [C,2C)
+    const float* mr;
     double count[3];
     int C, B, nchunk, ngroups;
 };
@@ -488,9 +515,10 @@ __global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
     if (idx >= a.B * 3 * a.C) return;
     const int ch = idx % a.C, bp = idx / a.C;
     double s1 = 0, s2 = 0;
+#pragma unroll 8
     for (int k = 0; k < a.nchunk; ++k) {
-        const float* q = a.part + ((size_t(bp) * a.nchunk + k) * a.C + ch) * 2;
-        s1 += q[0]; s2 += q[1];
+        const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * a.C + ch) * 2);
+        s1 += q.x; s2 += q.y;
     }
     a.A[size_t(idx) * 2] = float(s1); a.A[size_t(idx) * 2 + 1] = float(s2);
 }
@@ -506,10 +534,18 @@ __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
             const double gg = double(a.gamma[p][ch]) * sc;
             g1 += gg * a.A[(size_t(bp) * C + ch) * 2]; g2 += gg * a.A[(size_t(bp) * C + ch) * 2 + 1];
         }
+        // per-channel constants of the apply pass, 8 floats per channel:
+        //   xh = x*c0 + c1 ; z = xh*c2 + c3 ; dx = dz*c4 - c5 - xh*c6        (c7 unused)
+        const float mean = a.mr[(size_t(bp) * G + g) * 2], rstd = a.mr[(size_t(bp) * G + g) * 2 + 1];
+        const float k1 = float(g1 / a.count[p]), k2 = float(g2 / a.count[p]);
         for (int k = 0; k < cg; ++k) {
             const int ch = g * cg + k;
-            a.coef[(size_t(bp) * C + ch) * 2] = float(g1 / a.count[p]);
-            a.coef[(size_t(bp) * C + ch) * 2 + 1] = float(g2 / a.count[p]);
+            const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
+            const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
+            const float gam = a.gamma[p][ch], bet = a.beta[p][ch];
+            float* o = a.coef + (size_t(bp) * C + ch) * 8;
+            o[0] = rstd; o[1] = -mean * rstd; o[2] = gam * sc; o[3] = bet * sc + sh;
+            o[4] = rstd * gam * sc; o[5] = rstd * k1; o[6] = rstd * k2; o[7] = 0.f;
         }
     }
     // (2) dgamma / dbeta (sum over the batch)
@@ -553,20 +589,21 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, long long beg
     const float4 dy = gn_dy4(a, p, b, row, col, pix, q);
     float4 ad = make_float4(0, 0, 0, 0);
     if (a.add[p]) ad = reinterpret_cast<const float4*>(a.add[p])[pix * a.cq + q];
+    const float4* ct = reinterpret_cast<const float4*>(a.coef + ((size_t(b) * 3 + p) * a.C + 4 * q) * 8);
     const float xv[4] = {x.x, x.y, x.z, x.w}, dv[4] = {dy.x, dy.y, dy.z, dy.w}, av[4] = {ad.x, ad.y, ad.z, ad.w};
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int chn = 4 * q + k;
-        const GnChan c = gn_chan(a, p, b, chn);
-        float xh;
-        const float dz = gn_dz(c, xv[k], dv[k], xh);
-        const float* cf = a.coef + ((size_t(b) * 3 + p) * a.C + chn) * 2;
-        o[k] = c.rstd * (c.gam * c.sc * dz - cf[0] - xh * cf[1]) + av[k];
+        const float4 c0 = ct[2 * k], c1 = ct[2 * k + 1];
+        const float xh = fmaf(xv[k], c0.x, c0.y);
+        const float z = fmaf(xh, c0.z, c0.w);
+        const float sg = sigmoid_f(z);
+        const float dz = dv[k] * sg * (1.0f + z * (1.0f - sg));
+        o[k] = dz * c1.x - c1.y - xh * c1.z + av[k];
     }
     reinterpret_cast<float4*>(a.dx[p])[pix * a.cq + q] = make_float4(o[0], o[1], o[2], o[3]);
 }
-size_t gn_bwd_ws_floats(int B, int C) { return size_t(B) * 3 * kGnBwdChunks * C * 2 + size_t(B) * 3 * C * 4; }
+size_t gn_bwd_ws_floats(int B, int C) { return size_t(B) * 3 * kGnBwdChunks * C * 2 + size_t(B) * 3 * C * 10; }
 int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     GnBwdArgs a;
     const Tri& x = s.x;
@@ -593,7 +630,7 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(a.cq * a.pl), size_t(a.pl) * x.C * 2 * sizeof(float), st, a);
     S3D_HIP(hipGetLastError());
     GnBwdFinArgs f;
-    f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride;
+    f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride; f.mr = s.stats.mr;
     for (int p = 0; p < 3; ++p) {
         f.gamma[p] = s.gamma[p]; f.beta[p] = s.beta[p]; f.dgamma[p] = s.dgamma[p]; f.dbeta[p] = s.dbeta[p];
         f.count[p] = double(x.C / s.ngroups) * x.g.h[p] * x.g.w[p];
