@@ -118,6 +118,7 @@ struct ConvArgs {
     int B, cin, cout;
     int gn_sg, gn_nsub, gn_maxparts;          // GroupNorm partial layout when job[].gn_part is set
     int relu;                                 // direct kernels only: ReLU in the epilogue (the decoder MLPs as 1x1 convs)
+    int xcd_swizzle;                          // Winograd kernel: logical block order contiguous per XCD (set by the launcher)
 };
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3 };
 // Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.

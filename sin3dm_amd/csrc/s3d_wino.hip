@@ -271,7 +271,13 @@ constexpr int W2_ITEMS_PT = (W2_ITEMS + 255) / 256;       // halo float4 items p
 
 __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[2 * W2_AELEMS];
-    const int bid = blockIdx.x;
+    // workgroup i runs on XCD i % 8 (each XCD has its own L2): give every XCD a contiguous range of logical blocks, so
+    // that the two 64-channel column blocks of a pixel tile and the neighbouring tiles (shared halo) hit the same L2
+    int bid = blockIdx.x;
+    if (args.xcd_swizzle) {
+        const int chunk = int(gridDim.x) >> 3;
+        if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
+    }
     int j = 0;
     while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
     const ConvJob& J = args.job[j];
@@ -519,6 +525,8 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
+    static const int xcd = getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1;
+    a.xcd_swizzle = xcd;
     if (two) hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
