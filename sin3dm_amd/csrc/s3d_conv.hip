@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
     float* const Abase = smem;
     float* const Bbase = smem + 2 * CFG::A_ELEMS;
 
-    const int bid = blockIdx.x;
+    // workgroup i runs on XCD i % 8: contiguous logical ranges per XCD keep a tile's column blocks and its halo
+    // neighbours in one L2 (see k_conv_wino2)
+    int bid = blockIdx.x;
+    if (args.xcd_swizzle) {
+        const int chunk = int(gridDim.x) >> 3;
+        if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
+    }
     int j = 0;
     while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
     const ConvJob& J = args.job[j];
@@ -481,6 +487,8 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
+    static const int xcd = getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1;
+    a.xcd_swizzle = xcd;
     hipLaunchKernelGGL(k_conv_mfma<CFG>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
