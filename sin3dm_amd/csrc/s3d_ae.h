@@ -34,7 +34,6 @@ int launch_gather(const PointSet& ps, const float* const feat[2][3], const int p
 int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
                    const float* const dX[2], hipStream_t st);
 
-int launch_relu(float* x, long long n, hipStream_t st);
 // dpre = dact[:, coff:coff+C] * (act > 0) and colsum[C] = its column sums (ws: colsum_ws_floats(C))
 int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,
                     float* colsum, hipStream_t st);

@@ -386,19 +386,6 @@ int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3]
 }
 
 // ------------------------------------------------------------------ small element-wise pieces of the MLP
-__global__ void k_relu(float* __restrict__ x, long long n4) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    float4 v = reinterpret_cast<float4*>(x)[i];
-    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    reinterpret_cast<float4*>(x)[i] = v;
-}
-int launch_relu(float* x, long long n, hipStream_t st) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(k_relu, dim3(cdivll(n / 4, 256)), dim3(256), 0, st, x, n / 4);
-    S3D_HIP(hipGetLastError());
-    return 0;
-}
 // dpre[n][c] = dact[n][coff + c] * (act[n][c] > 0)   (dact row stride dstride), and the column sums of dpre (the bias
 // gradient) in the same pass: per-chunk partials here, added in chunk order by k_colsum_fin
 constexpr int kColChunks = 256;

@@ -64,7 +64,6 @@ int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out
 // y = L(f(in)): dW/db (when dW != null) and dx = (dy W) * f'(in) (when dx != null); dy rows are dy_stride apart
 int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
                       float* db, float* dx, hipStream_t st);
-int launch_scale(float* v, long long n, float s, hipStream_t st);
 
 int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
                     float* xt, hipStream_t st);

@@ -933,18 +933,6 @@ int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, in
     return 0;
 }
 
-// scale a [B][L][C] vector set in place (mean gradients: divide by the averaged length)
-__global__ void k_scale(float* __restrict__ v, long long n, float s) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] *= s;
-}
-int launch_scale(float* v, long long n, float s, hipStream_t st) {
-    if (!n) return 0;
-    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, v, n, s);
-    S3D_HIP(hipGetLastError());
-    return 0;
-}
-
 // ------------------------------------------------------------------ diffusion training elementwise pieces
 // q_sample (src/diffusion/gaussian_diffusion.py:189-207): x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps
 __global__ void k_q_sample(const float* __restrict__ x0, const float* __restrict__ eps, const float* __restrict__ sa,
