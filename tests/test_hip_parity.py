@@ -232,3 +232,36 @@ def test_decoder_grid_vs_oracle(oracle):
     pts_out = net.decode(cu(pts), [cu(f) for f in fm], aabb=aabb, clamp_color=True).cpu().numpy()
     # the in-kernel grid coordinates may differ from torch's CPU linspace/div by one ulp
     assert relerr(pts_out, grid.reshape(-1, 4)) < 1e-5, "grid mode and point mode must agree"
+
+
+@pytest.mark.gpu
+def test_full_size_trajectory_vs_cpu_port(oracle):
+    """BASELINE config 2 itself (128-ch UNet, 128^3 triplane, DDPM-1000 schedule): eight consecutive ancestral steps
+    from t = 999 with identical noise on the HIP path and on the CPU port (oracle/torch_port.py, the reference's
+    algorithm on ATen/oneDNN).  ~2.5 s of CPU time per step bounds the length; tools/validate_full_size.py runs longer
+    chains (profiles/r01_full_size_parity.txt)."""
+    import torch
+    import torch_port as tp
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
+    mc, (H, W, D), steps = 128, (128, 128, 128), 8
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0)
+    model = TriplaneUNetModelSmall(12, mc, 12, use_scale_shift_norm=True)
+    model.load_state_dict(sd)
+    model.cuda().eval()
+    diffusion = create_gaussian_diffusion(steps=1000, predict_xstart=True)
+    tab, _ = oracle.schedule_tables(None, 1000)
+    g = torch.Generator().manual_seed(3)
+    x_cpu = torch.randn((1, 12, H + D, W + D), generator=g)
+    x_gpu = x_cpu.cuda()
+    worst = 0.0
+    for k in range(steps):
+        t = 999 - k
+        eps = torch.randn(x_cpu.shape, generator=g)
+        diffusion.noise_fn = lambda z, e=eps: e.to(z.device)
+        with torch.no_grad():
+            x_gpu = diffusion.p_sample(model, x_gpu, torch.tensor([t], device="cuda"), model_kwargs=dict(H=H, W=W, D=D))["sample"]
+            out = tp.unet_forward(sd, x_cpu, torch.tensor([float(t)]), H, W, D, mc)
+            x_cpu, _ = tp.p_sample_update(out, x_cpu, eps, tab, t)
+        worst = max(worst, relerr(x_gpu.cpu().numpy(), x_cpu.numpy()))
+    assert worst < 1e-4, worst
