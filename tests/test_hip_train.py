@@ -172,7 +172,8 @@ def test_torch_optimizer_also_works():
     assert torch.isfinite(y).all()
 
 
-@pytest.mark.parametrize("mc,hwd,B", [(64, (12, 8, 10), 2), (64, (46, 64, 46), 1), (128, (20, 24, 12), 1)])
+@pytest.mark.parametrize("mc,hwd,B", [(64, (12, 8, 10), 2), (64, (46, 64, 46), 1), (128, (20, 24, 12), 1),
+                                      (64, (92, 128, 92), 1)])         # the last one is BASELINE config 4's towerruins size
 def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
     """Wider models (2 and 4 channels per GroupNorm group, 64-wide MFMA tiles with several K slices) against the
     CPU oracle's autograd (oracle/torch_port.py, itself pinned to the reference's gradients)."""
