@@ -59,30 +59,33 @@ class LossAwareSampler(ScheduleSampler):
 
 
 class LossSecondMomentResampler(LossAwareSampler):
+    """Importance-samples timesteps proportionally to the RMS of their last `history_per_term` losses, once every
+    timestep has that many (uniform until then), mixed with `uniform_prob` of the uniform distribution."""
+
     def __init__(self, diffusion, history_per_term=10, uniform_prob=0.001):
         self.diffusion = diffusion
         self.history_per_term = history_per_term
         self.uniform_prob = uniform_prob
-        self._loss_history = np.zeros([diffusion.num_timesteps, history_per_term], dtype=np.float64)
-        self._loss_counts = np.zeros([diffusion.num_timesteps], dtype=np.int64)
+        T = diffusion.num_timesteps
+        self._loss_history = np.zeros([T, history_per_term], dtype=np.float64)   # ring buffer per timestep
+        self._loss_counts = np.zeros([T], dtype=np.int64)                       # losses seen, saturating at the window
+        self._next = np.zeros([T], dtype=np.int64)                              # ring write position
+
+    def _warmed_up(self):
+        return bool(np.all(self._loss_counts == self.history_per_term))
 
     def weights(self):
+        T = self.diffusion.num_timesteps
         if not self._warmed_up():
-            return np.ones([self.diffusion.num_timesteps], dtype=np.float64)
-        w = np.sqrt(np.mean(self._loss_history ** 2, axis=-1))
-        w /= np.sum(w)
-        w *= 1 - self.uniform_prob
-        w += self.uniform_prob / len(w)
-        return w
+            return np.ones([T], dtype=np.float64)
+        rms = np.sqrt((self._loss_history ** 2).mean(axis=-1))                  # order inside the window is irrelevant
+        return (1 - self.uniform_prob) * rms / rms.sum() + self.uniform_prob / T
 
     def update_with_all_losses(self, ts, losses):
         for t, loss in zip(ts, losses):
-            if self._loss_counts[t] == self.history_per_term:
-                self._loss_history[t, :-1] = self._loss_history[t, 1:]       # drop the oldest term
-                self._loss_history[t, -1] = loss
-            else:
-                self._loss_history[t, self._loss_counts[t]] = loss
+            if self._loss_counts[t] < self.history_per_term:
+                self._loss_history[t, self._loss_counts[t]] = loss               # fill phase keeps arrival order
                 self._loss_counts[t] += 1
-
-    def _warmed_up(self):
-        return bool((self._loss_counts == self.history_per_term).all())
+            else:
+                self._loss_history[t, self._next[t]] = loss                      # overwrite the oldest entry
+                self._next[t] = (self._next[t] + 1) % self.history_per_term
