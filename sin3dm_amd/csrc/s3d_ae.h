@@ -31,8 +31,10 @@ int launch_inorm_silu(const float* x, double* part, const float* gamma, const fl
 struct PointSet { const float* pts; long long N, Np; float aabb[6]; };   // Np = N rounded up to the GEMM row tile
 int launch_gather(const PointSet& ps, const float* const feat[2][3], const int ph[3], const int pw[3], int C, int nnets,
                   float* const X[2], hipStream_t st);
+// backward of launch_gather: dfeat (every element written) from dX; ws: scatter_ws_bytes(...) bytes.  No float atomics.
+size_t scatter_ws_bytes(long long Np, const int ph[3], const int pw[3]);
 int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
-                   const float* const dX[2], hipStream_t st);
+                   const float* const dX[2], void* ws, hipStream_t st);
 
 // dpre = dact[:, coff:coff+C] * (act > 0) and colsum[C] = its column sums (ws: colsum_ws_floats(C))
 int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,

@@ -13,8 +13,8 @@
 //   MLPs     DecoderMLPSkipConcat as 1x1 convolutions over the point list (fp32 MFMA); activations kept for the backward
 //   losses   weighted-L1 sdf + masked texture loss (k_loss_*)
 //   backward the same operators transposed: MLP dgrad (1x1 conv with W^T), MLP wgrad (k_wgrad_mfma<1>), scatter-add of the
-//            point gradients onto the planes (fp32 atomics — the only non-repeatable reduction of the library, exactly
-//            where PyTorch's grid_sampler backward has one), 5x5 dgrad / wgrad (k_wgrad_mfma<25>), InstanceNorm backward
+//            point gradients onto the planes (points sorted by plane cell, then a per-pixel gather in that fixed order:
+//            no float atomics, unlike PyTorch's grid_sampler backward), 5x5 dgrad / wgrad (k_wgrad_mfma<25>), InstanceNorm backward
 //            (the GroupNorm backward with one channel per group), tanh/InstanceNorm backward and the encoder's weight
 //            gradient as a 2-D correlation with the projections.
 // Parameters: one flat fp32 device vector in the order [geo_encoder, geo_convs, geo_decoder | tex_encoder, tex_convs,
@@ -317,10 +317,10 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // ---- scatter the point gradients onto the planes
     float* dF[2][3];
     for (int n = 0; n < 2; ++n) for (int p = 0; p < 3; ++p) dF[n][p] = ar.alloc<float>(hw[p] * up);
+    char* sws = ar.alloc<char>(scatter_ws_bytes(Np, g.h, g.w));
     if (!meas) {
-        for (int n = 0; n < 2; ++n) for (int p = 0; p < 3; ++p) S3D_HIP(hipMemsetAsync(dF[n][p], 0, hw[p] * up * sizeof(float), st));
         const float* dx[2] = {dX0[0], dX0[1]};
-        S3D_TRY(launch_scatter(ps, dF, g.h, g.w, up, 2, dx, st));
+        S3D_TRY(launch_scatter(ps, dF, g.h, g.w, up, 2, dx, sws, st));
     }
     // ---- plane blocks
     float* dfeat[3];

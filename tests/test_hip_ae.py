@@ -60,6 +60,9 @@ def test_encode_forward_losses_and_grads():
     losses, pred2, grads = net.loss_and_grads(vol, pts, sdf, tex, _loss_cfg(thr), want_pred=True)
     assert torch.equal(pred2, pred)
     assert abs(float(losses[0]) - float(g["sdf_loss"])) < 1e-5 and abs(float(losses[1]) - float(g["tex_loss"])) < 1e-5
+    grads = grads.clone()
+    _, _, again = net.loss_and_grads(vol, pts, sdf, tex, _loss_cfg(thr))
+    assert torch.equal(grads, again)                               # every reduction has a fixed order (no float atomics)
     named = {k: v.cpu().numpy() for k, v in net.split_flat(grads).items()}
     assert all(np.isfinite(v).all() for v in named.values())
     w = digest_errors(named, g, "grad")
