@@ -539,7 +539,8 @@ int s3d_decoder_prepare_triplane(s3d_decoder* d, const float* xy, const float* x
 
 int s3d_decoder_decode_points(s3d_decoder* d, const float* pts, int64_t N, const float aabb[6], int clamp_color, float* out,
                               void* stream) {
-    S3D_CHECK(d && pts && aabb && out && N >= 0, S3D_ERR_INVALID, "decode_points: bad argument");
+    S3D_CHECK(d && aabb && N >= 0 && (N == 0 || (pts && out)), S3D_ERR_INVALID, "decode_points: bad argument");
+    if (N == 0) return 0;                                   // decoding no points is a no-op (empty tensors have null pointers)
     return run_decode(d, pts, N, aabb, nullptr, clamp_color, out, static_cast<hipStream_t>(stream));
 }
 
