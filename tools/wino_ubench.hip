@@ -40,7 +40,8 @@ int main() {
     printf("W_ABL=%d S3D_WINO=%s\n", W_ABL, getenv("S3D_WINO") ? getenv("S3D_WINO") : "(default 2)");
     for (int c : {128, 256, 512}) run(c, 64, 128, 1, 10, false);     // 384 blocks (wino2) / 192 (wino1)
     for (int c : {128, 256, 512}) run(c, 128, 128, 1, 10, false);    // 768 / 384
-    run(256, 256, 64, 1, 10, false);                                  // the half-resolution layer
+    for (int co : {64, 128, 256, 512}) run(256, co, 64, 1, 10, false);   // half resolution: 96 / 192 / 384 / 768 blocks
+    run(128, 256, 64, 1, 10, false);
     run(128, 128, 128, 8, 3, false);
     run(128, 128, 128, 1, 10, true);
     return 0;
