@@ -173,7 +173,7 @@ class TrainLoop:
         self.logkv("step", self.step + self.resume_step)
         self.logkv("samples", (self.step + self.resume_step + 1) * self.global_batch)
         self.logkv("lr", self.opt.lr)
-        if (self.step + 1) % self.log_interval == 0:      # the step whose values the next dumpkvs() prints
+        if self.step % self.log_interval == 0:            # the steps whose values run_loop dumps
             # grad_norm / param_norm of MixedPrecisionTrainer._compute_norms (fp16_util.py:217-225): two reductions over
             # the flat vectors instead of 2 x 138 small ones (and only when they are going to be printed: .item() syncs)
             self.logkv("grad_norm", float(self._grad.norm()))
