@@ -266,6 +266,10 @@ S3D_API int s3d_mc_count(s3d_mc* m, const float* grid, int X, int Y, int Z, int 
                          int64_t* n_verts, int64_t* n_tris, void* stream);
 /* pass 2: verts [n_verts][3], attrs [n_verts][n_attr] or null (channels 1..n_attr of the grid), tris [n_tris][3] */
 S3D_API int s3d_mc_extract(s3d_mc* m, float* verts, float* attrs, int n_attr, int32_t* tris, void* stream);
+/* Connected components of an indexed triangle mesh (the `pcu.connected_components` step of sdfgrid_to_mesh,
+ * src/encoding/utils3d.py:204-208): labels[v] = smallest vertex index of v's component.  tris [n_tris][3], labels
+ * [n_verts] on the device; synchronises `stream` (iterates to a fixed point). */
+S3D_API int s3d_mesh_components(const int32_t* tris, int64_t n_tris, int64_t n_verts, int32_t* labels, void* stream);
 
 #ifdef __cplusplus
 }

@@ -255,3 +255,13 @@ def marching_cubes(grid, iso=0.0, pad_value=1.0):
     tris = np.empty((nt.value, 3), np.int32)
     f(*args, verts.ctypes.data_as(c_fp), tris.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nv), C.byref(nt))
     return verts, tris
+
+
+def mesh_components(tris, n_verts):
+    """labels[v] = smallest vertex index of v's connected component (checker of s3d_mesh_components)."""
+    t = np.ascontiguousarray(tris, np.int32)
+    labels = np.empty(n_verts, np.int32)
+    f = lib().orc_mesh_components
+    f.restype = None
+    f(t.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(len(t)), C.c_int64(n_verts), labels.ctypes.data_as(C.POINTER(C.c_int32)))
+    return labels

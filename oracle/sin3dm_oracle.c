@@ -760,3 +760,16 @@ ORC_API int orc_marching_cubes(const float* v, int X, int Y, int Z, int stride, 
     *n_verts = nv; *n_tris = nt;
     return 0;
 }
+
+/* Connected components of an indexed triangle mesh by union-find; labels[v] = smallest vertex index of v's component.
+ * Checker of s3d_mesh_components (the pcu.connected_components step of sdfgrid_to_mesh, src/encoding/utils3d.py:204-208). */
+static int32_t uf_find(int32_t* p, int32_t v) { while (p[v] != v) { p[v] = p[p[v]]; v = p[v]; } return v; }
+ORC_API void orc_mesh_components(const int32_t* tris, int64_t nt, int64_t nv, int32_t* labels) {
+    for (int64_t i = 0; i < nv; ++i) labels[i] = (int32_t)i;
+    for (int64_t i = 0; i < nt; ++i)
+        for (int k = 1; k < 3; ++k) {
+            int32_t a = uf_find(labels, tris[i * 3]), b = uf_find(labels, tris[i * 3 + k]);
+            if (a < b) labels[b] = a; else if (b < a) labels[a] = b;          /* the smaller index stays the root */
+        }
+    for (int64_t i = 0; i < nv; ++i) labels[i] = uf_find(labels, (int32_t)i);
+}

@@ -91,6 +91,7 @@ SIGNATURES = {
     "s3d_mc_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float,
                                c_i64p, c_i64p, C.c_void_p]),
     "s3d_mc_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "s3d_mesh_components": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     # auto-encoder training tier
     "s3d_ae_create": (C.c_int, [C.POINTER(DecoderCfg), C.POINTER(C.c_void_p)]),
     "s3d_ae_destroy": (None, [C.c_void_p]),

@@ -55,12 +55,31 @@ def marching_cubes(grid, iso=0.0, pad_value=1.0, n_attr=0):
     return verts, tris, attrs
 
 
-def grid_to_world(verts, dims, aabb):
-    """Index coordinates of the cell-centred decode grid (sample_grid_points_aabb, utils3d.py:13-25) -> world space."""
-    aabb = torch.as_tensor(aabb, dtype=torch.float32, device=verts.device)
-    size = aabb[3:] - aabb[:3]
-    r = torch.tensor([float(d) for d in dims], device=verts.device)
-    return (verts + 0.5) / r * size + aabb[:3]
+def mesh_components(tris, n_verts):
+    """labels [n_verts] int32: the smallest vertex index of each vertex's connected component (device)."""
+    _lib.require_gpu(tris)
+    t = tris.contiguous().to(torch.int32)
+    labels = torch.empty(n_verts, device=t.device, dtype=torch.int32)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().s3d_mesh_components(_lib.ptr(t), t.shape[0], n_verts, _lib.ptr(labels), _lib.stream_ptr()))
+    return labels
+
+
+def largest_component(verts, tris, attrs=None):
+    """Keep the connected component with the most faces and drop unreferenced vertices (sdfgrid_to_mesh with
+    only_largest_cc=True, utils3d.py:204-208: pcu.connected_components + remove_unreferenced_mesh_vertices).
+    The components come from the device kernel; the compaction below is index bookkeeping."""
+    if tris.shape[0] == 0:
+        return verts, tris, attrs
+    labels = mesh_components(tris, verts.shape[0])
+    face_label = labels[tris[:, 0].long()]
+    roots, counts = torch.unique(face_label, return_counts=True)          # sorted by root id: ties -> smallest root
+    best = roots[torch.argmax(counts)]
+    keep_f = face_label == best
+    keep_v = labels == best
+    remap = torch.cumsum(keep_v.to(torch.int32), 0, dtype=torch.int32) - 1
+    new_tris = remap[tris[keep_f].long()]
+    return verts[keep_v], new_tris.contiguous(), (attrs[keep_v] if attrs is not None else None)
 
 
 def export_obj(path, verts, tris, colors=None):

@@ -122,21 +122,27 @@ class ShapeAutoEncoder:
         return vox
 
     @torch.no_grad()
-    def decode_mesh(self, save_dir, triplane_feat, reso, name="object.obj"):
-        """Iso-surface of the decoded SDF as a vertex-coloured OBJ: decode_grid -> marching cubes on the device
-        (sdfgrid_to_mesh, utils3d.py:196-203: pad with +1, level 0) -> world coordinates.  The reference's decode_texmesh
-        (:362-473) continues with a connected-component filter, decimation, a UV atlas and texture baking
-        (point_cloud_utils / open3d / xatlas / nvdiffrast): out of scope; the decoded colour is interpolated onto the
-        vertices instead."""
-        from .isosurface import export_obj, grid_to_world, marching_cubes
+    def decode_mesh(self, save_dir, triplane_feat, reso, name="object.obj", only_largest_cc=True, save_voxel=True):
+        """The geometry half of decode_texmesh (reference :362-390): decode_grid -> voxel.npz -> iso-surface of the
+        padded SDF grid at level 0 -> largest connected component -> `v / reso * box_size + box_min`, all on the device
+        (sdfgrid_to_mesh, utils3d.py:196-208, used PyMCubes + point_cloud_utils on the CPU).  What follows there —
+        quadric decimation, UV atlas, texture baking (open3d, xatlas, nvdiffrast) — is out of scope; the decoded colour
+        is interpolated onto the vertices and written as a vertex-coloured OBJ instead."""
+        from .isosurface import export_obj, largest_component, marching_cubes
         H, W = triplane_feat[0].shape[-2:]
         D = triplane_feat[1].shape[-1]
         aabb = self._resize_aabb((H, W, D))
         grid = self.decode_grid(triplane_feat, reso, aabb=aabb)                  # [Nx, Ny, Nz, 1+3], colours clamped
+        os.makedirs(save_dir, exist_ok=True)
+        if save_voxel:
+            np.savez_compressed(os.path.join(save_dir, "voxel.npz"), vox_grid=(grid[..., 0] < 0).cpu().numpy())
         verts, tris, cols = marching_cubes(grid, 0.0, 1.0, n_attr=grid.shape[-1] - 1)
-        verts = grid_to_world(verts, grid.shape[:3], aabb)
-        path = os.path.join(save_dir, name)
-        export_obj(path, verts, tris, cols)
+        if only_largest_cc:
+            verts, tris, cols = largest_component(verts, tris, cols)
+        box_min = aabb[:3]
+        box_size = aabb[3:].max() - aabb[:3].min()                               # the reference's re-normalisation (:385-387)
+        verts = verts / float(reso) * box_size + box_min
+        export_obj(os.path.join(save_dir, name), verts, tris, cols)
         return verts, tris, cols
 
     # ------------------------------------------------------------------ training (reference :51-139, 178-258)

@@ -119,3 +119,39 @@ def test_hip_full_size_grid():
     key = e[:, 0] * (len(v) + 1) + e[:, 1]
     rev = e[:, 1] * (len(v) + 1) + e[:, 0]
     assert len(torch.unique(key)) == len(key) and torch.equal(torch.sort(key)[0], torch.sort(rev)[0])   # closed, oriented
+
+
+def _two_blobs_mesh(oracle, n=26):
+    f, _ = _field("two", n)
+    return oracle.marching_cubes(f, 0.0, 1.0)
+
+
+def test_oracle_components(oracle):
+    v, t = _two_blobs_mesh(oracle)
+    lab = oracle.mesh_components(t, len(v))
+    roots = np.unique(lab)
+    assert len(roots) == 2 and all(lab[r] == r for r in roots)                 # a root is its own label
+    assert np.array_equal(lab[t[:, 0]], lab[t[:, 1]]) and np.array_equal(lab[t[:, 0]], lab[t[:, 2]])
+    for r in roots:
+        assert r == np.flatnonzero(lab == r).min()                             # label = smallest vertex index
+
+
+@pytest.mark.gpu
+def test_hip_components_and_largest(oracle):
+    import torch
+    from sin3dm_amd.encoding.isosurface import largest_component, mesh_components
+    v, t = _two_blobs_mesh(oracle, 40)
+    lab = mesh_components(torch.from_numpy(t).cuda(), len(v))
+    assert np.array_equal(lab.cpu().numpy(), oracle.mesh_components(t, len(v)))
+    # a long thin strip: the label has to travel 5000 triangles (pointer jumping keeps the iteration count low)
+    n = 5000
+    strip = np.stack([np.arange(n), np.arange(n) + 1, np.arange(n) + 2], 1).astype(np.int32)
+    lab2 = mesh_components(torch.from_numpy(strip).cuda(), n + 2)
+    assert int(lab2.max()) == 0
+    vv, tt, _ = largest_component(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda())
+    ref = oracle.mesh_components(t, len(v))
+    roots, counts = np.unique(ref[t[:, 0]], return_counts=True)
+    best = roots[np.argmax(counts)]
+    assert len(vv) == int((ref == best).sum()) and len(tt) == int(counts.max())
+    closed, chi = _invariants(vv.cpu().numpy(), tt.cpu().numpy())
+    assert closed and chi == 2                                                   # one closed blob is left
