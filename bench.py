@@ -132,12 +132,13 @@ def main():
     torch.manual_seed(1000 + rank)
     x = torch.randn(1, 12, H + D, W + D, device=dev)
 
+    all_t = torch.arange(T_STEPS, device=dev, dtype=torch.int64)[:, None].contiguous()     # as GaussianDiffusion._loop does
+
     def run(n, x, start):
         with torch.no_grad():
             for k in range(n):
                 i = (T_STEPS - 1 - (start + k)) % T_STEPS
-                t = torch.full((1,), i, device=dev, dtype=torch.int64)
-                x = diffusion.p_sample(model, x, t, model_kwargs=kw)["sample"]
+                x = diffusion.p_sample(model, x, all_t[i], model_kwargs=kw)["sample"]
         return x
 
     def barrier():

@@ -223,8 +223,10 @@ class GaussianDiffusion:
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
+        # every step's timestep batch as a row of one tensor built up front (a th.full per step is a kernel launch)
+        all_t = th.arange(self.num_timesteps, device=device, dtype=th.int64)[:, None].expand(-1, shape[0]).contiguous()
         for i in indices:
-            t = th.full((shape[0],), i, device=device, dtype=th.int64)
+            t = all_t[i]
             with th.no_grad():
                 out = step_fn(model, img, t, **kw)
                 yield out

@@ -88,11 +88,13 @@ class _WrappedModel:
         return self.model.parameters()
 
     def __call__(self, x, ts, **kwargs):
-        key = (str(ts.device), ts.dtype)
+        # the map is kept in float32: the denoiser embeds float timesteps anyway (nn.py:113), so one gather replaces the
+        # reference's integer gather + cast (exact: indices < 2^24)
+        key = str(ts.device)
         m = self._maps.get(key)
         if m is None:
-            m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+            m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=th.float32)
         new_ts = m[ts]
         if self.rescale_timesteps:
-            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
+            new_ts = new_ts * (1000.0 / self.original_num_steps)
         return self.model(x, new_ts, **kwargs)
