@@ -268,9 +268,18 @@ constexpr int W2_HH = W2_TH + 2, W2_HW = W2_TW + 2;
 constexpr int W2_AELEMS = W2_HH * W2_HW * W_LD;
 constexpr int W2_ITEMS = W2_HH * W2_HW * (W_KC / 4);
 constexpr int W2_ITEMS_PT = (W2_ITEMS + 255) / 256;       // halo float4 items per thread and chunk (6)
+constexpr int W2_ABUF = W2_ITEMS_PT * 32 * W_LD;          // LDS buffer stride: 6 rounds x 32 pixels, so no store of a round needs a predicate
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef W_TIMING
+__device__ unsigned long long* g_wtime;       // tools/wino_ubench.hip: per block {entry, k-loop begin, k-loop end, exit} (wall clock) + hw id
+#define W_STAMP(k) if (threadIdx.x == 0) g_wtime[size_t(blockIdx.x) * 8 + (k)] = wall_clock64();
+#else
+#define W_STAMP(k)
+#endif
 __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * W2_AELEMS];
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_ABUF + W2_ITEMS_PT * 256];
+    W_STAMP(0)
     // workgroup i runs on XCD i % 8 (each XCD has its own L2): give every XCD a contiguous range of logical blocks, so
     // that the two 64-channel column blocks of a pixel tile and the neighbouring tiles (shared halo) hit the same L2
     int bid = blockIdx.x;
@@ -293,35 +302,56 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     const int fh = wid & 1, wn = wid >> 1;
     const int i = lane & 31, half = lane >> 5;
     const int tr = i >> 3, tc = i & 7;
-    // patch rows this wave needs: fh, fh+1, fh+2 (u0,u1 need d0,d1,d2; u2,u3 need d1,d2,d3)
-    const int patch0 = ((2 * tr + fh) * W2_HW + 2 * tc) * W_LD + half * 4;
+    // The wave's two frequency rows need three rows of the 4x4 patch: u0 = d0 - d2, u1 = d1 + d2 (fh = 0) or
+    // u2 = d2 - d1, u3 = d1 - d3 (fh = 1).  Both are t0 = x - y, t1 = y + sgn * z with the rows picked per wave
+    // (x, y, z) = (d0, d2, d1) / (d2, d1, d3): the choice lives in three LDS addresses, the loop has no branch.
+    const int prow = (2 * tr * W2_HW + 2 * tc) * W_LD + half * 4;
+    const int px0 = prow + (fh ? 2 : 0) * W2_HW * W_LD, py0 = prow + (fh ? 1 : 2) * W2_HW * W_LD, pz0 = prow + (fh ? 3 : 1) * W2_HW * W_LD;
+    const float sgn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(fh ? 0xBF800000 : 0x3F800000));
 
     const int n32_total = (cout + 31) / 32;
     int n32 = ntile * 2 + wn;
     const bool n_live = n32 < n32_total;
     if (!n_live) n32 = n32_total - 1;
     const int k8_total = cin / 8;
-    const float* ub = J.wgt + ((size_t(n32) * k8_total) * 16 + fh * 8) * 256 + lane * 4;
+    // weights: this wave's fragments of step k8, frequency f sit (k8 * 16 + f) KB into its slab; lane * 16 bytes is the only VGPR
+    const float* ub = J.wgt + ((size_t(n32) * k8_total) * 16 + fh * 8) * 256;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, k8_total * 16 * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wfrag = [&](int step, int f) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (step * 16 + f) * 1024, 0));
+    };
     const float* inb = J.in + size_t(b) * h * w * cin;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto item_load = [&](int it, int ch) -> f32x4 {
-        const int idx = it * 256 + tid;
-        const int pix = idx >> 3, q = idx & 7;
+    // Halo staging.  Round `it` gives a thread the float4 (pixel it*32 + tid/8, channel quad tid%8) of the 10x18-pixel
+    // halo.  The loads are raw buffer loads: one byte offset per round in a VGPR, the chunk offset in an SGPR, and an
+    // offset beyond the descriptor's range for everything outside the image (or past the halo), which the hardware
+    // answers with zeros - the conv's padding costs no select and no predicate, and nothing depends on the loaded
+    // data until the ds_write at the end of the k-step.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, h * w * cin * 4, 0x00020000);
+    // The six byte offsets of a thread live in LDS behind the two halo buffers (a k-step fetches its pair with one
+    // ds_read_b64): six more live VGPRs made the allocator spill, and a scratch reload waits vmcnt(0) inside the k-loop.
+    unsigned* gtab = reinterpret_cast<unsigned*>(smem + 2 * W2_ABUF);
+    auto item_offset = [&](int it) -> unsigned {
+        const int pix = it * 32 + (tid >> 3);
         const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        const bool ok = idx < W2_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        f32x4 v = wg4(inb + (size_t(ok ? gy : 0) * w + (ok ? gx : 0)) * cin + ch * W_KC + q * 4)[0];
-        return ok ? v : zero4;
+        const bool ok = pix < W2_HH * W2_HW && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        return ok ? unsigned((gy * w + gx) * cin + (tid & 7) * 4) * 4u : 0x80000000u;
+    };
+    const int lds_w = (tid >> 3) * W_LD + (tid & 7) * 4;
+    auto item_load = [&](unsigned off, int ch) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, ch * (W_KC * 4), 0));
     };
     auto item_store = [&](int it, int buf, f32x4 v) {
-        const int idx = it * 256 + tid;
-        if (idx < W2_ITEMS) *reinterpret_cast<f32x4*>(smem + buf * W2_AELEMS + (idx >> 3) * W_LD + (idx & 7) * 4) = v;
+        *reinterpret_cast<f32x4*>(smem + buf * W2_ABUF + lds_w + it * (32 * W_LD)) = v;
     };
-    // column pass for this wave's two frequency rows from patch rows r0,r1,r2 (= d[fh], d[fh+1], d[fh+2])
-    auto col_pair = [&](const f32x4& r0, const f32x4& r1, const f32x4& r2, f32x4& t0, f32x4& t1) {
-        if (fh == 0) { t0 = r0 - r2; t1 = r1 + r2; }      // u0 = d0 - d2, u1 = d1 + d2
-        else         { t0 = r1 - r0; t1 = r0 - r2; }      // u2 = d2 - d1, u3 = d1 - d3
+    auto col_pair = [&](const f32x4& x, const f32x4& y, const f32x4& z, f32x4& t0, f32x4& t1) {
+        t0 = x - y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t1[e] = fmaf(sgn, z[e], y[e]);
+        asm volatile("" : "+v"(t0), "+v"(t1));            // computed here: keeps the three raw rows from staying live until the row pass
     };
 
     f32x16 acc[8];
@@ -332,48 +362,71 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
 
     const int nchunks = cin / W_KC;
 #pragma unroll
-    for (int it = 0; it < W2_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+    for (int it = 0; it < W2_ITEMS_PT; ++it) {
+        const unsigned off = item_offset(it);
+        gtab[it * 256 + tid] = off;
+        item_store(it, 0, item_load(off, 0));
+    }
     __syncthreads();
     f32x4 VA[8], VB[8], ring[8];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + patch0 + (0 * W2_HW + bb) * W_LD);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(smem + patch0 + (1 * W2_HW + bb) * W_LD);
-        const f32x4 r2 = *reinterpret_cast<const f32x4*>(smem + patch0 + (2 * W2_HW + bb) * W_LD);
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + px0 + bb * W_LD);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(smem + py0 + bb * W_LD);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(smem + pz0 + bb * W_LD);
         col_pair(r0, r1, r2, VA[bb], VA[4 + bb]);
     }
     wino_row_pass(VA); wino_row_pass(VA + 4);
 #pragma unroll
-    for (int f = 0; f < 8; ++f) ring[f] = wg4(ub + f * 256)[0];
+    for (int f = 0; f < 8; ++f) { ring[f] = wfrag(0, f); __builtin_amdgcn_sched_barrier(0); }   // in order: the loop waits for fragment 0 only
 
+    // One k-step = 32 slots of {one MFMA + a small piece of the other work}, pinned with sched_barrier: the wave issues
+    // in order, so work placed between two MFMAs runs in the shadow of the first (64 cycles) and the pipe never waits
+    // for it.  Per step: 12 patch reads + column pass for the NEXT step's operands (slots of f = 0..3), the row passes
+    // (f = 4, 5), 8 weight fragments (one per f), 2 halo loads whose data is only touched by the ds_write at the end.
+#define W2_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
+#define W2_PIN(v) asm volatile("" : "+v"(v))
 #define WINO2_STEP(Vc, Vn, K8)                                                                                        \
     {                                                                                                                 \
         const int step = chunk * 4 + (K8);                                                                            \
         const int nstep = (K8) < 3 ? step + 1 : gnext * 4;                                                            \
-        const int nbuf = ((K8) == 3 ? (chunk + 1) : chunk) & 1;                                                       \
-        const float* nsrc = smem + nbuf * W2_AELEMS + patch0 + (((K8) + 1) & 3) * 8;                                    \
-        f32x4 pf[2], cr0, cr1, cr2;                                                                                   \
+        if ((K8) == 3) { ax += tog; ay += tog; az += tog; tog = -tog; }      /* the next patch is in the other buffer */ \
+        constexpr int koff = (((K8) + 1) & 3) * 32;                                                                   \
         constexpr int it0 = (K8) * 2, itn = (K8) == 3 ? 0 : 2;                                                        \
-        _Pragma("unroll") for (int t = 0; t < itn; ++t) pf[t] = item_load(it0 + t, gnext);                            \
+        f32x4 pf[2], cx, cy, cz;                                                                                      \
+        unsigned g0 = 0, g1 = 0;                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 8; ++f) {                                                               \
-            if (f < 4) {                                                     /* next patch: column f, 3 rows */       \
-                cr0 = *reinterpret_cast<const f32x4*>(nsrc + (0 * W2_HW + f) * W_LD);                                   \
-                cr1 = *reinterpret_cast<const f32x4*>(nsrc + (1 * W2_HW + f) * W_LD);                                   \
-                cr2 = *reinterpret_cast<const f32x4*>(nsrc + (2 * W2_HW + f) * W_LD);                                   \
-            }                                                                                                         \
             const f32x4 bq = ring[f];                                                                                 \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][e], bq[e], acc[f], 0, 0, 0);                      \
-            ring[f] = wg4(ub + (size_t(nstep) * 16 + f) * 256)[0];           /* same frequency, next step */          \
-            if (f < 4) col_pair(cr0, cr1, cr2, Vn[f], Vn[4 + f]);                                                     \
-            if (f == 5) wino_row_pass(Vn);                                                                            \
-            if (f == 6) wino_row_pass(Vn + 4);                                                                        \
+            /* slot 0 */                                                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][0], bq[0], acc[f], 0, 0, 0);                          \
+            if (f < 4) { cx = W2_LDS4(ax + koff + f * (W_LD * 4)); cy = W2_LDS4(ay + koff + f * (W_LD * 4)); cz = W2_LDS4(az + koff + f * (W_LD * 4)); } \
+            if (f == 0 && itn) { g0 = gtab[it0 * 256 + tid]; g1 = gtab[(it0 + 1) * 256 + tid]; }                      \
+            if (f == 4) { const f32x4 d0 = Vn[0], d2 = Vn[2]; Vn[0] = d0 - d2; W2_PIN(Vn[0]); rp = Vn[1] + d2; W2_PIN(rp); rq = d2 - Vn[1]; W2_PIN(rq); } \
+            if (f == 5) { const f32x4 d0 = Vn[4], d2 = Vn[6]; Vn[4] = d0 - d2; W2_PIN(Vn[4]); rp = Vn[5] + d2; W2_PIN(rp); rq = d2 - Vn[5]; W2_PIN(rq); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            /* slot 1 */                                                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][1], bq[1], acc[f], 0, 0, 0);                          \
+            ring[f] = wfrag((W_ABL & 8) ? 0 : nstep, f);                     /* same frequency, next step */          \
+            if (f == 1 && itn) { pf[0] = (W_ABL & 16) ? zero4 : item_load(g0, gnext); pf[1] = (W_ABL & 16) ? zero4 : item_load(g1, gnext); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            /* slot 2 */                                                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][2], bq[2], acc[f], 0, 0, 0);                          \
+            if (f < 4) { Vn[f] = cx - cy; W2_PIN(Vn[f]); }                                                            \
+            if (f == 4) { Vn[3] = Vn[1] - Vn[3]; W2_PIN(Vn[3]); Vn[1] = rp; Vn[2] = rq; }                             \
+            if (f == 5) { Vn[7] = Vn[5] - Vn[7]; W2_PIN(Vn[7]); Vn[5] = rp; Vn[6] = rq; }                             \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            /* slot 3 */                                                                                              \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][3], bq[3], acc[f], 0, 0, 0);                          \
+            if (f < 4) { _Pragma("unroll") for (int e = 0; e < 4; ++e) Vn[4 + f][e] = fmaf(sgn, cz[e], cy[e]); W2_PIN(Vn[4 + f]); } \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
         }                                                                                                             \
         _Pragma("unroll") for (int t = 0; t < itn; ++t) item_store(it0 + t, (chunk + 1) & 1, pf[t]);                   \
         if ((K8) == 2) __syncthreads();                                                                               \
     }
 
+    int ax = px0 * 4, ay = py0 * 4, az = pz0 * 4, tog = W2_ABUF * 4;          // byte offsets of the patch rows in the buffer being read
+    f32x4 rp, rq;
+    W_STAMP(1)
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int gnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
         WINO2_STEP(VA, VB, 0)
@@ -382,6 +435,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         WINO2_STEP(VB, VA, 3)
     }
 #undef WINO2_STEP
+#undef W2_LDS4
+#undef W2_PIN
+    W_STAMP(2)
 
     // ---- epilogue.  M[u][v] = acc[ui*4+v] with u = 2*fh + ui.  Output row y of a tile needs P[y][v]:
     //   P[0][v] = M0 + M1 + M2,  P[1][v] = M1 - M2 - M3.
@@ -465,6 +521,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
             dst[0] = double(gs); dst[1] = double(gss);
         }
     }
+    W_STAMP(3)
+#ifdef W_TIMING
+    if (threadIdx.x == 0) g_wtime[size_t(blockIdx.x) * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+#endif
 }
 
 // ------------------------------------------------------------------ host side
@@ -518,6 +578,7 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st) {
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
+        S3D_CHECK(size_t(J.h) * J.w * a.cin * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wino conv: a plane of one sample must stay below 2 GiB");
         J.tiles_x = (J.w + tw - 1) / tw;
         J.tiles_per_img = J.tiles_x * ((J.h + th - 1) / th);
         J.n_tiles_n = (a.cout + 63) / 64;

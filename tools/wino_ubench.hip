@@ -24,6 +24,9 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
         if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
     }
+#ifdef W_TIMING
+    unsigned long long* tb; CK(hipMalloc(&tb, size_t(1 << 16) * 64)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_wtime), &tb, sizeof tb));
+#endif
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) launch_conv_wino(a, 0);
     CK(hipDeviceSynchronize());
@@ -34,6 +37,28 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     double us = ms * 1e3 / iters;
     double fl = 2.0 * 9 * cin * cout * npix;
     printf("wino cin=%4d cout=%4d hw=%3d B=%d extras=%d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF\n", cin, cout, hw, B, extras, us, fl / us / 1e6, fl * 4 / 9 / us / 1e6);
+#ifdef W_TIMING
+    {   // per-block phase times of one launch (wall_clock64 ticks of 10 ns)
+        int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
+        launch_conv_wino(a, 0); CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> t(size_t(blocks) * 8);
+        CK(hipMemcpy(t.data(), tb, t.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t3 = 0;
+        for (int i = 0; i < blocks; ++i) { t0 = std::min(t0, t[i * 8]); t3 = std::max(t3, t[i * 8 + 3]); }
+        double sp[2] = {0, 0}, sk[2] = {0, 0}, se[2] = {0, 0}; int n[2] = {0, 0};
+        std::vector<int> percu(8 * 64, 0);
+        for (int i = 0; i < blocks; ++i) {
+            const int late = (t[i * 8] - t0) > 300;                        // started more than 3 us after the first block
+            sp[late] += (t[i * 8 + 1] - t[i * 8]) * 0.01; sk[late] += (t[i * 8 + 2] - t[i * 8 + 1]) * 0.01; se[late] += (t[i * 8 + 3] - t[i * 8 + 2]) * 0.01; ++n[late];
+        }
+        printf("    timing: span %.1f us; first-wave blocks %d: prologue %.1f k-loop %.1f epilogue %.1f us; later blocks %d: prologue %.1f k-loop %.1f epilogue %.1f us\n",
+               (t3 - t0) * 0.01, n[0], sp[0] / std::max(n[0], 1), sk[0] / std::max(n[0], 1), se[0] / std::max(n[0], 1), n[1], sp[1] / std::max(n[1], 1), sk[1] / std::max(n[1], 1), se[1] / std::max(n[1], 1));
+        // start-time histogram in 10 us bins
+        int hist[16] = {0}; for (int i = 0; i < blocks; ++i) hist[std::min<unsigned long long>(15, (t[i * 8] - t0) / 1000)]++;
+        printf("    block starts per 10 us:"); for (int i = 0; i < 16; ++i) printf(" %d", hist[i]); printf("\n");
+        CK(hipFree(tb));
+    }
+#endif
     CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
 int main() {
