@@ -510,7 +510,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
-            if (conv_use_wino() && a.job[0].wgt_wino) {
+            if (conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) {   // (its epilogue moves channel quads; GroupNorm'd layers always qualify)
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino;
                 return launch_conv_wino(a, st);
             }

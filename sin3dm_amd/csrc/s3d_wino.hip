@@ -278,7 +278,9 @@ __device__ unsigned long long* g_wtime;       // tools/wino_ubench.hip: per bloc
 #define W_STAMP(k)
 #endif
 __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * W2_ABUF + W2_ITEMS_PT * 256];
+    // k-loop: two halo buffers + the halo offsets; epilogue: two [128 pixels][64 channels] share images (64 KB, two blocks per CU)
+    __shared__ __attribute__((aligned(16))) float smem[2 * W2_TH * W2_TW * 64];
+    static_assert(2 * W2_ABUF + W2_ITEMS_PT * 256 <= 2 * W2_TH * W2_TW * 64, "LDS plan");
     W_STAMP(0)
     // workgroup i runs on XCD i % 8 (each XCD has its own L2): give every XCD a contiguous range of logical blocks, so
     // that the two 64-channel column blocks of a pixel tile and the neighbouring tiles (shared halo) hit the same L2
@@ -361,6 +363,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
     const int nchunks = cin / W_KC;
+    f32x4 VA[8], VB[8], ring[8];
+    // first weight fragments before anything else (their latency hides behind the halo staging); in order, so that the
+    // loop's first wait is for fragment 0 only
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { ring[f] = wfrag(0, f); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int it = 0; it < W2_ITEMS_PT; ++it) {
         const unsigned off = item_offset(it);
@@ -368,7 +375,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         item_store(it, 0, item_load(off, 0));
     }
     __syncthreads();
-    f32x4 VA[8], VB[8], ring[8];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + px0 + bb * W_LD);
@@ -377,8 +383,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         col_pair(r0, r1, r2, VA[bb], VA[4 + bb]);
     }
     wino_row_pass(VA); wino_row_pass(VA + 4);
-#pragma unroll
-    for (int f = 0; f < 8; ++f) { ring[f] = wfrag(0, f); __builtin_amdgcn_sched_barrier(0); }   // in order: the loop waits for fragment 0 only
 
     // One k-step = 32 slots of {one MFMA + a small piece of the other work}, pinned with sched_barrier: the wave issues
     // in order, so work placed between two MFMAs runs in the shadow of the first (64 cycles) and the pipe never waits
@@ -439,9 +443,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
 #undef W2_PIN
     W_STAMP(2)
 
-    // ---- epilogue.  M[u][v] = acc[ui*4+v] with u = 2*fh + ui.  Output row y of a tile needs P[y][v]:
-    //   P[0][v] = M0 + M1 + M2,  P[1][v] = M1 - M2 - M3.
-    // Wave fh=0 finishes y=0 and needs M2 from its partner; wave fh=1 finishes y=1 and needs M1.
+    // ---- epilogue.  M[u][v] = acc[ui*4+v] with u = 2*fh + ui.  Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]]:
+    //   row pass  P[0][v] = M0 + M1 + M2,  P[1][v] = M1 - M2 - M3;   column pass  Y[y][0] = P0 + P1 + P2,  Y[y][1] = P1 - P2 - P3.
+    // Both passes are linear, so each wave pushes its two frequency rows through them alone: wave fh = 0 holds
+    // (M0 + M1, M1), wave fh = 1 holds (M2, -M2 - M3) as its shares of (P[0], P[1]); an output is the sum of the two
+    // waves' shares.  The shares go to LDS as two [128 pixels][64 channels] images (ONE barrier), and the tile is
+    // finished by threads that own 4 consecutive channels of a pixel column: the rank-1 tables, the residual and the
+    // output move as 16-byte accesses (1 KB per wave instruction; the MFMA layout would give 4-byte ones and four times
+    // as many memory instructions, which is what the epilogue spent its time on), requested before the barrier.
     const float* __restrict__ p_bias = J.bias;
     const float* __restrict__ p_bbias = J.bbias;
     const float* __restrict__ p_rcol = J.rcol;
@@ -449,76 +458,101 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     const float* __restrict__ p_res = J.res;
     float* __restrict__ p_out = J.out;
     double* p_gn = J.gn_part;
-    const int co = (ntile * 2 + wn) * 32 + i;
-    const bool co_ok = n_live && co < cout;
-    const int coc = co_ok ? co : 0;
-    float base = p_bias ? p_bias[coc] : 0.f;
-    if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
-    float gs = 0.f, gss = 0.f;
-    float* xw = smem + wid * (16 * 64);                  // this wave's exchange slot: [4 rows][4 v][64 lanes]
-    const float* xr = smem + (wid ^ 1) * (16 * 64);      // partner (same wn, other fh)
+    float* img0 = smem;                                  // shares of the even output rows' owner ... indexed [row parity][pixel][64]
     __syncthreads();                                     // all patch reads of the last step are done
+    W_STAMP(5)
+    {
+        // lane (i, half) holds channel wn*32 + i of Winograd tiles ti(r) = (r&3) + 8*(r>>2) + 4*half; pixel (2*(ti>>3) + y, 2*(ti&7) + x)
+        float* mine = img0 + wn * 32 + i;                // [share kind][pixel][64]: kind 0 = shares of finished rows, 1 = shares sent
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        float own[4][4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+        for (int r = 0; r < 16; ++r) {
+            float kp[4], sd[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int r = rg * 4 + rr;
-                const float ma = acc[0 * 4 + v][r], mb = acc[1 * 4 + v][r];   // fh=0: M0, M1 ; fh=1: M2, M3
-                own[rr][v] = fh == 0 ? ma + mb : -ma - mb;
-                xw[(rr * 4 + v) * 64 + lane] = fh == 0 ? mb : ma;            // send M1 (fh=0) or M2 (fh=1)
+                const float ma = acc[v][r], mb = acc[4 + v][r];              // fh = 0: M0, M1 ; fh = 1: M2, M3
+                const float sm = ma + mb;
+                kp[v] = fh == 0 ? sm : -sm;                                   // share of P[fh]
+                sd[v] = fh == 0 ? mb : ma;                                    // share of P[1 - fh]
             }
-        __syncthreads();
-        float val[8]; bool ok[8]; size_t oidx[8]; int yy_[8], xx_[8];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = rg * 4 + rr;
             const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int y = ty0 + 2 * (ti >> 3) + fh, xt = tx0 + 2 * (ti & 7);
-            float P[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) P[v] = own[rr][v] + xr[(rr * 4 + v) * 64 + lane];
-            const float Y0 = P[0] + P[1] + P[2], Y1 = P[1] - P[2] - P[3];
-#pragma unroll
-            for (int xx = 0; xx < 2; ++xx) {
-                const int k = rr * 2 + xx, x = xt + xx;
-                yy_[k] = y; xx_[k] = x;
-                ok[k] = y < h && x < w && co_ok;
-                oidx[k] = ok[k] ? ((size_t(b) * h + y) * w + x) * cout + co : 0;
-                val[k] = (xx == 0 ? Y0 : Y1) + base;
-            }
+            const int pk = ((2 * (ti >> 3) + fh) * W2_TW + 2 * (ti & 7)) * 64;          // own row (parity fh)
+            const int ps = ((2 * (ti >> 3) + 1 - fh) * W2_TW + 2 * (ti & 7)) * 64;      // partner's row
+            mine[pk] = kp[0] + kp[1] + kp[2];
+            mine[pk + 64] = kp[1] - kp[2] - kp[3];
+            mine[W2_TH * W2_TW * 64 + ps] = sd[0] + sd[1] + sd[2];
+            mine[W2_TH * W2_TW * 64 + ps + 64] = sd[1] - sd[2] - sd[3];
         }
-        float tc_[8], tr_[8], ts[8];
+    }
+    // finishing thread: channels co4..co4+3 of pixel column xl, rows 0..7
+    const int quad = tid & 15, xl = tid >> 4;
+    const int co4 = ntile * 64 + quad * 4;
+    const bool c_ok = co4 < cout;
+    const int coc = c_ok ? co4 : 0;
+    const int x = tx0 + xl;
+    const bool x_ok = x < w && c_ok;
+    const int xc = x < w ? x : 0;
+    f32x4 base4 = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+    if (p_bbias) base4 += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+    f32x4 tcol[W2_TH], trow[W2_TH], tres[W2_TH];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { tc_[k] = 0.f; tr_[k] = 0.f; ts[k] = 0.f; }
-        if (p_rcol) {
+    for (int yl = 0; yl < W2_TH; ++yl) { tcol[yl] = zero4; trow[yl] = zero4; tres[yl] = zero4; }
+    if (p_rcol) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tc_[k] = p_rcol[ok[k] ? ((size_t(b) * w + xx_[k]) * 4 + w_edge_variant(yy_[k], h)) * cout + co : 0];
+        for (int yl = 0; yl < W2_TH; ++yl) {
+            const int y = ty0 + yl;
+            tcol[yl] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + w_edge_variant(y < h ? y : 0, h)) * cout + coc);
         }
-        if (p_rrow) {
+    }
+    if (p_rrow) {
+        const int vx = w_edge_variant(xc, w);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tr_[k] = p_rrow[ok[k] ? ((size_t(b) * h + yy_[k]) * 4 + w_edge_variant(xx_[k], w)) * cout + co : 0];
+        for (int yl = 0; yl < W2_TH; ++yl) {
+            const int y = ty0 + yl;
+            trow[yl] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
         }
-        if (p_res) {
+    }
+    if (p_res) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ts[k] = p_res[oidx[k]];
+        for (int yl = 0; yl < W2_TH; ++yl) {
+            const int y = ty0 + yl;
+            tres[yl] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
         }
+    }
+    __syncthreads();                                     // both share images are complete
+    W_STAMP(6)
+    f32x4 gs4 = zero4, gss4 = zero4;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float v = val[k] + ((tc_[k] + tr_[k]) + ts[k]);
-            if (ok[k]) { p_out[oidx[k]] = v; gs += v; gss = fmaf(v, v, gss); }
+    for (int yl = 0; yl < W2_TH; ++yl) {
+        const int y = ty0 + yl;
+        const float* sp = img0 + (yl * W2_TW + xl) * 64 + quad * 4;
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + W2_TH * W2_TW * 64);
+        const f32x4 v = ((ka + kb) + base4) + ((tcol[yl] + trow[yl]) + tres[yl]);
+        if (x_ok && y < h) {
+            *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
+            gs4 += v; gss4 += v * v;
         }
-        __syncthreads();                                 // exchange slots are rewritten next round
     }
     if (p_gn) {
-        gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
-        for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
-        if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
-            const int part = tile_idx * 2 + fh;
-            double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
-            dst[0] = double(gs); dst[1] = double(gss);
+        // per wave: 4 pixel columns (lanes l, l+16, l+32, l+48) x 8 rows of 16 channel quads; one part per wave
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gs4[e] += __shfl_xor(gs4[e], 16, 64); gss4[e] += __shfl_xor(gss4[e], 16, 64);
+            gs4[e] += __shfl_xor(gs4[e], 32, 64); gss4[e] += __shfl_xor(gss4[e], 32, 64);
+        }
+        const int sg = args.gn_sg;
+        const int part = tile_idx * 4 + wid;
+        double* dst = p_gn + (size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub * 2;
+        if (sg >= 4) {
+            float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
+            for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+            if (lane < 16 && c_ok && (co4 % sg) == 0) { dst[(co4 / sg) * 2] = double(s); dst[(co4 / sg) * 2 + 1] = double(ss); }
+        } else if (lane < 16 && c_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                if (sg == 2) { dst[((co4 + e) / 2) * 2] = double(gs4[e] + gs4[e + 1]); dst[((co4 + e) / 2) * 2 + 1] = double(gss4[e] + gss4[e + 1]); }
+                else { dst[(co4 + e) * 2] = double(gs4[e]); dst[(co4 + e) * 2 + 1] = double(gss4[e]);
+                       dst[(co4 + e + 1) * 2] = double(gs4[e + 1]); dst[(co4 + e + 1) * 2 + 1] = double(gss4[e + 1]); }
+            }
         }
     }
     W_STAMP(3)
@@ -541,7 +575,7 @@ bool conv_use_wino() { return wino_variant() != 0 && !conv_use_naive(); }
 
 void wino_gn_parts(const Geo& g, int nparts[3]) {
     for (int p = 0; p < 3; ++p) {
-        if (wino_variant() == 2) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 2;
+        if (wino_variant() == 2) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 4;   // one per wave
         else nparts[p] = ((g.w[p] + W_T - 1) / W_T) * ((g.h[p] + W_T - 1) / W_T) * 2;
     }
 }
@@ -572,7 +606,7 @@ size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, in
 }
 
 int launch_conv_wino(ConvArgs& a, hipStream_t st) {
-    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
     const bool two = wino_variant() == 2;
     const int th = two ? W2_TH : W_T, tw = two ? W2_TW : W_T;
     int blocks = 0;
