@@ -195,7 +195,8 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& a, Tri& y, 
 struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);
 
-int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st);
+// part != null: pixel-chunk form that also emits the GroupNorm partials of y (kGnChunks parts per plane, 32 groups)
+int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials* part = nullptr);
 // bilinear (align_corners=False) resize into a channel slice of a wider NHWC tensor
 int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, int ho, int wo, int out_cstride,
                     int out_coff, hipStream_t st);

@@ -52,6 +52,37 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w,
     return 0;
 }
 
+// Block tail shared by the kernels that emit GroupNorm partials for a pixel chunk: thread (q, l) holds {sum, sumsq} of
+// channel quad q over its pixels; the block adds them per group in a fixed order and writes out[32 groups][2].
+__device__ __forceinline__ void gn_chunk_reduce(double* sm, const double s[4], const double ss[4], int q, int l, int C, int pl,
+                                                double* out) {
+    for (int k = 0; k < 4; ++k) {
+        sm[(size_t(l) * C + 4 * q + k) * 2 + 0] = s[k];
+        sm[(size_t(l) * C + 4 * q + k) * 2 + 1] = ss[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x, cg = C / 32;
+        double S = 0, SS = 0;
+        for (int ll = 0; ll < pl; ++ll)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) {
+                S += sm[(size_t(ll) * C + c) * 2 + 0];
+                SS += sm[(size_t(ll) * C + c) * 2 + 1];
+            }
+        out[g * 2] = S; out[g * 2 + 1] = SS;
+    }
+}
+__device__ __forceinline__ void gn_acc(double s[4], double ss[4], const float4& v) {
+    s[0] += v.x; ss[0] += double(v.x) * v.x;
+    s[1] += v.y; ss[1] += double(v.y) * v.y;
+    s[2] += v.z; ss[2] += double(v.z) * v.z;
+    s[3] += v.w; ss[3] += double(v.w) * v.w;
+}
+static void thread_shape(int C, int& cq, int& pl) {
+    cq = C / 4;
+    pl = cq >= 256 ? 1 : 256 / cq;
+}
+
 // ------------------------------------------------------------------ in_conv
 // decompose_featmaps (src/utils/triplane_util.py:20-25) + TriplaneConv(in, ch, 1x1, no rollout)
 // (src/diffusion/unet_triplane.py:378, 482).  One thread = one pixel x 4 output channels.
@@ -134,26 +165,7 @@ __global__ void k_gn_partials(GnPartArgs a) {
         s[2] += v.z; ss[2] += double(v.z) * v.z;
         s[3] += v.w; ss[3] += double(v.w) * v.w;
     }
-    for (int k = 0; k < 4; ++k) {
-        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 0] = s[k];
-        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 1] = ss[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        const int g = threadIdx.x, cg = a.C / 32;
-        double S = 0, SS = 0;
-        for (int ll = 0; ll < a.pl; ++ll)
-            for (int c = g * cg; c < (g + 1) * cg; ++c) {
-                S += sm[(size_t(ll) * a.C + c) * 2 + 0];
-                SS += sm[(size_t(ll) * a.C + c) * 2 + 1];
-            }
-        double* o = a.part + (((size_t(b) * 3 + p) * kGnChunks + chunk) * 32 + g) * 2;
-        o[0] = S; o[1] = SS;
-    }
-}
-static void thread_shape(int C, int& cq, int& pl) {
-    cq = C / 4;
-    pl = cq >= 256 ? 1 : 256 / cq;
+    gn_chunk_reduce(sm, s, ss, q, l, a.C, a.pl, a.part + ((size_t(b) * 3 + p) * kGnChunks + chunk) * 64);
 }
 int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st) {
     GnPartArgs a;
@@ -400,7 +412,30 @@ __global__ void k_avgpool(PoolArgs a) {
     reinterpret_cast<float4*>(a.y[p])[((size_t(b) * ho + yo) * wo + xo) * a.cq + q] = o;
     (void)ho;
 }
-int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st) {
+__global__ void k_avgpool_gn(PoolArgs a, double* part, int pl) {        // pixel-chunk form that also emits GroupNorm partials of y
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    const int ho = a.h[p] / 2, wo = a.w[p] / 2, npix = ho * wo;
+    const int per = (npix + kGnChunks - 1) / kGnChunks;
+    const int p0 = chunk * per, p1 = min(npix, p0 + per);
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    const float4* xb = reinterpret_cast<const float4*>(a.x[p]) + size_t(b) * a.h[p] * a.w[p] * a.cq + q;
+    float4* yb = reinterpret_cast<float4*>(a.y[p]) + size_t(b) * npix * a.cq + q;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int pix = p0 + l; pix < p1; pix += pl) {
+        const int yo = pix / wo, xo = pix - yo * wo;
+        const float4* src = xb + (size_t(2 * yo) * a.w[p] + 2 * xo) * a.cq;
+        const float4 v00 = src[0], v01 = src[a.cq], v10 = src[size_t(a.w[p]) * a.cq], v11 = src[size_t(a.w[p] + 1) * a.cq];
+        float4 o;
+        o.x = (v00.x + v01.x + v10.x + v11.x) * 0.25f; o.y = (v00.y + v01.y + v10.y + v11.y) * 0.25f;
+        o.z = (v00.z + v01.z + v10.z + v11.z) * 0.25f; o.w = (v00.w + v01.w + v10.w + v11.w) * 0.25f;
+        yb[size_t(pix) * a.cq] = o;
+        gn_acc(s, ss, o);
+    }
+    gn_chunk_reduce(reinterpret_cast<double*>(smem_raw), s, ss, q, l, a.cq * 4, pl, part + ((size_t(b) * 3 + p) * kGnChunks + chunk) * 64);
+}
+int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials* part) {
     PoolArgs a;
     a.cq = x.C / 4; a.B = B; a.begin[0] = 0;
     for (int p = 0; p < 3; ++p) {
@@ -409,6 +444,13 @@ int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st) {
     }
     long long n = a.begin[3] * B;
     if (!n) return 0;
+    if (part) {
+        int cq, pl; thread_shape(x.C, cq, pl);
+        S3D_CHECK(part->maxparts == kGnChunks && part->nsub == 32 && x.C % 32 == 0 && cq <= 1024, S3D_ERR_INVALID, "avgpool: GroupNorm partial layout");
+        hipLaunchKernelGGL(k_avgpool_gn, dim3(kGnChunks, 3, B), dim3(cq * pl), size_t(pl) * x.C * 2 * sizeof(double), st, a, part->p, pl);
+        S3D_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_avgpool, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

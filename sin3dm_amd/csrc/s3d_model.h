@@ -176,6 +176,23 @@ struct Fwd {
         for (int p = 0; p < 3; ++p) t.p[p] = ar().alloc<float>(size_t(B) * g.h[p] * g.w[p] * C);
         return t;
     }
+    // For a producer that writes kGnChunks GroupNorm partials of its output itself (avgpool; the chunked forms of in_conv and
+    // upsample+concat were 1.5x slower than flat kernel + read pass: 384 blocks cannot keep enough loads in flight):
+    // allocate the partials before the launch, finish() after it; the tensor then carries its statistics like a conv output.
+    struct ChunkStats { GnPartials part; GnStats gs; };
+    ChunkStats chunk_stats() {
+        ChunkStats c;
+        c.part.p = ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64);
+        c.part.maxparts = kGnChunks; c.part.nsub = 32;
+        for (int p = 0; p < 3; ++p) c.part.nparts[p] = kGnChunks;
+        c.gs.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+        return c;
+    }
+    int finish(const ChunkStats& c, Tri& t) {
+        t.gn = c.gs.mr;
+        if (ar().measuring) return 0;
+        return launch_gn_finalize(c.part, t.g, t.C, B, c.gs, st);
+    }
     // GroupNorm {mean, rstd} of x: taken from its producer's epilogue when available, otherwise one read pass.
     int stats_of(const Tri& x, GnStats& out) {
         if (x.gn) { out.mr = x.gn; return 0; }

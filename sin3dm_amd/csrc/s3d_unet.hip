@@ -233,7 +233,9 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             Tri d = f.alloc_tri(h.C, h.g.half());
             for (int p = 0; p < 3; ++p)
                 S3D_CHECK(d.g.h[p] > 0 && d.g.w[p] > 0, S3D_ERR_INVALID, "plane too small to downsample (level %d)", level);
-            if (!meas) S3D_TRY(launch_avgpool(h, B, d, st));
+            const Fwd::ChunkStats cs = f.chunk_stats();
+            if (!meas) S3D_TRY(launch_avgpool(h, B, d, st, &cs.part));
+            S3D_TRY(f.finish(cs, d));
             h = d;
         }
         Tri o;

@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs args) {
 // needs one 4-float exchange per output tile between the two waves through LDS.
 constexpr int W2_TH = 8, W2_TW = 16;                      // output tile: 4 x 8 Winograd tiles = one 32-row MFMA tile
 constexpr int W2_HH = W2_TH + 2, W2_HW = W2_TW + 2;
-constexpr int W2_AELEMS = W2_HH * W2_HW * W_LD;
 constexpr int W2_ITEMS = W2_HH * W2_HW * (W_KC / 4);
 constexpr int W2_ITEMS_PT = (W2_ITEMS + 255) / 256;       // halo float4 items per thread and chunk (6)
 constexpr int W2_ABUF = W2_ITEMS_PT * 32 * W_LD;          // LDS buffer stride: 6 rounds x 32 pixels, so no store of a round needs a predicate
