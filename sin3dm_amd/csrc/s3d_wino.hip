@@ -281,10 +281,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[2 * W2_TH * W2_TW * 64];
     static_assert(2 * W2_ABUF + W2_ITEMS_PT * 256 <= 2 * W2_TH * W2_TW * 64, "LDS plan");
     W_STAMP(0)
+    // The prologue and epilogue are short and latency-bound; a partner wave on the same SIMD that is in its k-loop is older
+    // and would win every VALU issue slot (priority, then age): run them at raised priority, the k-loop at 0.
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     // workgroup i runs on XCD i % 8 (each XCD has its own L2): give every XCD a contiguous range of logical blocks, so
     // that the two 64-channel column blocks of a pixel tile and the neighbouring tiles (shared halo) hit the same L2
     int bid = blockIdx.x;
-    if (args.xcd_swizzle) {
+    if (args.xcd_swizzle & 1) {
         const int chunk = int(gridDim.x) >> 3;
         if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
     }
@@ -373,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         gtab[it * 256 + tid] = off;
         item_store(it, 0, item_load(off, 0));
     }
+    W_STAMP(7)
     __syncthreads();
+    W_STAMP(4)
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(smem + px0 + bb * W_LD);
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     int ax = px0 * 4, ay = py0 * 4, az = pz0 * 4, tog = W2_ABUF * 4;          // byte offsets of the patch rows in the buffer being read
     f32x4 rp, rq;
     W_STAMP(1)
+    __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int gnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
         WINO2_STEP(VA, VB, 0)
@@ -440,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
 #undef WINO2_STEP
 #undef W2_LDS4
 #undef W2_PIN
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     W_STAMP(2)
 
     // ---- epilogue.  M[u][v] = acc[ui*4+v] with u = 2*fh + ui.  Y = A^T M A with A^T = [[1,1,1,0],[0,1,-1,-1]]:
@@ -556,7 +563,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
     }
     W_STAMP(3)
 #ifdef W_TIMING
-    if (threadIdx.x == 0) g_wtime[size_t(blockIdx.x) * 8 + 4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
 #endif
 }
 
@@ -619,7 +625,7 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    static const int xcd = getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1;
+    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
     if (two) hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);

@@ -45,16 +45,18 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         CK(hipMemcpy(t.data(), tb, t.size() * 8, hipMemcpyDeviceToHost));
         unsigned long long t0 = ~0ull, t3 = 0;
         for (int i = 0; i < blocks; ++i) { t0 = std::min(t0, t[i * 8]); t3 = std::max(t3, t[i * 8 + 3]); }
-        double sp[2] = {0, 0}, sk[2] = {0, 0}, se[2] = {0, 0}, e1[2] = {0, 0}, e2[2] = {0, 0}; int n[2] = {0, 0};
+        double sp[2] = {0, 0}, sk[2] = {0, 0}, se[2] = {0, 0}, e1[2] = {0, 0}, e2[2] = {0, 0}, q1[2] = {0, 0}, q2[2] = {0, 0}; int n[2] = {0, 0};
         std::vector<int> percu(8 * 64, 0);
         for (int i = 0; i < blocks; ++i) {
             const int late = (t[i * 8] - t0) > 300;                        // started more than 3 us after the first block
             sp[late] += (t[i * 8 + 1] - t[i * 8]) * 0.01; sk[late] += (t[i * 8 + 2] - t[i * 8 + 1]) * 0.01; se[late] += (t[i * 8 + 3] - t[i * 8 + 2]) * 0.01; ++n[late];
+            q1[late] += (t[i * 8 + 7] - t[i * 8]) * 0.01; q2[late] += (t[i * 8 + 4] - t[i * 8 + 7]) * 0.01;
             e1[late] += (t[i * 8 + 5] - t[i * 8 + 2]) * 0.01; e2[late] += (t[i * 8 + 6] - t[i * 8 + 5]) * 0.01;
         }
         printf("    timing: span %.1f us; first-wave blocks %d: prologue %.1f k-loop %.1f epilogue %.1f us; later blocks %d: prologue %.1f k-loop %.1f epilogue %.1f us\n",
                (t3 - t0) * 0.01, n[0], sp[0] / std::max(n[0], 1), sk[0] / std::max(n[0], 1), se[0] / std::max(n[0], 1), n[1], sp[1] / std::max(n[1], 1), sk[1] / std::max(n[1], 1), se[1] / std::max(n[1], 1));
         printf("    epilogue split (first / later): k-loop-end barrier %.1f / %.1f, transform + exchange + operand loads %.1f / %.1f us\n", e1[0] / std::max(n[0], 1), e1[1] / std::max(n[1], 1), e2[0] / std::max(n[0], 1), e2[1] / std::max(n[1], 1));
+        printf("    prologue split (first / later): setup + halo landed in LDS %.1f / %.1f, barrier %.1f / %.1f us\n", q1[0] / std::max(n[0], 1), q1[1] / std::max(n[1], 1), q2[0] / std::max(n[0], 1), q2[1] / std::max(n[1], 1));
         // start-time histogram in 10 us bins
         int hist[16] = {0}; for (int i = 0; i < blocks; ++i) hist[std::min<unsigned long long>(15, (t[i * 8] - t0) / 1000)]++;
         printf("    block starts per 10 us:"); for (int i = 0; i < 16; ++i) printf(" %d", hist[i]); printf("\n");
