@@ -1,0 +1,35 @@
+#!/bin/bash
+# Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r01'
+# Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
+R=${1:-r01}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/refresh
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline --profile-every 0"
+# 1. kernel trace + stats
+rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o t --output-format csv -- $B > /tmp/p1.log 2>&1
+cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/${R}_kernel_stats.csv
+python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 65 > $OUT/${R}_kernel_summary.txt
+# 2. HBM traffic: two PMC passes (counters only with --kernel-trace)
+P="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-every 0"
+rm -rf /tmp/p2 && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o t --output-format csv -- $P > /tmp/p2.log 2>&1
+rm -rf /tmp/p3 && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o t --output-format csv -- $P > /tmp/p3.log 2>&1
+python3 $ROOT/tools/pmc_traffic.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_traffic.json k_conv_wino2
+# 3. SQ counters
+rm -rf /tmp/p4 && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p4 -o t --output-format csv -- $P > /tmp/p4.log 2>&1
+{ echo "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 6 --warmup 2";
+  echo "MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)";
+  python3 $ROOT/tools/pmc_sq_summary.py $(find /tmp/p4 -name "*counter_collection.csv" | head -1); } > $OUT/${R}_pmc_sq_summary.txt
+cd $ROOT
+# 4. the headline line (uses profiles/<round>_pmc_traffic.json as committed; copy the new one in first for the traffic field)
+cp $OUT/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
+python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench.json
+# 5. other configurations, training, decode
+python3 tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/${R}_other_configs.txt
+{ python3 tools/bench_train.py 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
+python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${R}_decode_and_isosurface.txt
+# 6. Winograd kernel alone, with per-block phase times
+[ -x tools/ub_wino_t ] && timeout 120 tools/ub_wino_t > $OUT/${R}_wino_ubench_raw.txt
+ls -la $OUT
