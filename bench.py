@@ -186,7 +186,7 @@ def main():
                     # north_star also asks for the HBM-roofline fraction of the same kernel: PMC bytes / live launch time
                     "hbm_gbs": round(traffic / (prof.ms[0] / prof.launches[0] * 1e-3) / 1e9, 1) if traffic else None,
                     "hbm_frac_of_8TBs": round(traffic / (prof.ms[0] / prof.launches[0] * 1e-3) / 8e12, 4) if traffic else None,
-                    "kernel": ("k_conv_wino2 (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
+                    "kernel": (("k_conv_wino2" if os.environ.get("S3D_WINO") == "2" else "k_conv_wino4") + " (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
                               ", dense own-channel part of the rollout TriplaneConv)",
                     "avg_launch_us": round(prof.ms[0] / prof.launches[0] * 1e3, 2),
                     "launches_timed": int(prof.launches[0]),

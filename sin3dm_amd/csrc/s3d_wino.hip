@@ -5,18 +5,23 @@
 // against an fp64 direct convolution: 4.5e-7 relative (direct fp32: 2.8e-7), far inside the 1e-3 gate.
 //
 // Everything happens inside one kernel — no transformed tensors ever touch HBM:
-//   * block = 16x16 output pixels (8x8 Winograd tiles) x 64 output channels, 4 waves = 2 (tile halves) x 2 (32 couts);
-//   * the 18x18x32-channel input halo of a chunk sits in LDS; a lane owns ONE Winograd tile (MFMA row) and reads its
-//     4x4 patch as 16 ds_read_b128, applies B^T d B in registers (64 packed adds) and thereby holds the A operands
-//     of all 16 frequencies for 4 channels — already in the "lane half 0 takes k0..3, half 1 k4..7" order;
+//   * a block owns an 8x16-pixel output tile = 4x8 Winograd tiles = one 32-row MFMA tile; the 10x18x32-channel input
+//     halo of a K chunk sits in LDS; a lane owns ONE Winograd tile (MFMA row), reads its 4x4 patch with ds_read_b128,
+//     applies B^T d B in registers and thereby holds the A operands for 4 channels — already in the "lane half 0 takes
+//     k0..3, half 1 k4..7" order;
 //   * the transformed weights U = G g G^T are pre-packed on the host in MFMA *fragment order*, so a B operand is one
-//     fully coalesced 1 KB global load per (frequency, 8 channels) — no LDS, no barrier for weights;
-//   * a wave keeps 16 accumulators (one per frequency, 256 AGPRs) for its 32 tiles x 32 channels, so the inverse
-//     transform A^T M A needs only values the lane already holds; the epilogue then matches the direct kernel
-//     (bias, rank-1 rollout terms, residual, GroupNorm partial sums);
-//   * software pipeline inside the wave (one wave per SIMD): while the 64 MFMAs of a k-step run, the next step's
-//     patch is read and transformed, the weight fragments stream through an 8-deep register ring and a slice of the
-//     next chunk's halo is fetched; one barrier per 32-channel chunk.
+//     fully coalesced 1 KB load per (frequency, 8 channels) — no LDS, no barrier for weights;
+//   * the 16 frequencies of a (tile, 32 output channels) unit are split over several waves, so that two or three waves
+//     fit on every SIMD and cover each other's barriers and latency-bound phases:
+//       k_conv_wino4 (default)  four waves, one row of the 4x4 frequency grid each: 64 accumulator registers,
+//                               three 32-channel blocks per CU;
+//       k_conv_wino2 (S3D_WINO=2) two waves, two rows each: 128 accumulator registers, two 64-channel blocks per CU;
+//   * software pipeline inside a wave: a k-step is a sequence of pinned slots {one MFMA + a small piece of the other
+//     work} (next step's patch reads and transform, one weight fragment per frequency through a register ring, two halo
+//     loads); one barrier per 32-channel chunk;
+//   * the inverse transform is linear: every wave pushes its frequency rows through it alone and the shares meet in LDS,
+//     where threads owning 4 consecutive channels of a pixel finish the tile (bias, rank-1 rollout terms, residual,
+//     GroupNorm partial sums) with 16-byte accesses.
 #include "s3d_common.h"
 
 namespace s3d {
@@ -27,15 +32,10 @@ typedef const f32x4 __attribute__((address_space(1)))* wgf4;
 __device__ __forceinline__ wgf4 wg4(const float* p) { return (wgf4)(uintptr_t)p; }
 
 #ifndef W_ABL
-#define W_ABL 0                        // tools/wino_ubench.hip only: 1 no epilogue stores, 2 no epilogue, 4 no k-loop, 8 weights from one hot 16 KB, 16 no halo staging
+#define W_ABL 0                        // tools/wino_ubench.hip only (k_conv_wino2): 8 weights from one hot 16 KB, 16 no halo loads
 #endif
-constexpr int W_T = 16;                 // output tile side
-constexpr int W_H = W_T + 2;            // halo side
 constexpr int W_KC = 32;                // channels per chunk
 constexpr int W_LD = W_KC + 4;          // padded LDS pixel row (floats)
-constexpr int W_AELEMS = W_H * W_H * W_LD;
-constexpr int W_ITEMS = W_H * W_H * (W_KC / 4);           // float4 items per chunk
-constexpr int W_NIT = (W_ITEMS + 255) / 256;              // per thread (11)
 
 __device__ __forceinline__ int w_edge_variant(int idx, int n) { return n == 1 ? 3 : (idx == 0 ? 1 : (idx == n - 1 ? 2 : 0)); }
 
@@ -43,226 +43,12 @@ __device__ __forceinline__ void wino_row_pass(f32x4* r) {      // one patch row,
     const f32x4 d0 = r[0], d1 = r[1], d2 = r[2], d3 = r[3];
     r[0] = d0 - d2; r[1] = d1 + d2; r[2] = d2 - d1; r[3] = d1 - d3;
 }
-__device__ __forceinline__ void wino_col_pass(f32x4* c) {      // one patch column (stride 4), along a
-    const f32x4 d0 = c[0], d1 = c[4], d2 = c[8], d3 = c[12];
-    c[0] = d0 - d2; c[4] = d1 + d2; c[8] = d2 - d1; c[12] = d1 - d3;
-}
-// B^T d B for the 4x4 patch p[a*4+b] (each a float4 of channels), in place -> V[u*4+v]
-__device__ __forceinline__ void wino_input_transform(f32x4* p) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {       // along b: s0 = d0-d2, s1 = d1+d2, s2 = d2-d1, s3 = d1-d3
-        const f32x4 d0 = p[a * 4 + 0], d1 = p[a * 4 + 1], d2 = p[a * 4 + 2], d3 = p[a * 4 + 3];
-        p[a * 4 + 0] = d0 - d2; p[a * 4 + 1] = d1 + d2; p[a * 4 + 2] = d2 - d1; p[a * 4 + 3] = d1 - d3;
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {       // along a
-        const f32x4 d0 = p[0 * 4 + b], d1 = p[1 * 4 + b], d2 = p[2 * 4 + b], d3 = p[3 * 4 + b];
-        p[0 * 4 + b] = d0 - d2; p[1 * 4 + b] = d1 + d2; p[2 * 4 + b] = d2 - d1; p[3 * 4 + b] = d1 - d3;
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void k_conv_wino(ConvArgs args) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * W_AELEMS];
-    const int bid = blockIdx.x;
-    int j = 0;
-    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
-    const ConvJob& J = args.job[j];
-    int local = bid - J.block_begin;
-    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
-    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
-    const int tile_idx = local;
-    const int ty0 = (local / J.tiles_x) * W_T, tx0 = (local % J.tiles_x) * W_T;
-    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int i = lane & 31, half = lane >> 5;
-    const int tr = wm * 4 + (i >> 3), tc = i & 7;               // this lane's Winograd tile inside the 8x8 grid
-    const int patch0 = ((2 * tr) * W_H + 2 * tc) * W_LD + half * 4;   // LDS float offset of its patch origin
-
-    // fragment-ordered weights: [n32 tile][k8 step][16 freq][64 lanes][4]
-    const int n32_total = (cout + 31) / 32;
-    int n32 = ntile * 2 + wn;
-    const bool n_live = n32 < n32_total;
-    if (!n_live) n32 = n32_total - 1;                            // clamp (outputs masked by co < cout below)
-    const int k8_total = cin / 8;
-    const float* ub = J.wgt + (size_t(n32) * k8_total) * (16 * 256) + lane * 4;
-
-    const float* inb = J.in + size_t(b) * h * w * cin;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    // halo staging of one float4 item of chunk `ch` into LDS buffer `buf`
-    auto item_load = [&](int it, int ch) -> f32x4 {
-        const int idx = it * 256 + tid;
-        const int pix = idx >> 3, q = idx & 7;
-        const int hy = pix / W_H, hx = pix - hy * W_H;
-        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        const bool ok = idx < W_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        f32x4 v = wg4(inb + (size_t(ok ? gy : 0) * w + (ok ? gx : 0)) * cin + ch * W_KC + q * 4)[0];
-        return ok ? v : zero4;
-    };
-    auto item_store = [&](int it, int buf, f32x4 v) {
-        const int idx = it * 256 + tid;
-        if (idx < W_ITEMS) *reinterpret_cast<f32x4*>(smem + buf * W_AELEMS + (idx >> 3) * W_LD + (idx & 7) * 4) = v;
-    };
-
-    // (A per-block rotation of the K-chunk order was tried against L2 hot-spotting on the shared weight lines: no gain,
-    // and it made a sample's rounding depend on its position in the batch, so the order is the natural one.)
-    const int nchunks = cin / W_KC;
-    const int rot = 0;
-    auto rot_chunk = [&](int c) { const int g = c + rot; return g >= nchunks ? g - nchunks : g; };
-
-    f32x16 acc[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
-
-    // ---- prologue: chunk 0 -> LDS buffer 0; first patch transformed; first 8 weight fragments in flight
-#pragma unroll
-    for (int it = 0; it < W_NIT; ++it) item_store(it, 0, item_load(it, rot_chunk(0)));
-    __syncthreads();
-    f32x4 VA[16], VB[16], ring[8];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) VA[a * 4 + bb] = *reinterpret_cast<const f32x4*>(smem + patch0 + (a * W_H + bb) * W_LD);
-    wino_input_transform(VA);
-    if (W_ABL & 32) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) VB[k] = VA[k] + 1.f;
-    }
-#pragma unroll
-    for (int f = 0; f < 8; ++f) ring[f] = wg4(ub + (size_t(rot_chunk(0)) * 4 * 16 + f) * 256)[0];
-
-    // one k-step: 64 MFMAs with Vc; meanwhile read+transform the next patch into Vn, refill the ring, stage halo items
-#define WINO_STEP(Vc, Vn, K8)                                                                                         \
-    {                                                                                                                 \
-        const int step = gch * 4 + (K8);                                     /* global k8 index (rotated chunk) */    \
-        const int nstep = (K8) < 3 ? step + 1 : gnext * 4;                                                            \
-        const int nbuf = ((K8) == 3 ? (chunk + 1) : chunk) & 1;              /* buffer holding the next step's patch */ \
-        const float* nsrc = smem + nbuf * W_AELEMS + patch0 + (((K8) + 1) & 3) * 8;                                    \
-        f32x4 pf[4];                                                                                                  \
-        constexpr int it0 = (K8) * 4, itn = (K8) == 2 ? 3 : ((K8) == 3 ? 0 : 4);                                       \
-        _Pragma("unroll") for (int t = 0; t < itn; ++t) pf[t] = (W_ABL & 16) ? zero4 : item_load(it0 + t, gnext);     \
-        _Pragma("unroll") for (int f = 0; f < 16; ++f) {                                                              \
-            if (!(W_ABL & 32) && f < 8 && (f & 1) == 0) {                    /* next patch: row f/2 */               \
-                _Pragma("unroll") for (int bb = 0; bb < 4; ++bb)                                                      \
-                    Vn[(f >> 1) * 4 + bb] = *reinterpret_cast<const f32x4*>(nsrc + ((f >> 1) * W_H + bb) * W_LD);     \
-            }                                                                                                         \
-            const f32x4 bq = ring[f & 7];                                                                             \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                             \
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][e], bq[e], acc[f], 0, 0, 0);                      \
-            {                                                                /* refill the slot 8 fragments ahead */ \
-                const int fs = f + 8 < 16 ? step : nstep, ff = (f + 8) & 15;                                          \
-                ring[f & 7] = wg4(ub + (size_t((W_ABL & 8) ? 0 : fs) * 16 + ff) * 256)[0];                                              \
-            }                                                                                                         \
-            if (!(W_ABL & 32) && f >= 2 && f <= 8 && (f & 1) == 0) wino_row_pass(Vn + ((f >> 1) - 1) * 4);  /* row read two groups ago */ \
-            if (!(W_ABL & 32) && f >= 9 && f <= 12) wino_col_pass(Vn + (f - 9));                                      \
-            if ((W_ABL & 64) && !(W_ABL & 128)) continue;                                                               \
-            __builtin_amdgcn_sched_barrier(0);                               /* keep loads this far ahead of use */   \
-        }                                                                                                             \
-        _Pragma("unroll") for (int t = 0; t < itn; ++t) item_store(it0 + t, (chunk + 1) & 1, pf[t]);                   \
-        if ((K8) == 2) __syncthreads();                                      /* next chunk's halo complete */         \
-    }
-
-    for (int chunk = 0; chunk < ((W_ABL & 4) ? 0 : nchunks); ++chunk) {
-        const int gch = rot_chunk(chunk);
-        const int gnext = chunk + 1 < nchunks ? rot_chunk(chunk + 1) : gch;
-        WINO_STEP(VA, VB, 0)
-        WINO_STEP(VB, VA, 1)
-        WINO_STEP(VA, VB, 2)
-        WINO_STEP(VB, VA, 3)
-    }
-#undef WINO_STEP
-
-    // ---- epilogue: inverse transform A^T M A per tile, then the same fused tail as the direct kernel
-    const float* __restrict__ p_bias = J.bias;
-    const float* __restrict__ p_bbias = J.bbias;
-    const float* __restrict__ p_rcol = J.rcol;
-    const float* __restrict__ p_rrow = J.rrow;
-    const float* __restrict__ p_res = J.res;
-    float* __restrict__ p_out = J.out;
-    double* p_gn = J.gn_part;
-    const int co = (ntile * 2 + wn) * 32 + i;
-    const bool co_ok = n_live && co < cout;
-    const int coc = co_ok ? co : 0;
-    float base = p_bias ? p_bias[coc] : 0.f;
-    if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
-    float gs = 0.f, gss = 0.f;
-    if (W_ABL & 2) { if (co_ok && acc[0][0] == 12345.f) p_out[0] = acc[3][1] + VA[0][0] + ring[0][0]; return; }
-    // 4 MFMA rows (= 4 tiles = 16 output pixels) per round: inverse transform, then every rank-1 / residual load of
-    // the round is issued before any is consumed (predicated, clamped addresses, no per-element branches)
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        float val[16]; bool ok[16]; size_t oidx[16];
-        int yy_[16], xx_[16];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = rg * 4 + rr;
-            const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;                  // MFMA row -> tile of this wave
-            const int ytile = ty0 + 2 * (wm * 4 + (ti >> 3)), xtile = tx0 + 2 * (ti & 7);
-            float P[2][4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float m0 = acc[0 * 4 + v][r], m1 = acc[1 * 4 + v][r], m2 = acc[2 * 4 + v][r], m3 = acc[3 * 4 + v][r];
-                P[0][v] = m0 + m1 + m2; P[1][v] = m1 - m2 - m3;
-            }
-#pragma unroll
-            for (int yy = 0; yy < 2; ++yy) {
-                const float Y0 = P[yy][0] + P[yy][1] + P[yy][2], Y1 = P[yy][1] - P[yy][2] - P[yy][3];
-#pragma unroll
-                for (int xx = 0; xx < 2; ++xx) {
-                    const int k = rr * 4 + yy * 2 + xx;
-                    const int y = ytile + yy, x = xtile + xx;
-                    yy_[k] = y; xx_[k] = x;
-                    ok[k] = y < h && x < w && co_ok;
-                    oidx[k] = ok[k] ? ((size_t(b) * h + y) * w + x) * cout + co : 0;
-                    val[k] = (xx == 0 ? Y0 : Y1) + base;
-                }
-            }
-        }
-        // issue every load of the round first (three uniform branches, no use in between), then consume
-        float tc[16], tr_[16], ts[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { tc[k] = 0.f; tr_[k] = 0.f; ts[k] = 0.f; }
-        if (p_rcol) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tc[k] = p_rcol[ok[k] ? ((size_t(b) * w + xx_[k]) * 4 + w_edge_variant(yy_[k], h)) * cout + co : 0];
-        }
-        if (p_rrow) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) tr_[k] = p_rrow[ok[k] ? ((size_t(b) * h + yy_[k]) * 4 + w_edge_variant(xx_[k], w)) * cout + co : 0];
-        }
-        if (p_res) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) ts[k] = p_res[oidx[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) val[k] += (tc[k] + tr_[k]) + ts[k];    // !ok lanes hold clamped garbage, never stored
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (ok[k] && !((W_ABL & 1) && val[k] != 12345.f)) { p_out[oidx[k]] = val[k]; gs += val[k]; gss = fmaf(val[k], val[k], gss); }
-    }
-    if (p_gn) {
-        gs += __shfl_xor(gs, 32, 64); gss += __shfl_xor(gss, 32, 64);
-        for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
-        if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
-            const int part = tile_idx * 2 + wm;
-            double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
-            dst[0] = double(gs); dst[1] = double(gss);
-        }
-    }
-}
 
 // ------------------------------------------------------------------ two waves per SIMD: the frequencies split in halves
-// Same data flow as k_conv_wino with an 8x16-pixel tile (one 32-row MFMA tile); a (tile, 32-channel) unit is shared by TWO waves that each own 8 of
-// the 16 frequencies (rows u = 2*fh, 2*fh+1 of the 4x4 frequency grid): 128 accumulator registers per wave instead of
-// 256, so two waves fit on every SIMD.  That (a) lets one wave's barrier / prologue / epilogue time be covered by its
-// neighbour's MFMAs and (b) halves the scheduling quantum, which removes most of the last-round imbalance at batch 1
-// (1536 units on 1024 SIMDs became 3072 half-units that the dispatcher packs 3 per SIMD).  Costs: each wave redoes the
-// cheap column pass of the input transform for its rows only (12 of the 16 patch reads), and the inverse transform
-// needs one 4-float exchange per output tile between the two waves through LDS.
+// A (tile, 32-channel) unit is shared by TWO waves that each own 8 of the 16 frequencies (rows u = 2*fh, 2*fh+1 of the 4x4
+// frequency grid): 128 accumulator registers per wave, two 64-channel blocks per CU.  Slightly ahead of k_conv_wino4
+// when a launch has many more blocks than the GPU has slots (batch 8: +0.7 %) because the halo is staged once per 64
+// output channels; behind it everywhere else (batch 1: -6 %, small planes -15 %).
 constexpr int W2_TH = 8, W2_TW = 16;                      // output tile: 4 x 8 Winograd tiles = one 32-row MFMA tile
 constexpr int W2_HH = W2_TH + 2, W2_HW = W2_TW + 2;
 constexpr int W2_ITEMS = W2_HH * W2_HW * (W_KC / 4);
@@ -566,23 +352,273 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
 #endif
 }
 
+// ------------------------------------------------------------------ three waves per SIMD: one frequency row per wave
+// Same tile (8x16 pixels) and the same data flow as k_conv_wino2, but a block owns 32 output channels and its four waves
+// own one row u of the 4x4 frequency grid each: 64 accumulator registers, <= 168 VGPRs, 52 KB of LDS -> THREE blocks per
+// CU, three waves on every SIMD.  The half-resolution layers at batch 1 become 768 blocks on 768 slots (k_conv_wino2:
+// 384 blocks, half the CUs with one block and the other half with two), the full-resolution ones two full rounds instead
+// of one and a half; small planes fill more of the GPU.  The price: the halo is staged per 32 output channels.
+//   wave u needs two rows of the 4x4 patch: t = x + s*y with (x, y, s) = (d0, d2, -), (d1, d2, +), (d2, d1, -), (d1, d3, -)
+constexpr int W4_ABUF = W2_HH * W2_HW * W_LD;             // halo buffer stride (unpadded: the last staging round is predicated)
+constexpr int W4_IMG = (W2_TH / 2) * W2_TW * 32;          // one share image: [4 tile rows][16 columns][32 channels]
+__global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
+    // k-loop: two halo buffers; epilogue: six share images (three per output-row parity) over the same memory
+    __shared__ __attribute__((aligned(16))) float smem[2 * W4_ABUF];
+    static_assert(6 * W4_IMG <= 2 * W4_ABUF, "LDS plan");
+    W_STAMP(0)
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    int bid = blockIdx.x;
+    if (args.xcd_swizzle & 1) {
+        const int chunk = int(gridDim.x) >> 3;
+        if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
+    }
+    int j = 0;
+    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int n32 = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int tile_idx = local;
+    const int ty0 = (local / J.tiles_x) * W2_TH, tx0 = (local % J.tiles_x) * W2_TW;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);             // frequency row of this wave
+    const int i = lane & 31, half = lane >> 5;
+    const int tr = i >> 3, tc = i & 7;
+    const int prow = (2 * tr * W2_HW + 2 * tc) * W_LD + half * 4;
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(u == 1 ? 0x3F800000 : 0xBF800000));
+
+    const int k8_total = cin / 8;
+    const float* ub = J.wgt + ((size_t(n32) * k8_total) * 16 + u * 4) * 256;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, k8_total * 16 * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wfrag = [&](int step, int f) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (step * 16 + f) * 1024, 0));
+    };
+    const float* inb = J.in + size_t(b) * h * w * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, h * w * cin * 4, 0x00020000);
+    unsigned goff[W2_ITEMS_PT];                                         // (this kernel has the registers for them)
+#pragma unroll
+    for (int it = 0; it < W2_ITEMS_PT; ++it) {
+        const int pix = it * 32 + (tid >> 3);
+        const int hy = pix / W2_HW, hx = pix - hy * W2_HW;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = pix < W2_HH * W2_HW && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        goff[it] = ok ? unsigned((gy * w + gx) * cin + (tid & 7) * 4) * 4u : 0x80000000u;
+    }
+    const int lds_w = (tid >> 3) * W_LD + (tid & 7) * 4;
+    const bool last_ok = (W2_ITEMS_PT - 1) * 32 + (tid >> 3) < W2_HH * W2_HW;   // the sixth round covers pixels 160..191 of 180
+    auto item_load = [&](int it, int ch) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], ch * (W_KC * 4), 0));
+    };
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        if (it < W2_ITEMS_PT - 1 || last_ok) *reinterpret_cast<f32x4*>(smem + buf * W4_ABUF + lds_w + it * (32 * W_LD)) = v;
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int nchunks = cin / W_KC;
+    f32x4 VA[4], VB[4], ring[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { ring[f] = wfrag(0, f); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int it = 0; it < W2_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+    W_STAMP(7)
+    __syncthreads();
+    W_STAMP(4)
+#define W4_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
+#define W4_PIN(v) asm volatile("" : "+v"(v))
+    int ax = (prow + xrow * W2_HW * W_LD) * 4, ay = (prow + yrow * W2_HW * W_LD) * 4, tog = W4_ABUF * 4;
+    {
+        f32x4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 x = W4_LDS4(ax + c * (W_LD * 4)), y = W4_LDS4(ay + c * (W_LD * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c][e] = fmaf(sgn, y[e], x[e]);
+        }
+        VA[0] = t[0] - t[2]; VA[1] = t[1] + t[2]; VA[2] = t[2] - t[1]; VA[3] = t[1] - t[3];
+    }
+
+    // One k-step = 16 slots of {one MFMA + a small piece of the other work}: 8 patch reads + column pass for the next
+    // step's operands (slots of f = 0, 1), its row pass (f = 2, 3), 4 weight fragments, 2 halo loads.
+#define WINO4_STEP(Vc, Vn, K8)                                                                                        \
+    {                                                                                                                 \
+        const int step = chunk * 4 + (K8);                                                                            \
+        const int nstep = (K8) < 3 ? step + 1 : gnext * 4;                                                            \
+        if ((K8) == 3) { ax += tog; ay += tog; tog = -tog; }                 /* the next patch is in the other buffer */ \
+        constexpr int koff = (((K8) + 1) & 3) * 32;                                                                   \
+        constexpr int it0 = (K8) * 2, itn = (K8) == 3 ? 0 : 2;                                                        \
+        f32x4 pf[2], cx0, cy0, cx1, cy1, t0, t1, t2, t3;                                                              \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                               \
+            const f32x4 bq = ring[f];                                                                                 \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][0], bq[0], acc[f], 0, 0, 0);                          \
+            if (f < 2) {                                                                                              \
+                cx0 = W4_LDS4(ax + koff + (2 * f) * (W_LD * 4)); cy0 = W4_LDS4(ay + koff + (2 * f) * (W_LD * 4));     \
+                cx1 = W4_LDS4(ax + koff + (2 * f + 1) * (W_LD * 4)); cy1 = W4_LDS4(ay + koff + (2 * f + 1) * (W_LD * 4)); \
+            }                                                                                                         \
+            if (f == 2) { Vn[0] = t0 - t2; W4_PIN(Vn[0]); }                                                           \
+            if (f == 3) { Vn[3] = t1 - t3; W4_PIN(Vn[3]); }                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][1], bq[1], acc[f], 0, 0, 0);                          \
+            ring[f] = wfrag(nstep, f);                                                                                \
+            if (f == 1 && itn) { pf[0] = item_load(it0, gnext); pf[1] = item_load(it0 + 1, gnext); }                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][2], bq[2], acc[f], 0, 0, 0);                          \
+            if (f == 0) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t0[e] = fmaf(sgn, cy0[e], cx0[e]); W4_PIN(t0); } \
+            if (f == 1) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t2[e] = fmaf(sgn, cy0[e], cx0[e]); W4_PIN(t2); } \
+            if (f == 2) { Vn[1] = t1 + t2; W4_PIN(Vn[1]); }                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][3], bq[3], acc[f], 0, 0, 0);                          \
+            if (f == 0) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t1[e] = fmaf(sgn, cy1[e], cx1[e]); W4_PIN(t1); } \
+            if (f == 1) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t3[e] = fmaf(sgn, cy1[e], cx1[e]); W4_PIN(t3); } \
+            if (f == 2) { Vn[2] = t2 - t1; W4_PIN(Vn[2]); }                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < itn; ++t) item_store(it0 + t, (chunk + 1) & 1, pf[t]);                   \
+        if ((K8) == 2) __syncthreads();                                                                               \
+    }
+
+    W_STAMP(1)
+    __builtin_amdgcn_s_setprio(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int gnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
+        WINO4_STEP(VA, VB, 0)
+        WINO4_STEP(VB, VA, 1)
+        WINO4_STEP(VA, VB, 2)
+        WINO4_STEP(VB, VA, 3)
+    }
+#undef WINO4_STEP
+#undef W4_LDS4
+#undef W4_PIN
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    W_STAMP(2)
+
+    // ---- epilogue.  M[v] = acc[v] is row u of the frequency grid.  Column pass first (c0 = M0 + M1 + M2, c1 = M1 - M2 - M3
+    // give the two pixels of a tile row); output row 0 of a tile is c(u0) + c(u1) + c(u2), row 1 is c(u1) - c(u2) - c(u3):
+    // every wave writes its signed contribution into share images [4 tile rows][16 columns][32 channels] (three per
+    // output-row parity), then threads owning 4 consecutive channels of a pixel add three images, the rank-1 tables,
+    // the residual and the bias and store 16 bytes.
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    __syncthreads();                                     // all patch reads of the last step are done
+    W_STAMP(5)
+    {
+        // image index: parity 0 <- u0, u1, u2 (images 0, 1, 2); parity 1 <- u1, u2, u3 (images 3, 4, 5)
+        float* img_a = smem + (u < 3 ? u : 5) * W4_IMG + i;             // first image this wave writes
+        float* img_b = smem + (u == 1 ? 3 : 4) * W4_IMG + i;            // second one (u = 1, 2 only)
+        const float sa = u == 3 ? -1.f : 1.f, sb = u == 2 ? -1.f : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
+            const float c0 = m0 + m1 + m2, c1 = m1 - m2 - m3;
+            const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pp = ((ti >> 3) * W2_TW + 2 * (ti & 7)) * 32;
+            img_a[pp] = sa * c0; img_a[pp + 32] = sa * c1;
+            if (u == 1 || u == 2) { img_b[pp] = sb * c0; img_b[pp + 32] = sb * c1; }
+        }
+    }
+    // finishing thread: channels co4..co4+3 of pixel column xl, rows rsel*4 .. rsel*4+3 of the tile
+    const int quad = tid & 7, xl = (tid >> 3) & 15, rsel = tid >> 7;
+    const int co4 = n32 * 32 + quad * 4;
+    const bool c_ok = co4 < cout;
+    const int coc = c_ok ? co4 : 0;
+    const int x = tx0 + xl;
+    const bool x_ok = x < w && c_ok;
+    const int xc = x < w ? x : 0;
+    f32x4 base4 = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+    if (p_bbias) base4 += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+    f32x4 tcol[4], trow[4], tres[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
+    if (p_rcol) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ty0 + rsel * 4 + k;
+            tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + w_edge_variant(y < h ? y : 0, h)) * cout + coc);
+        }
+    }
+    if (p_rrow) {
+        const int vx = w_edge_variant(xc, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ty0 + rsel * 4 + k;
+            trow[k] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
+        }
+    }
+    if (p_res) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ty0 + rsel * 4 + k;
+            tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+        }
+    }
+    __syncthreads();                                     // the share images are complete
+    W_STAMP(6)
+    f32x4 gs4 = zero4, gss4 = zero4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yl = rsel * 4 + k, y = ty0 + yl;
+        const float* sp = smem + (yl & 1) * 3 * W4_IMG + ((yl >> 1) * W2_TW + xl) * 32 + quad * 4;
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + W4_IMG),
+                    kc = *reinterpret_cast<const f32x4*>(sp + 2 * W4_IMG);
+        const f32x4 v = (((ka + kb) + kc) + base4) + ((tcol[k] + trow[k]) + tres[k]);
+        if (x_ok && y < h) {
+            *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
+            gs4 += v; gss4 += v * v;
+        }
+    }
+    if (p_gn) {
+        // per wave: 8 pixel columns (lanes l, l+8, ..) x 4 rows of 8 channel quads; one part per wave
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
+        const int sg = args.gn_sg;
+        const int part = tile_idx * 4 + u;
+        double* dst = p_gn + (size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub * 2;
+        if (sg >= 4) {
+            float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
+            for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+            if (lane < 8 && c_ok && (co4 % sg) == 0) { dst[(co4 / sg) * 2] = double(s); dst[(co4 / sg) * 2 + 1] = double(ss); }
+        } else if (lane < 8 && c_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                if (sg == 2) { dst[((co4 + e) / 2) * 2] = double(gs4[e] + gs4[e + 1]); dst[((co4 + e) / 2) * 2 + 1] = double(gss4[e] + gss4[e + 1]); }
+                else { dst[(co4 + e) * 2] = double(gs4[e]); dst[(co4 + e) * 2 + 1] = double(gss4[e]);
+                       dst[(co4 + e + 1) * 2] = double(gs4[e + 1]); dst[(co4 + e + 1) * 2 + 1] = double(gss4[e + 1]); }
+            }
+        }
+    }
+    W_STAMP(3)
+}
+
 // ------------------------------------------------------------------ host side
-static int wino_variant() {          // 2: two waves per SIMD (default), 1: one wave per SIMD, 0: direct kernel
+static int wino_variant() {          // 4: one frequency row per wave (default), 2: two rows per wave, 0: direct kernel
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("S3D_WINO");
-        v = e ? atoi(e) : 2;
-        if (v < 0 || v > 2) v = 2;
+        v = e ? atoi(e) : 4;
+        if (v != 0 && v != 2) v = 4;
     }
     return v;
 }
 bool conv_use_wino() { return wino_variant() != 0 && !conv_use_naive(); }
 
-void wino_gn_parts(const Geo& g, int nparts[3]) {
-    for (int p = 0; p < 3; ++p) {
-        if (wino_variant() == 2) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 4;   // one per wave
-        else nparts[p] = ((g.w[p] + W_T - 1) / W_T) * ((g.h[p] + W_T - 1) / W_T) * 2;
-    }
+void wino_gn_parts(const Geo& g, int nparts[3]) {    // one part per wave of a tile's block(s), both kernels
+    for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 4;
 }
 
 // U = G g G^T in double, stored in MFMA fragment order [n32][k8][16][64 lanes][4]; W is OIHW [cout][ctot][3][3],
@@ -612,23 +648,23 @@ size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, in
 
 int launch_conv_wino(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
-    const bool two = wino_variant() == 2;
-    const int th = two ? W2_TH : W_T, tw = two ? W2_TW : W_T;
+    // one kernel for every shape and batch size: a sample's result must not depend on what it is batched with
+    const bool four = wino_variant() == 4;
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
         S3D_CHECK(size_t(J.h) * J.w * a.cin * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wino conv: a plane of one sample must stay below 2 GiB");
-        J.tiles_x = (J.w + tw - 1) / tw;
-        J.tiles_per_img = J.tiles_x * ((J.h + th - 1) / th);
-        J.n_tiles_n = (a.cout + 63) / 64;
+        J.tiles_x = (J.w + W2_TW - 1) / W2_TW;
+        J.tiles_per_img = J.tiles_x * ((J.h + W2_TH - 1) / W2_TH);
+        J.n_tiles_n = four ? (a.cout + 31) / 32 : (a.cout + 63) / 64;
         J.block_begin = blocks;
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
-    if (two) hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_conv_wino, dim3(blocks), dim3(256), 0, st, a);
+    if (four) hipLaunchKernelGGL(k_conv_wino4, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }

@@ -24,7 +24,7 @@ def per_kernel(path, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-dom = sys.argv[4] if len(sys.argv) > 4 else "k_conv_wino2"
+dom = sys.argv[4] if len(sys.argv) > 4 else "k_conv_wino"
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --steps 6 --warmup 2 "
                "--no-cpu-baseline --profile-every 0; per-launch averages. read bytes = 2 * FETCH_SIZE KB * 1024 (gfx950 "
                "correction, MI355X_MICROARCH.md), write bytes = WRITE_SIZE KB * 1024.  Aggregated by tools/pmc_traffic.py.",

@@ -66,7 +66,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
 int main() {
-    printf("W_ABL=%d S3D_WINO=%s\n", W_ABL, getenv("S3D_WINO") ? getenv("S3D_WINO") : "(default 2)");
+    printf("W_ABL=%d S3D_WINO=%s\n", W_ABL, getenv("S3D_WINO") ? getenv("S3D_WINO") : "(default 4)");
     for (int c : {128, 256, 512}) run(c, 64, 128, 1, 10, false);     // 384 blocks (wino2) / 192 (wino1)
     for (int c : {128, 256, 512}) run(c, 128, 128, 1, 10, false);    // 768 / 384
     for (int co : {64, 128, 256, 512}) run(256, co, 64, 1, 10, false);   // half resolution: 96 / 192 / 384 / 768 blocks
