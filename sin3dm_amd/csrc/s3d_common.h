@@ -182,7 +182,7 @@ struct ActArgs {
     const float* film;       // [B][film_stride]: scale at [0,C), shift at [C,2C); or null
     int film_stride;
 };
-constexpr int kActRows = 8, kActCols = 16;   // tile of the act kernel
+constexpr int kActRows = 8, kActCols = 8;     // tile of the act kernel (measured: 8x16 +1 %, 4x16 +3 %, 16x8 +15 % per step)
 struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a tile's columns), colpart [B][ntr][w][C]
     float* rowpart[3];
     float* colpart[3];
