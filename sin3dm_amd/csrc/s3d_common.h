@@ -153,7 +153,7 @@ int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const fl
                    int Cout, Tri& out, hipStream_t st);
 
 // GroupNorm statistics.  Stage 1: producers emit partial {sum, sumsq} in double, indexed
-//   p[(((b*3 + plane) * maxparts + part) * nsub + sub) * 2 + {0,1}],  sub = channel / sg
+//   p[(((b*3 + plane) * nsub + sub) * maxparts + part) * 2 + {0,1}],  sub = channel / sg
 // where a "part" is a pixel chunk (launch_gn_partials) or one wave's 32-pixel tile of a convolution epilogue and a
 // "subgroup" is sg consecutive channels of one group.  Stage 2 (launch_gn_finalize) adds the parts in index order
 // and writes {mean, rstd} per (b, plane, group): deterministic, no float atomics.

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
             for (int off = 1; off < args.gn_sg; off <<= 1) { gs += __shfl_xor(gs, off, 64); gss += __shfl_xor(gss, off, 64); }
             if (lane < 32 && co_ok && (co % args.gn_sg) == 0) {
                 const int part = tile_idx * CFG::WM + wm;
-                double* dst = p_gn + ((size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub + co / args.gn_sg) * 2;
+                double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + co / args.gn_sg) * args.gn_maxparts + part) * 2;
                 dst[0] = double(gs); dst[1] = double(gss);
             }
         }

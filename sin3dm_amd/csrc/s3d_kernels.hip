@@ -53,9 +53,9 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w,
 }
 
 // Block tail shared by the kernels that emit GroupNorm partials for a pixel chunk: thread (q, l) holds {sum, sumsq} of
-// channel quad q over its pixels; the block adds them per group in a fixed order and writes out[32 groups][2].
+// channel quad q over its pixels; the block adds them per group in a fixed order and writes group g at out[g * gstride][2].
 __device__ __forceinline__ void gn_chunk_reduce(double* sm, const double s[4], const double ss[4], int q, int l, int C, int pl,
-                                                double* out) {
+                                                double* out, int gstride) {
     for (int k = 0; k < 4; ++k) {
         sm[(size_t(l) * C + 4 * q + k) * 2 + 0] = s[k];
         sm[(size_t(l) * C + 4 * q + k) * 2 + 1] = ss[k];
@@ -69,7 +69,7 @@ __device__ __forceinline__ void gn_chunk_reduce(double* sm, const double s[4], c
                 S += sm[(size_t(ll) * C + c) * 2 + 0];
                 SS += sm[(size_t(ll) * C + c) * 2 + 1];
             }
-        out[g * 2] = S; out[g * 2 + 1] = SS;
+        out[size_t(g) * gstride * 2] = S; out[size_t(g) * gstride * 2 + 1] = SS;
     }
 }
 __device__ __forceinline__ void gn_acc(double s[4], double ss[4], const float4& v) {
@@ -145,7 +145,7 @@ struct GnPartArgs {
     const float* x[3];
     int h[3], w[3];
     int C, cq, pl;
-    double* part;   // [B][3][kGnChunks][32][2]
+    double* part;   // [B][3][32 groups][kGnChunks][2]
 };
 __global__ void k_gn_partials(GnPartArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -165,7 +165,7 @@ __global__ void k_gn_partials(GnPartArgs a) {
         s[2] += v.z; ss[2] += double(v.z) * v.z;
         s[3] += v.w; ss[3] += double(v.w) * v.w;
     }
-    gn_chunk_reduce(sm, s, ss, q, l, a.C, a.pl, a.part + ((size_t(b) * 3 + p) * kGnChunks + chunk) * 64);
+    gn_chunk_reduce(sm, s, ss, q, l, a.C, a.pl, a.part + ((size_t(b) * 3 + p) * 32 * kGnChunks + chunk) * 2, kGnChunks);
 }
 int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st) {
     GnPartArgs a;
@@ -184,23 +184,24 @@ struct GnFinArgs {
     int maxparts, nparts[3], nsub, subs_per_group;
     double count[3];      // elements per group = (C/32)*h*w
 };
-__global__ void k_gn_finalize(GnFinArgs a) {
-    __shared__ double sm[32][32][2];
-    const int p = blockIdx.x, b = blockIdx.y;
-    const int g = threadIdx.x & 31, slice = threadIdx.x >> 5;          // 32 slices x 32 groups
+__global__ void k_gn_finalize(GnFinArgs a) {                   // one block per (group, plane, sample): 96 blocks at batch 1, not 3
+    __shared__ double sm[128][2];
+    const int g = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const double* base = a.part + (size_t(b) * 3 + p) * a.maxparts * a.nsub * 2;
     double S = 0, SS = 0;
-    for (int part = slice; part < a.nparts[p]; part += 32) {
-        const double* row = base + (size_t(part) * a.nsub + size_t(g) * a.subs_per_group) * 2;
-        for (int k = 0; k < a.subs_per_group; ++k) { S += row[2 * k]; SS += row[2 * k + 1]; }
+    for (int k = 0; k < a.subs_per_group; ++k) {               // [sub][part]: a group's parts are contiguous
+        const double* row = base + (size_t(g) * a.subs_per_group + k) * a.maxparts * 2;
+        for (int part = tid; part < a.nparts[p]; part += 128) { S += row[2 * part]; SS += row[2 * part + 1]; }
     }
-    sm[slice][g][0] = S; sm[slice][g][1] = SS;
+    sm[tid][0] = S; sm[tid][1] = SS;
     __syncthreads();
-    if (threadIdx.x < 32) {
-        double s = 0, ss = 0;
-        for (int k = 0; k < 32; ++k) { s += sm[k][g][0]; ss += sm[k][g][1]; }
-        const double m = s / a.count[p];
-        double var = ss / a.count[p] - m * m;
+    for (int s = 64; s >= 1; s >>= 1) {                        // fixed tree: bit-repeatable
+        if (tid < s) { sm[tid][0] += sm[tid + s][0]; sm[tid][1] += sm[tid + s][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double m = sm[0][0] / a.count[p];
+        double var = sm[0][1] / a.count[p] - m * m;
         if (var < 0) var = 0;
         float* o = a.mr + ((size_t(b) * 3 + p) * 32 + g) * 2;
         o[0] = float(m);
@@ -214,7 +215,7 @@ int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnSta
     a.subs_per_group = part.nsub / 32;
     for (int p = 0; p < 3; ++p) { a.nparts[p] = part.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
     if (!B) return 0;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(3, B), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(32, 3, B), dim3(128), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -433,7 +434,7 @@ __global__ void k_avgpool_gn(PoolArgs a, double* part, int pl) {        // pixel
         yb[size_t(pix) * a.cq] = o;
         gn_acc(s, ss, o);
     }
-    gn_chunk_reduce(reinterpret_cast<double*>(smem_raw), s, ss, q, l, a.cq * 4, pl, part + ((size_t(b) * 3 + p) * kGnChunks + chunk) * 64);
+    gn_chunk_reduce(reinterpret_cast<double*>(smem_raw), s, ss, q, l, a.cq * 4, pl, part + ((size_t(b) * 3 + p) * 32 * kGnChunks + chunk) * 2, kGnChunks);
 }
 int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials* part) {
     PoolArgs a;

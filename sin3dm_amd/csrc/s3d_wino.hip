@@ -333,17 +333,19 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         }
         const int sg = args.gn_sg;
         const int part = tile_idx * 4 + wid;
-        double* dst = p_gn + (size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub * 2;
+        auto put = [&](int sub, float s, float ss) {            // partial layout [b][plane][sub][part][2]
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+            dst[0] = double(s); dst[1] = double(ss);
+        };
         if (sg >= 4) {
             float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
             for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
-            if (lane < 16 && c_ok && (co4 % sg) == 0) { dst[(co4 / sg) * 2] = double(s); dst[(co4 / sg) * 2 + 1] = double(ss); }
+            if (lane < 16 && c_ok && (co4 % sg) == 0) put(co4 / sg, s, ss);
         } else if (lane < 16 && c_ok) {
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                if (sg == 2) { dst[((co4 + e) / 2) * 2] = double(gs4[e] + gs4[e + 1]); dst[((co4 + e) / 2) * 2 + 1] = double(gss4[e] + gss4[e + 1]); }
-                else { dst[(co4 + e) * 2] = double(gs4[e]); dst[(co4 + e) * 2 + 1] = double(gss4[e]);
-                       dst[(co4 + e + 1) * 2] = double(gs4[e + 1]); dst[(co4 + e + 1) * 2 + 1] = double(gss4[e + 1]); }
+                if (sg == 2) put((co4 + e) / 2, gs4[e] + gs4[e + 1], gss4[e] + gss4[e + 1]);
+                else { put(co4 + e, gs4[e], gss4[e]); put(co4 + e + 1, gs4[e + 1], gss4[e + 1]); }
             }
         }
     }
@@ -588,17 +590,19 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
             for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
         const int sg = args.gn_sg;
         const int part = tile_idx * 4 + u;
-        double* dst = p_gn + (size_t(b) * 3 * args.gn_maxparts + part) * args.gn_nsub * 2;
+        auto put = [&](int sub, float s, float ss) {            // partial layout [b][plane][sub][part][2]
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+            dst[0] = double(s); dst[1] = double(ss);
+        };
         if (sg >= 4) {
             float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
             for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
-            if (lane < 8 && c_ok && (co4 % sg) == 0) { dst[(co4 / sg) * 2] = double(s); dst[(co4 / sg) * 2 + 1] = double(ss); }
+            if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, s, ss);
         } else if (lane < 8 && c_ok) {
 #pragma unroll
             for (int e = 0; e < 4; e += 2) {
-                if (sg == 2) { dst[((co4 + e) / 2) * 2] = double(gs4[e] + gs4[e + 1]); dst[((co4 + e) / 2) * 2 + 1] = double(gss4[e] + gss4[e + 1]); }
-                else { dst[(co4 + e) * 2] = double(gs4[e]); dst[(co4 + e) * 2 + 1] = double(gss4[e]);
-                       dst[(co4 + e + 1) * 2] = double(gs4[e + 1]); dst[(co4 + e + 1) * 2 + 1] = double(gss4[e + 1]); }
+                if (sg == 2) put((co4 + e) / 2, gs4[e] + gs4[e + 1], gss4[e] + gss4[e + 1]);
+                else { put(co4 + e, gs4[e], gss4[e]); put(co4 + e + 1, gs4[e + 1], gss4[e + 1]); }
             }
         }
     }
