@@ -64,9 +64,11 @@ def test_leaf_ops(tag, C):
 
 
 def test_conv_edge_shapes(oracle):
-    """ragged tiles, 1-pixel planes (edge variant 3) and Cout not a multiple of the N tile."""
+    """ragged tiles, 1-pixel planes (edge variant 3), Cout not a multiple of the N tile, and a Cout that is not a
+    multiple of 4 (the Winograd epilogue moves channel quads: such a layer takes the direct kernel)."""
     from sin3dm_amd import ops
-    for (B, C, H, W, D, cout) in ((1, 32, 1, 1, 1, 32), (2, 32, 1, 37, 2, 24), (1, 64, 17, 3, 33, 72), (1, 32, 40, 9, 1, 64)):
+    for (B, C, H, W, D, cout) in ((1, 32, 1, 1, 1, 32), (2, 32, 1, 37, 2, 24), (1, 64, 17, 3, 33, 72), (1, 32, 40, 9, 1, 64),
+                                  (1, 32, 9, 12, 5, 30)):
         fm = [T.synthetic_noise(s, 11 + i) for i, s in enumerate(((B, C, H, W), (B, C, H, D), (B, C, W, D)))]
         sd = {}
         for p in T.PLANES:
