@@ -317,24 +317,40 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
         __syncthreads();
         if (tt + 1 < t_end) load_tile(tt + 1);            // in flight while the matrix cores work on this tile
         __builtin_amdgcn_sched_barrier(0);
+        // one step = one pixel pair (lane half kk takes pixel c + kk); the operands of step s + 1 are read from LDS before the
+        // MFMAs of step s are issued, so their latency runs under the matrix pipe (it used to sit in front of every MFMA group)
+        constexpr int S = WG_TR * WG_TC / 2;
+        float avc[WT], bvc[NT][WT], avn[WT], bvn[NT][WT];
+        auto lds_step = [&](int st, float (&av)[WT], float (&bv)[NT][WT]) {
+            const int r = st / (WG_TC / 2), c = (st % (WG_TC / 2)) * 2;
 #pragma unroll
-        for (int r = 0; r < WG_TR; ++r)
-#pragma unroll 2
-            for (int c = 0; c < WG_TC; c += 2) {
-                float av[WT];
+            for (int m = 0; m < WT; ++m) av[m] = sm.dy[wm * WT + m][r * WG_TC + c + kk][i];
 #pragma unroll
-                for (int m = 0; m < WT; ++m) av[m] = sm.dy[wm * WT + m][r * WG_TC + c + kk][i];
+            for (int t = 0; t < NT; ++t) {
+                const int dr = TROWS == 3 ? t / KW : 0, dc = t % KW;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int dr = TROWS == 3 ? t / KW : 0, dc = t % KW;
-#pragma unroll
-                    for (int n = 0; n < WT; ++n) {
-                        const float bv = sm.a[wn * WT + n][(r + dr) * AC + c + kk + dc][i];
-#pragma unroll
-                        for (int m = 0; m < WT; ++m) acc[t][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv, acc[t][m][n], 0, 0, 0);
-                    }
-                }
+                for (int n = 0; n < WT; ++n) bv[t][n] = sm.a[wn * WT + n][(r + dr) * AC + c + kk + dc][i];
             }
+        };
+        lds_step(0, avc, bvc);
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (st + 1 < S) lds_step(st + 1, avn, bvn);
+            __builtin_amdgcn_sched_barrier(0);                 // (left alone, the scheduler sinks the reads back to their uses)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int n = 0; n < WT; ++n)
+#pragma unroll
+                    for (int m = 0; m < WT; ++m) acc[t][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(avc[m], bvc[t][n], acc[t][m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < WT; ++m) avc[m] = avn[m];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int n = 0; n < WT; ++n) bvc[t][n] = bvn[t][n];
+        }
     }
     // partial [ks][co][ci][TAPS]
     float* part = J.part + size_t(ks) * args.cout * args.cin * TAPS;
@@ -371,11 +387,15 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     int planes = 0;
     for (int p = 0; p < 3; ++p) { tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC); planes += g.h[p] > 0; }
     const int bt = taps == 1 ? 128 : 64;
-    const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1);
-    long long ks = (512 + base - 1) / base;                          // aim for ~2 blocks per CU ...
+    const int rows = taps == 9 ? 3 : (taps == 25 ? 5 : 1);           // blocks per (tile, slice): one kernel row each
+    const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1) * rows;
+    // one balanced round of equal blocks: as many as fit two per CU (the kernels hold 2-3 blocks per CU), never more -
+    // 516 blocks on 512 slots cost a whole extra round
+    static const int slots = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 2 * cus; }();
+    long long ks = std::max<long long>(1, slots / base);
     const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
-    return int(std::min<long long>(ks, 64));                         // ... but bound the partial-sum traffic
+    return int(std::min<long long>(ks, 64));                         // ... and bound the partial-sum traffic
 }
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
@@ -386,8 +406,8 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
     const int bt = w.taps == 1 ? 128 : 64;                           // block tile (see WT)
     a.n_co = cdiv(w.cout, bt); a.n_ci = cdiv(w.cin, bt);
-    // small layers: one kernel row per block (3x the blocks, a third of the registers -> more waves per SIMD)
-    const bool split_rows = w.taps == 25 || (w.taps == 9 && a.n_co * a.n_ci * a.ksplit * 3 < 768);
+    // one kernel row per block (3x / 5x the blocks, a third of the accumulators -> three waves per SIMD)
+    const bool split_rows = w.taps != 1;
     const int row_blocks = w.taps == 25 ? 5 : 3;
     int blocks = 0;
     a.njobs = w.nplanes;
@@ -400,8 +420,7 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     }
     if (!blocks || !w.B) return 0;
     if (w.taps == 25) hipLaunchKernelGGL((k_wgrad_mfma<25, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else if (w.taps == 9 && split_rows) hipLaunchKernelGGL((k_wgrad_mfma<9, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 3, 1>), dim3(blocks), dim3(256), 0, st, a);
+    else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     WgRedArgs r;
