@@ -389,13 +389,14 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     const int bt = taps == 1 ? 128 : 64;
     const int rows = taps == 9 ? 3 : (taps == 25 ? 5 : 1);           // blocks per (tile, slice): one kernel row each
     const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1) * rows;
-    // one balanced round of equal blocks: as many as fit two per CU (the kernels hold 2-3 blocks per CU), never more -
-    // 516 blocks on 512 slots cost a whole extra round
-    static const int slots = [] { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); return 2 * cus; }();
+    // one balanced round of equal blocks: as many as are resident at once, never more - 516 blocks on 512 slots cost a
+    // whole extra round (measured at 64 channels, batch 4: 2 per CU 4.90 ms/step, 3 per CU 4.79)
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int slots = (taps == 9 ? 3 : 2) * cus;                     // blocks the kernel variant holds per CU (registers / LDS)
     long long ks = std::max<long long>(1, slots / base);
     const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
-    return int(std::min<long long>(ks, 64));                         // ... and bound the partial-sum traffic
+    return int(std::min<long long>(ks, 96));                         // ... and bound the partial-sum traffic
 }
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
