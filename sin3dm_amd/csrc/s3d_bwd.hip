@@ -79,11 +79,12 @@ int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3]
 // dbias[p][co] = sum_b sum_r R[p][b][r][1][co]; optionally the per-sample sums over all planes (the gradient of
 // emb_out when it is added to h, use_scale_shift_norm=False, src/diffusion/unet_triplane.py:298-303).
 struct BiasArgs { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
+constexpr int kBiasCh = 16, kBiasLanes = 1024 / kBiasCh;   // channels per block x row lanes (few channels: more blocks for a latency-bound sum)
 __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
-    // 64 channels x 16 row lanes.  All (sample, plane) partial sums are accumulated first (independent loads in flight),
-    // then reduced over the lanes through LDS, four samples at a time.
-    __shared__ float sm[12][16][64];
-    const int cl = threadIdx.x & 63, lane = threadIdx.x >> 6, co = blockIdx.x * 64 + cl;
+    // All (sample, plane) partial sums are accumulated first (independent loads in flight), then reduced over the lanes
+    // through LDS in lane order, four samples at a time.
+    __shared__ float sm[12][kBiasLanes][kBiasCh];
+    const int cl = threadIdx.x % kBiasCh, lane = threadIdx.x / kBiasCh, co = blockIdx.x * kBiasCh + cl;
     float tot_p[3] = {0.f, 0.f, 0.f};
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = min(4, a.B - b0);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
                 float acc = 0.f;
                 if (bb < nb && co < a.C) {
                     const float* R = a.R[p] + size_t(b0 + bb) * a.h[p] * 3 * a.C + a.C + co;
-                    for (int r = lane; r < a.h[p]; r += 16) acc += R[size_t(r) * 3 * a.C];
+                    for (int r = lane; r < a.h[p]; r += kBiasLanes) acc += R[size_t(r) * 3 * a.C];
                 }
                 s[bb][p] = acc;
             }
@@ -110,8 +111,7 @@ __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
                 float tot = 0.f;
                 for (int p = 0; p < 3; ++p) {
                     float t = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) t += sm[bb * 3 + p][k][cl];
+                    for (int k = 0; k < kBiasLanes; ++k) t += sm[bb * 3 + p][k][cl];
                     tot += t; tot_p[p] += t;
                 }
                 if (a.per_sample) a.per_sample[size_t(b0 + bb) * a.per_sample_stride + co] = tot;
@@ -126,7 +126,7 @@ int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const
     BiasArgs a;
     for (int p = 0; p < 3; ++p) { a.R[p] = R[p]; a.dbias[p] = dbias ? dbias[p] : nullptr; a.h[p] = g.h[p]; }
     a.per_sample = per_sample; a.per_sample_stride = per_sample_stride; a.B = B; a.C = C;
-    hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, 64)), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_bias_grad, dim3(cdiv(C, kBiasCh)), dim3(1024), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
