@@ -134,71 +134,65 @@ int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const
 // ------------------------------------------------------------------ weight gradient of the two mean-channel slots
 // row-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_r' v[b][r'][ci] * R[b][r'-dr+1][dc][co]
 // col-varying slot:  dW[co][slot*C+ci][dr][dc] = sum_b sum_c' v[b][c'][ci] * Cs[b][c'-dc+1][dr][co]
-// One block = one 32(co) x 32(ci) tile of one slot with all nine taps as nine MFMA accumulators; the contraction
-// over (b, position) is split across the block's four waves and their partials are added through LDS in wave order.
+// One block = one 32(co) x 32(ci) tile of one slot and one tap offset t along the varying axis (three MFMA accumulators,
+// one per tap of the other axis); the contraction over (b, position) is split across the block's sixteen waves and
+// their partials are added through LDS in wave order.  The loop is bound by the latency of its operand loads (one
+// step = 4 dwords from L2 per lane for 3 MFMAs), so what counts is waves: 3 x 16 per tile instead of 4.
 struct SlotJob { const float* v; const float* S; float* dW; int L, slot, col_varying; };
 struct SlotArgs { SlotJob job[6]; int B, C, cout, ctot, n_ci; };
-__global__ __launch_bounds__(256) void k_slot_wgrad(SlotArgs a) {
-    __shared__ float red[4][16][64];
+constexpr int kSlotWaves = 16;
+__global__ __launch_bounds__(64 * kSlotWaves) void k_slot_wgrad(SlotArgs a) {
+    __shared__ float red[kSlotWaves][16][64];
     const SlotJob J = a.job[blockIdx.y];
-    const int tci = blockIdx.x % a.n_ci, tco = blockIdx.x / a.n_ci;
+    const int tci = blockIdx.x % a.n_ci, tco = blockIdx.x / a.n_ci, t = blockIdx.z;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, i = lane & 31, kk = lane >> 5;
     const int co = tco * 32 + i, ci = tci * 32 + i, L = J.L;
-    f32x16 acc[3][3];
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int pairs = (L + 1) / 2, total = a.B * pairs;
-    // one-deep software pipeline: the ten operand loads of step n+1 are in flight during the nine MFMAs of step n
-    float bv = 0.f, av[3][3];
-    auto load = [&](int it, float& b_out, float (&a_out)[3][3]) {
+    // one-deep software pipeline: the four operand loads of step n+1 are in flight during the MFMAs of step n
+    float bv = 0.f, av[3];
+    auto load = [&](int it, float& b_out, float (&a_out)[3]) {
         const int b = it / pairs, pos = (it % pairs) * 2 + kk;
         const bool in = it < total && pos < L;
         b_out = in ? J.v[(size_t(b) * L + pos) * a.C + ci] : 0.f;
+        const int q = pos - t + 1;
+        const bool ok = in && q >= 0 && q < L;
+        const float* S = J.S + (size_t(b) * L + (ok ? q : 0)) * 3 * a.cout + co;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int q = pos - t + 1;
-            const bool ok = in && q >= 0 && q < L;
-            const float* S = J.S + (size_t(b) * L + (ok ? q : 0)) * 3 * a.cout + co;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) a_out[t][j] = ok ? S[j * a.cout] : 0.f;
-        }
+        for (int j = 0; j < 3; ++j) a_out[j] = ok ? S[j * a.cout] : 0.f;
     };
     load(wid, bv, av);
-    for (int it = wid; it < total; it += 4) {
-        float nb, na[3][3];
-        load(it + 4, nb, na);
+    for (int it = wid; it < total; it += kSlotWaves) {
+        float nb, na[3];
+        load(it + kSlotWaves, nb, na);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bv, acc[t][j], 0, 0, 0);
+        for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         bv = nb;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) av[t][j] = na[t][j];
+        for (int j = 0; j < 3; ++j) av[j] = na[j];
     }
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int j = 0; j < 3; ++j) {
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            __syncthreads();
+        for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[j][r];
+        __syncthreads();
+        const int dr = J.col_varying ? j : t, dc = J.col_varying ? t : j;
+        for (int e = threadIdx.x; e < 1024; e += 64 * kSlotWaves) {
+            const int r = e >> 6, l = e & 63;
+            float v = red[0][r][l];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[wid][r][lane] = acc[t][j][r];
-            __syncthreads();
-            const int dr = J.col_varying ? j : t, dc = J.col_varying ? t : j;
-            for (int e = threadIdx.x; e < 1024; e += 256) {
-                const int r = e >> 6, l = e & 63;
-                const float v = red[0][r][l] + red[1][r][l] + red[2][r][l] + red[3][r][l];
-                const int oc = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ic = tci * 32 + (l & 31);
-                J.dW[(size_t(oc) * a.ctot + J.slot * a.C + ic) * 9 + dr * 3 + dc] = v;
-            }
+            for (int k = 1; k < kSlotWaves; ++k) v += red[k][r][l];
+            const int oc = tco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), ic = tci * 32 + (l & 31);
+            J.dW[(size_t(oc) * a.ctot + J.slot * a.C + ic) * 9 + dr * 3 + dc] = v;
         }
+    }
 }
 int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
     S3D_CHECK(s.C % 32 == 0 && s.cout % 32 == 0, S3D_ERR_INVALID, "slot_wgrad: channels must be multiples of 32");
@@ -212,7 +206,7 @@ int launch_slot_wgrad(const SlotWgradArgs& s, hipStream_t st) {
         SlotJob& jc = a.job[2 * p + 1];
         jc.v = s.colvec[p]; jc.S = s.Cs[p]; jc.dW = s.dW[p]; jc.L = s.g.w[p]; jc.slot = a_is_col ? 1 : 2; jc.col_varying = 1;
     }
-    hipLaunchKernelGGL(k_slot_wgrad, dim3((s.cout / 32) * a.n_ci, 6), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_slot_wgrad, dim3((s.cout / 32) * a.n_ci, 6, 3), dim3(64 * kSlotWaves), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
