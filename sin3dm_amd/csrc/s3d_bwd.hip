@@ -362,6 +362,159 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
             }
 }
 
+// ------------------------------------------------------------------ Winograd weight gradient of the 3x3 convolutions
+// Forward: Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile (s3d_wino.hip).  Hence
+//   dU[u][v][co][ci] = sum over tiles of (A dY A^T)[u][v][co] * (B^T d B)[u][v][ci]      (16 GEMMs, K = tiles)
+//   dg = G^T dU G                                                                          (k_wgrad_wino_reduce)
+// 16 multiplies per tile and channel pair instead of 36: 2.25x fewer MFMA flops than the direct weight gradient.
+// A block owns one 32(co) x 32(ci) pair and a slice of the pixel regions (8x16 pixels = 32 Winograd tiles, the
+// forward kernel's tile); its four waves own one row u of the frequency grid each (four accumulators).  A region's
+// input halo and dy tile are staged in LDS; a lane holds ONE channel (co for the
+// A operand, ci for the B operand) and, per MFMA step, one of two tiles (lane half = k index): it reads the 2 x 4
+// patch values and 2 x 2 dy values of its tile with ds_read_b32, transforms them in registers and feeds four MFMAs.
+constexpr int WW_TH = 8, WW_TW = 16, WW_HH = WW_TH + 2, WW_HW = WW_TW + 2, WW_LD = 36;
+struct WgwJob { const float* dy; const float* a; float* part; int h, w, tiles_x, regions; int block_begin; };
+struct WgwArgs { WgwJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci, njobs; };
+__global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
+    __shared__ __attribute__((aligned(16))) float sx[WW_HH * WW_HW * WW_LD];
+    __shared__ __attribute__((aligned(16))) float sdy[WW_TH * WW_TW * WW_LD];
+    int p = 0;
+    while (p + 1 < args.njobs && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
+    const WgwJob& J = args.job[p];
+    int local = blockIdx.x - J.block_begin;
+    const int ks = local % args.ksplit; local /= args.ksplit;
+    const int tci = local % args.n_ci, tco = local / args.n_ci;
+    const int co0 = tco * 32, ci0 = tci * 32;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // row u of B^T d B combines two patch rows, t = x + s*y: (d0,d2,-), (d1,d2,+), (d2,d1,-), (d1,d3,-);
+    // row u of A dY A^T combines the two dy rows with (c0, c1) = (1,0), (1,1), (1,-1), (0,-1)
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = u == 1 ? 1.f : -1.f;
+    const float c0 = u == 3 ? 0.f : 1.f, c1 = u == 0 ? 0.f : (u == 1 ? 1.f : -1.f);
+    f32x16 acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+
+    const long long total = (long long)J.regions * args.B;
+    const long long r_begin = total * ks / args.ksplit, r_end = total * (ks + 1) / args.ksplit;
+    constexpr int NX = (WW_HH * WW_HW * 8 + 255) / 256, NDY = (WW_TH * WW_TW * 8) / 256;
+    float4 rx[NX], rdy[NDY];
+    const int q = tid & 7, prow = tid >> 3;
+    // raw buffer loads: one byte offset per item, and an offset beyond the descriptor's range for everything outside the
+    // image (the hardware answers with zeros): no predicated branches around ten loads, 32-bit addressing
+    auto load_region = [&](long long rr) {
+        const int b = int(rr / J.regions), reg = int(rr % J.regions);
+        const int ty0 = (reg / J.tiles_x) * WW_TH, tx0 = (reg % J.tiles_x) * WW_TW;
+        const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.a + size_t(b) * J.h * J.w * args.a_cstride), 0, J.h * J.w * args.a_cstride * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.dy + size_t(b) * J.h * J.w * args.cout), 0, J.h * J.w * args.cout * 4, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int pix = k * 32 + prow, hy = pix / WW_HW, hx = pix - hy * WW_HW;
+            const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+            const bool ok = pix < WW_HH * WW_HW && gy >= 0 && gy < J.h && gx >= 0 && gx < J.w;
+            const unsigned off = ok ? unsigned((gy * J.w + gx) * args.a_cstride + ci0 + q * 4) * 4u : 0x80000000u;
+            rx[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsa, off, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) {
+            const int pix = k * 32 + prow, y = ty0 + pix / WW_TW, x = tx0 + pix % WW_TW;
+            const bool ok = y < J.h && x < J.w;
+            const unsigned off = ok ? unsigned((y * J.w + x) * args.cout + co0 + q * 4) * 4u : 0x80000000u;
+            rdy[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsd, off, 0, 0));
+        }
+    };
+    auto store_region = [&]() {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int pix = k * 32 + prow;
+            if (pix < WW_HH * WW_HW) *reinterpret_cast<float4*>(sx + pix * WW_LD + q * 4) = rx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NDY; ++k) *reinterpret_cast<float4*>(sdy + (k * 32 + prow) * WW_LD + q * 4) = rdy[k];
+    };
+    // operands of MFMA step st (tiles 2*st and 2*st + 1, one per lane half): 8 patch values, 4 dy values
+    struct Ops { float x[4], y[4], d0[2], d1[2]; };
+    auto lds_step = [&](int st, Ops& o) {
+        const int t = 2 * st + half, tr = t >> 3, tc = t & 7;
+        const float* px = sx + ((2 * tr + xrow) * WW_HW + 2 * tc) * WW_LD + i;
+        const float* py = sx + ((2 * tr + yrow) * WW_HW + 2 * tc) * WW_LD + i;
+        const float* pd = sdy + ((2 * tr) * WW_TW + 2 * tc) * WW_LD + i;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { o.x[b] = px[b * WW_LD]; o.y[b] = py[b * WW_LD]; }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) { o.d0[x] = pd[x * WW_LD]; o.d1[x] = pd[(WW_TW + x) * WW_LD]; }
+    };
+    for (long long rr = r_begin; rr < r_end; ++rr) {
+        // no register prefetch of the next region (40 VGPRs that made the allocator spill): with three blocks per CU the
+        // other waves of the SIMD keep the matrix pipe busy while this one waits for its loads
+        load_region(rr);
+        __syncthreads();                                  // everyone is done with the previous region
+        store_region();
+        __syncthreads();
+        Ops cur, nxt;
+        lds_step(0, cur);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            if (st + 1 < 16) lds_step(st + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            // B^T d B, row u: column pass then row pass
+            float t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[b] = fmaf(sgn, cur.y[b], cur.x[b]);
+            const float V[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+            // A dY A^T, row u
+            const float r0 = c0 * cur.d0[0] + c1 * cur.d1[0], r1 = c0 * cur.d0[1] + c1 * cur.d1[1];
+            const float M[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(M[v], V[v], acc[v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+    // partial [ks][16 freq][cout][cin]
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        float* dst = J.part + ((size_t(ks) * 16 + u * 4 + v) * args.cout + co0) * args.cin + ci0 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[size_t((r & 3) + 8 * (r >> 2) + 4 * half) * args.cin] = acc[v][r];
+    }
+}
+// dg = G^T (sum of the slices' dU) G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
+__global__ void k_wgrad_wino_reduce(WgwRedArgs a) {
+    const long long n = (long long)a.cout * a.cin;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int p = blockIdx.y;
+    float S[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) S[f] = 0.f;
+    for (int k = 0; k < a.ksplit; ++k)
+#pragma unroll
+        for (int f = 0; f < 16; ++f) S[f] += a.part[p][(size_t(k) * 16 + f) * n + idx];
+    float T[4][3];
+#pragma unroll
+    for (int uu = 0; uu < 4; ++uu) {
+        const float h1 = 0.5f * S[uu * 4 + 1], h2 = 0.5f * S[uu * 4 + 2];
+        T[uu][0] = S[uu * 4 + 0] + (h1 + h2); T[uu][1] = h1 - h2; T[uu][2] = (h1 + h2) + S[uu * 4 + 3];
+    }
+    const int ci = int(idx % a.cin), co = int(idx / a.cin);
+    if (ci >= a.cin_store) return;
+    float* d = a.dW[p] + (size_t(co) * a.ctot + ci) * 9;
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const float h1 = 0.5f * T[1][jj], h2 = 0.5f * T[2][jj];
+        d[0 * 3 + jj] = T[0][jj] + (h1 + h2); d[1 * 3 + jj] = h1 - h2; d[2 * 3 + jj] = (h1 + h2) + T[3][jj];
+    }
+}
+static bool wgrad_use_wino() {
+    static const bool on = !(getenv("S3D_WGRAD_WINO") && atoi(getenv("S3D_WGRAD_WINO")) == 0);
+    return on;
+}
+
 struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
 __global__ void k_wgrad_reduce(WgRedArgs a) {
     const long long n = (long long)a.cout * a.cin * a.taps;
@@ -377,26 +530,58 @@ __global__ void k_wgrad_reduce(WgRedArgs a) {
 }
 
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     long long tiles = 0;
     int planes = 0;
+    if (taps == 9 && wgrad_use_wino()) {
+        // Winograd kernel: 32x32 channel pairs, 8x16-pixel regions, three blocks per CU; one balanced round of blocks
+        for (int p = 0; p < 3; ++p) { tiles += (long long)cdiv(g.h[p], WW_TH) * cdiv(g.w[p], WW_TW); planes += g.h[p] > 0; }
+        const long long base = (long long)(cout / 32) * (cin / 32) * std::max(planes, 1);
+        long long ks = std::max<long long>(1, 3 * cus / base);
+        const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
+        return int(std::max<long long>(1, std::min(std::min(ks, per_plane), (long long)96)));
+    }
     for (int p = 0; p < 3; ++p) { tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC); planes += g.h[p] > 0; }
     const int bt = taps == 1 ? 128 : 64;
     const int rows = taps == 9 ? 3 : (taps == 25 ? 5 : 1);           // blocks per (tile, slice): one kernel row each
     const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1) * rows;
     // one balanced round of equal blocks: as many as are resident at once, never more - 516 blocks on 512 slots cost a
     // whole extra round (measured at 64 channels, batch 4: 2 per CU 4.90 ms/step, 3 per CU 4.79)
-    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     const int slots = (taps == 9 ? 3 : 2) * cus;                     // blocks the kernel variant holds per CU (registers / LDS)
     long long ks = std::max<long long>(1, slots / base);
     const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
     return int(std::min<long long>(ks, 96));                         // ... and bound the partial-sum traffic
 }
-size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
+size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * (taps == 9 && wgrad_use_wino() ? 16 : taps); }
 
 int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     S3D_CHECK(w.taps == 9 || w.taps == 1 || w.taps == 25, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
     S3D_CHECK(w.cin % 32 == 0 && w.cout % 32 == 0, S3D_ERR_INVALID, "wgrad: channels must be multiples of 32");
+    if (w.taps == 9 && wgrad_use_wino()) {
+        WgwArgs a;
+        a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
+        a.n_co = w.cout / 32; a.n_ci = w.cin / 32; a.njobs = w.nplanes;
+        int blocks = 0;
+        for (int p = 0; p < w.nplanes; ++p) {
+            WgwJob& J = a.job[p];
+            J.dy = w.dy.p[p]; J.a = w.a.p[p]; J.part = w.part[p]; J.h = w.dy.g.h[p]; J.w = w.dy.g.w[p];
+            S3D_CHECK(size_t(J.h) * J.w * std::max(w.a.C, w.cout) * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wgrad: a plane of one sample must stay below 2 GiB");
+            J.tiles_x = cdiv(J.w, WW_TW); J.regions = J.tiles_x * cdiv(J.h, WW_TH);
+            J.block_begin = blocks;
+            blocks += a.n_co * a.n_ci * a.ksplit;
+        }
+        if (!blocks || !w.B) return 0;
+        hipLaunchKernelGGL(k_wgrad_wino, dim3(blocks), dim3(256), 0, st, a);
+        S3D_HIP(hipGetLastError());
+        WgwRedArgs r;
+        for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
+        r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin;
+        const long long n = (long long)w.cout * w.cin;
+        hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3((unsigned)((n + 255) / 256), w.nplanes), dim3(256), 0, st, r);
+        S3D_HIP(hipGetLastError());
+        return 0;
+    }
     WgArgs a;
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
     const int bt = w.taps == 1 ? 128 : 64;                           // block tile (see WT)
