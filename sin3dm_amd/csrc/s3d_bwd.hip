@@ -551,7 +551,7 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     long long ks = std::max<long long>(1, slots / base);
     const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
-    return int(std::min<long long>(ks, 96));                         // ... and bound the partial-sum traffic
+    return int(std::min<long long>(ks, 128));                        // ... and bound the partial-sum traffic
 }
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * (taps == 9 && wgrad_use_wino() ? 16 : taps); }
 
