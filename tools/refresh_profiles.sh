@@ -29,7 +29,7 @@ python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 # 5. other configurations, training, decode
 python3 tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/${R}_other_configs.txt
 { python3 tools/bench_train.py 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
-python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${R}_decode_and_isosurface.txt
+{ python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
 # 6. Winograd kernel alone, with per-block phase times
 [ -x tools/ub_wino_t ] && timeout 120 tools/ub_wino_t > $OUT/${R}_wino_ubench_raw.txt
 ls -la $OUT
