@@ -57,7 +57,7 @@ constexpr int W2_ABUF = W2_ITEMS_PT * 32 * W_LD;          // LDS buffer stride: 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef W_TIMING
-__device__ unsigned long long* g_wtime;       // tools/wino_ubench.hip: per block {entry, k-loop begin, k-loop end, exit} (wall clock) + hw id
+__device__ unsigned long long* g_wtime;       // tools/wino_ubench.hip: eight wall-clock stamps per block (entry, halo landed, first MFMA, last MFMA, epilogue barriers, exit)
 #define W_STAMP(k) if (threadIdx.x == 0) g_wtime[size_t(blockIdx.x) * 8 + (k)] = wall_clock64();
 #else
 #define W_STAMP(k)
@@ -350,8 +350,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         }
     }
     W_STAMP(3)
-#ifdef W_TIMING
-#endif
 }
 
 // ------------------------------------------------------------------ three waves per SIMD: one frequency row per wave
