@@ -88,6 +88,20 @@ def test_training_losses_and_grads(tag, mc, raw, ssn, cm, B):
     assert w["norm"] < 2e-4 and w["proj"] < 2e-4 and w["head"] < 2e-3 and w["full"] < 2e-4, (w, _offenders(grads, g, f"{tag}.grad"))
 
 
+def test_grads_with_the_direct_weight_gradient_kernel():
+    """S3D_WGRAD_WINO=0 (the direct 3x3 weight gradient, default for 1x1 / 5x5) against the same golden gradients; the
+    switch is read once per process, hence the subprocess."""
+    import os, subprocess, sys
+    code = ("import sys; sys.path.insert(0, 'tests')\n"
+            "import test_hip_train as tt\n"
+            "tt.test_training_losses_and_grads(*tt.TRAIN_CASES[0]); tt.test_training_losses_and_grads(*tt.TRAIN_CASES[4])\n"
+            "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_WGRAD_WINO="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_fast_path_equals_autograd_and_is_repeatable():
     """training_losses_and_grads (no autograd graph) gives the same flat gradient as loss.backward(), bit for bit,
     and twice the same bits (all reductions have a fixed order)."""
