@@ -149,8 +149,12 @@ int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int h, int w,
 
 // in_conv: composed NCHW x [B,Cin,H+D,W+D] -> three NHWC planes through a 1x1 conv (Cin small).
 // wT: [3][Cin][Cout] (transposed), bias [3][Cout]
+// part != null (only when in_conv_gn_parts() says the shape supports it, with exactly those part counts): the kernel
+// also writes the GroupNorm partials of its output
+struct GnPartials;
+bool in_conv_gn_parts(const Geo& g, int Cin, int Cout, int nparts[3]);
 int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const float* wT, const float* bias,
-                   int Cout, Tri& out, hipStream_t st);
+                   int Cout, Tri& out, hipStream_t st, const GnPartials* part = nullptr);
 
 // GroupNorm statistics.  Stage 1: producers emit partial {sum, sumsq} in double, indexed
 //   p[(((b*3 + plane) * nsub + sub) * maxparts + part) * 2 + {0,1}],  sub = channel / sg
@@ -201,7 +205,8 @@ int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials
 int launch_bilinear(const float* in, int B, int C, int hi, int wi, float* out, int ho, int wo, int out_cstride,
                     int out_coff, hipStream_t st);
 // exact-2x bilinear upsample of u fused with the concat [up(u) | skip] for all three planes (out.C = u.C + sk.C)
-int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st);
+bool upcat_gn_parts(const Geo& out_g, int C, int nparts[3]);      // part counts of the form that also emits GroupNorm partials
+int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st, const GnPartials* part = nullptr);
 int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, int out_cstride, int out_coff,
                       hipStream_t st);
 

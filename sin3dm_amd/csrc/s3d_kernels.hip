@@ -125,8 +125,9 @@ __global__ void k_in_conv(InConvArgs a) {
 // consecutive in the composed input map (a row segment of xy / xz, a column segment of yz), stages their Cin x PX input
 // values with coalesced loads and lets every thread (quad, pixel lane) form PX/8 outputs from LDS broadcasts.
 template <int PX>
-__global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, int segs1, int segs2) {
+__global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, int segs1, int segs2, double* part, int maxparts) {
     __shared__ __attribute__((aligned(16))) float sx[PX][16];
+    __shared__ float sred[2][8][128];                          // GroupNorm partials of the block: [sum | sumsq][pixel lane][channel]
     const int b = blockIdx.y;
     int blk = blockIdx.x, p = 0;
     if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; } }
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, in
     for (int ci = 0; ci < 16; ++ci) wv[ci] = ci < a.Cin ? wq[size_t(ci) * 32] : make_float4(0, 0, 0, 0);
     const float4 bias = reinterpret_cast<const float4*>(a.bias + size_t(p) * a.Cout)[q];
     __syncthreads();
+    const int blk_in_plane = blk;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < PX / 8; ++k) {
         const int e = k * 8 + lp;
@@ -167,10 +170,32 @@ __global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, in
         }
         const int y = p == 2 ? s0 + e : line, xx = p == 2 ? line : s0 + e;
         reinterpret_cast<float4*>(a.out[p] + ((size_t(b) * h + y) * w + xx) * a.Cout)[q] = acc;
+        gs[0] += acc.x; gs[1] += acc.y; gs[2] += acc.z; gs[3] += acc.w;
+        gss[0] = fmaf(acc.x, acc.x, gss[0]); gss[1] = fmaf(acc.y, acc.y, gss[1]); gss[2] = fmaf(acc.z, acc.z, gss[2]); gss[3] = fmaf(acc.w, acc.w, gss[3]);
+    }
+    if (part) {                                                // one GroupNorm part per block (Cout = 128: a group = one channel quad)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sred[0][lp][4 * q + k] = gs[k]; sred[1][lp][4 * q + k] = gss[k]; }
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            const int g = threadIdx.x;
+            double S = 0, SS = 0;
+            for (int l = 0; l < 8; ++l)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { S += sred[0][l][4 * g + k]; SS += sred[1][l][4 * g + k]; }
+            double* o = part + (((size_t(b) * 3 + p) * 32 + g) * maxparts + blk_in_plane) * 2;
+            o[0] = S; o[1] = SS;
+        }
     }
 }
+constexpr int kInConvPx = 32;
+bool in_conv_gn_parts(const Geo& g, int Cin, int Cout, int nparts[3]) {
+    if (!(Cout == 128 && Cin <= 16)) return false;
+    for (int p = 0; p < 3; ++p) { const int len = p == 2 ? g.h[p] : g.w[p], lines = p == 2 ? g.w[p] : g.h[p]; nparts[p] = lines * ((len + kInConvPx - 1) / kInConvPx); }
+    return true;
+}
 int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const float* wT, const float* bias,
-                   int Cout, Tri& out, hipStream_t st) {
+                   int Cout, Tri& out, hipStream_t st, const GnPartials* part) {
     InConvArgs a;
     a.x = x; a.wT = wT; a.bias = bias; a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
     a.pix_begin[0] = 0;
@@ -180,14 +205,15 @@ int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const fl
     }
     long long n = a.pix_begin[3] * (Cout / 4) * B;
     if (!n) return 0;
-    if (Cout == 128 && Cin <= 16) {                                   // the LDS-staged form (22 -> 10 us at 128^3; 16 / 32 / 64 pixels per block measured equal)
-        constexpr int px = 32;
-        auto segs = [&](int p) { const int len = p == 2 ? a.h[p] : a.w[p], lines = p == 2 ? a.w[p] : a.h[p]; return lines * ((len + px - 1) / px); };
-        const int s0 = segs(0), s1 = segs(1), s2 = segs(2);
-        hipLaunchKernelGGL(k_in_conv_lds<px>, dim3(s0 + s1 + s2, B), dim3(256), 0, st, a, s0, s1, s2);
+    int segs[3];
+    if (in_conv_gn_parts(out.g, Cin, Cout, segs)) {                   // the LDS-staged form (22 -> 10 us at 128^3; 16 / 32 / 64 pixels per block measured equal)
+        S3D_CHECK(!part || (part->nsub == 32 && part->nparts[0] == segs[0] && part->nparts[1] == segs[1] && part->nparts[2] == segs[2]), S3D_ERR_INVALID, "in_conv: GroupNorm partial layout");
+        hipLaunchKernelGGL(k_in_conv_lds<kInConvPx>, dim3(segs[0] + segs[1] + segs[2], B), dim3(256), 0, st, a, segs[0], segs[1], segs[2],
+                           part ? part->p : nullptr, part ? part->maxparts : 0);
         S3D_HIP(hipGetLastError());
         return 0;
     }
+    S3D_CHECK(!part, S3D_ERR_INVALID, "in_conv: this shape does not emit GroupNorm partials");
     hipLaunchKernelGGL(k_in_conv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -592,7 +618,58 @@ __global__ void k_upcat(UpCatArgs a) {
     }
     reinterpret_cast<float4*>(a.out[p])[((size_t(b) * ho + yo) * wo + xo) * oq + q] = o;
 }
-int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st) {
+// The same pass with 4 pixels x all channel quads per block, which also leaves the block's GroupNorm partial of the
+// concatenated tensor (per-channel sums of the 4 pixels through LDS, then 32 threads add their group's channels).
+constexpr int kUpcatPx = 4;
+__global__ void k_upcat_gn(UpCatArgs a, double* part, int maxparts) {
+    extern __shared__ __attribute__((aligned(16))) float up_sm[];     // [2][kUpcatPx][C]
+    const int p = blockIdx.y, b = blockIdx.z;
+    const int hi = a.hi[p], wi = a.wi[p], ho = 2 * hi, wo = 2 * wi, npix = ho * wo;
+    const int oq = a.cuq + a.csq, C = oq * 4;
+    const int q = threadIdx.x % oq, lp = threadIdx.x / oq;
+    const int pix = blockIdx.x * kUpcatPx + lp;
+    if (int(blockIdx.x) * kUpcatPx >= npix) return;
+    float4 o = make_float4(0, 0, 0, 0);
+    if (pix < npix) {
+        const int xo = pix % wo, yo = pix / wo;
+        if (q >= a.cuq) {
+            o = reinterpret_cast<const float4*>(a.sk[p])[((size_t(b) * ho + yo) * wo + xo) * a.csq + (q - a.cuq)];
+        } else {
+            float fy = 0.5f * (float(yo) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = 0.5f * (float(xo) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+            int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+            const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+            const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+            const float4* src = reinterpret_cast<const float4*>(a.u[p]) + size_t(b) * hi * wi * a.cuq + q;
+            const float4 v00 = src[(size_t(y0) * wi + x0) * a.cuq], v01 = src[(size_t(y0) * wi + x1) * a.cuq];
+            const float4 v10 = src[(size_t(y1) * wi + x0) * a.cuq], v11 = src[(size_t(y1) * wi + x1) * a.cuq];
+            o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+            o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+            o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+            o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+        }
+        reinterpret_cast<float4*>(a.out[p])[((size_t(b) * ho + yo) * wo + xo) * oq + q] = o;
+    }
+    float* ss = up_sm + kUpcatPx * C;
+    *reinterpret_cast<float4*>(up_sm + lp * C + 4 * q) = o;                                   // pixels past the end contribute zeros
+    *reinterpret_cast<float4*>(ss + lp * C + 4 * q) = make_float4(o.x * o.x, o.y * o.y, o.z * o.z, o.w * o.w);
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x, cg = C / 32;
+        double S = 0, SS = 0;
+        for (int l = 0; l < kUpcatPx; ++l)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) { S += up_sm[l * C + c]; SS += ss[l * C + c]; }
+        double* op = part + (((size_t(b) * 3 + p) * 32 + g) * maxparts + blockIdx.x) * 2;
+        op[0] = S; op[1] = SS;
+    }
+}
+bool upcat_gn_parts(const Geo& out_g, int C, int nparts[3]) {
+    if (C % 32 != 0 || C / 4 * kUpcatPx > 1024) return false;
+    for (int p = 0; p < 3; ++p) nparts[p] = (out_g.h[p] * out_g.w[p] + kUpcatPx - 1) / kUpcatPx;
+    return true;
+}
+int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st, const GnPartials* part) {
     UpCatArgs a;
     a.cuq = u.C / 4; a.csq = sk.C / 4; a.B = B; a.begin[0] = 0;
     for (int p = 0; p < 3; ++p) {
@@ -601,6 +678,15 @@ int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st) {
     }
     const long long n = a.begin[3] * B;
     if (!n) return 0;
+    if (part) {
+        int np[3];
+        S3D_CHECK(upcat_gn_parts(out.g, out.C, np) && part->nsub == 32 && part->nparts[0] == np[0] && part->nparts[1] == np[1] && part->nparts[2] == np[2],
+                  S3D_ERR_INVALID, "upcat: GroupNorm partial layout");
+        const int mx = std::max(np[0], std::max(np[1], np[2]));
+        hipLaunchKernelGGL(k_upcat_gn, dim3(mx, 3, B), dim3(out.C / 4 * kUpcatPx), size_t(2) * kUpcatPx * out.C * sizeof(float), st, a, part->p, part->maxparts);
+        S3D_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(k_upcat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

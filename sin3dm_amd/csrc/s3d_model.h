@@ -180,11 +180,12 @@ struct Fwd {
     // upsample+concat were 1.5x slower than flat kernel + read pass: 384 blocks cannot keep enough loads in flight):
     // allocate the partials before the launch, finish() after it; the tensor then carries its statistics like a conv output.
     struct ChunkStats { GnPartials part; GnStats gs; };
-    ChunkStats chunk_stats() {
+    ChunkStats chunk_stats(const int* nparts = nullptr) {   // nparts: per-plane part counts of the producer (default kGnChunks)
         ChunkStats c;
-        c.part.p = ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64);
-        c.part.maxparts = kGnChunks; c.part.nsub = 32;
-        for (int p = 0; p < 3; ++p) c.part.nparts[p] = kGnChunks;
+        int mx = 0;
+        for (int p = 0; p < 3; ++p) { c.part.nparts[p] = nparts ? nparts[p] : kGnChunks; mx = std::max(mx, c.part.nparts[p]); }
+        c.part.maxparts = mx; c.part.nsub = 32;
+        c.part.p = ar().alloc<double>(size_t(B) * 3 * mx * 64);
         c.gs.mr = ar().alloc<float>(size_t(B) * 3 * 64);
         return c;
     }

@@ -224,7 +224,14 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
 
     Geo g0 = Geo::from_hwd(H, W, D);
     Tri h = f.alloc_tri(c.channel_mult[0] * mc, g0);
-    if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st));
+    {
+        int np[3];
+        if (in_conv_gn_parts(h.g, c.in_channels, h.C, np)) {        // the kernel leaves the GroupNorm partials of its output
+            const Fwd::ChunkStats cs = f.chunk_stats(np);
+            if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st, &cs.part));
+            S3D_TRY(f.finish(cs, h));
+        } else if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st));
+    }
     if (tape) tape->h0 = h;
 
     std::vector<Tri> hs;
@@ -256,7 +263,12 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             inp = f.alloc_tri(h.C + sk.C, sk.g);
             const Geo up = h.g.twice();
             if (up == sk.g) {                                       // the common case: one fused pass for all planes
-                if (!meas) S3D_TRY(launch_upcat(h, sk, B, inp, st));
+                int np[3];
+                if (upcat_gn_parts(inp.g, inp.C, np)) {
+                    const Fwd::ChunkStats cs = f.chunk_stats(np);
+                    if (!meas) S3D_TRY(launch_upcat(h, sk, B, inp, st, &cs.part));
+                    S3D_TRY(f.finish(cs, inp));
+                } else if (!meas) S3D_TRY(launch_upcat(h, sk, B, inp, st));
             } else
             for (int p = 0; p < 3; ++p) {
                 const bool same = up.h[p] == sk.g.h[p] && up.w[p] == sk.g.w[p];
