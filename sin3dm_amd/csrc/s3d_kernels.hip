@@ -121,13 +121,14 @@ __global__ void k_in_conv(InConvArgs a) {
     }
     reinterpret_cast<float4*>(a.out[p] + ((size_t(b) * a.h[p] + y) * a.w[p] + xx) * a.Cout)[q] = acc;
 }
-// LDS-staged form for Cout = 128 (32 channel quads = half a wave per pixel) and Cin <= 16: a block owns PX pixels that are
+// LDS-staged form for Cout = 64 / 128 / 256 and Cin <= 16: a block owns PX pixels that are
 // consecutive in the composed input map (a row segment of xy / xz, a column segment of yz), stages their Cin x PX input
 // values with coalesced loads and lets every thread (quad, pixel lane) form PX/8 outputs from LDS broadcasts.
-template <int PX>
+template <int PX, int CQ>                                  // CQ = channel quads per pixel (Cout / 4): 16, 32 or 64
 __global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, int segs1, int segs2, double* part, int maxparts) {
+    constexpr int LANES = 256 / CQ, C = 4 * CQ;             // pixel lanes of the block
     __shared__ __attribute__((aligned(16))) float sx[PX][16];
-    __shared__ float sred[2][8][128];                          // GroupNorm partials of the block: [sum | sumsq][pixel lane][channel]
+    __shared__ float sred[2][LANES][C];                      // GroupNorm partials of the block: [sum | sumsq][pixel lane][channel]
     const int b = blockIdx.y;
     int blk = blockIdx.x, p = 0;
     if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; } }
@@ -143,18 +144,17 @@ __global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, in
         const int ci = it / PX, e = it - ci * PX;
         sx[e][ci] = ci < a.Cin && s0 + e < len ? xb[(size_t(ci) * Hc + sy) * Wc + sx0 + e] : 0.f;
     }
-    const int q = threadIdx.x & 31, lp = threadIdx.x >> 5;
+    const int q = threadIdx.x % CQ, lp = threadIdx.x / CQ;
     const float4* wq = reinterpret_cast<const float4*>(a.wT + size_t(p) * a.Cin * a.Cout) + q;
     float4 wv[16];
 #pragma unroll
-    for (int ci = 0; ci < 16; ++ci) wv[ci] = ci < a.Cin ? wq[size_t(ci) * 32] : make_float4(0, 0, 0, 0);
+    for (int ci = 0; ci < 16; ++ci) wv[ci] = ci < a.Cin ? wq[size_t(ci) * CQ] : make_float4(0, 0, 0, 0);
     const float4 bias = reinterpret_cast<const float4*>(a.bias + size_t(p) * a.Cout)[q];
     __syncthreads();
-    const int blk_in_plane = blk;
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < PX / 8; ++k) {
-        const int e = k * 8 + lp;
+    for (int k = 0; k < PX / LANES; ++k) {
+        const int e = k * LANES + lp;
         if (s0 + e >= len) continue;
         float4 acc = bias;
 #pragma unroll
@@ -173,24 +173,25 @@ __global__ __launch_bounds__(256) void k_in_conv_lds(InConvArgs a, int segs0, in
         gs[0] += acc.x; gs[1] += acc.y; gs[2] += acc.z; gs[3] += acc.w;
         gss[0] = fmaf(acc.x, acc.x, gss[0]); gss[1] = fmaf(acc.y, acc.y, gss[1]); gss[2] = fmaf(acc.z, acc.z, gss[2]); gss[3] = fmaf(acc.w, acc.w, gss[3]);
     }
-    if (part) {                                                // one GroupNorm part per block (Cout = 128: a group = one channel quad)
+    if (part) {                                                // one GroupNorm part per block
 #pragma unroll
         for (int k = 0; k < 4; ++k) { sred[0][lp][4 * q + k] = gs[k]; sred[1][lp][4 * q + k] = gss[k]; }
         __syncthreads();
         if (threadIdx.x < 32) {
+            constexpr int cg = C / 32;
             const int g = threadIdx.x;
             double S = 0, SS = 0;
-            for (int l = 0; l < 8; ++l)
+            for (int l = 0; l < LANES; ++l)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { S += sred[0][l][4 * g + k]; SS += sred[1][l][4 * g + k]; }
-            double* o = part + (((size_t(b) * 3 + p) * 32 + g) * maxparts + blk_in_plane) * 2;
+                for (int k = 0; k < cg; ++k) { S += sred[0][l][cg * g + k]; SS += sred[1][l][cg * g + k]; }
+            double* o = part + (((size_t(b) * 3 + p) * 32 + g) * maxparts + blk) * 2;
             o[0] = S; o[1] = SS;
         }
     }
 }
 constexpr int kInConvPx = 32;
 bool in_conv_gn_parts(const Geo& g, int Cin, int Cout, int nparts[3]) {
-    if (!(Cout == 128 && Cin <= 16)) return false;
+    if (!((Cout == 64 || Cout == 128 || Cout == 256) && Cin <= 16)) return false;
     for (int p = 0; p < 3; ++p) { const int len = p == 2 ? g.h[p] : g.w[p], lines = p == 2 ? g.w[p] : g.h[p]; nparts[p] = lines * ((len + kInConvPx - 1) / kInConvPx); }
     return true;
 }
@@ -208,8 +209,12 @@ int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const fl
     int segs[3];
     if (in_conv_gn_parts(out.g, Cin, Cout, segs)) {                   // the LDS-staged form (22 -> 10 us at 128^3; 16 / 32 / 64 pixels per block measured equal)
         S3D_CHECK(!part || (part->nsub == 32 && part->nparts[0] == segs[0] && part->nparts[1] == segs[1] && part->nparts[2] == segs[2]), S3D_ERR_INVALID, "in_conv: GroupNorm partial layout");
-        hipLaunchKernelGGL(k_in_conv_lds<kInConvPx>, dim3(segs[0] + segs[1] + segs[2], B), dim3(256), 0, st, a, segs[0], segs[1], segs[2],
-                           part ? part->p : nullptr, part ? part->maxparts : 0);
+        const dim3 grid(segs[0] + segs[1] + segs[2], B);
+        double* pp = part ? part->p : nullptr;
+        const int mp = part ? part->maxparts : 0;
+        if (Cout == 64) hipLaunchKernelGGL((k_in_conv_lds<kInConvPx, 16>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], pp, mp);
+        else if (Cout == 128) hipLaunchKernelGGL((k_in_conv_lds<kInConvPx, 32>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], pp, mp);
+        else hipLaunchKernelGGL((k_in_conv_lds<kInConvPx, 64>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], pp, mp);
         S3D_HIP(hipGetLastError());
         return 0;
     }
