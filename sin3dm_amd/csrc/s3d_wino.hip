@@ -362,9 +362,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
 constexpr int W4_ABUF = W2_HH * W2_HW * W_LD;             // halo buffer stride (unpadded: the last staging round is predicated)
 constexpr int W4_IMG = (W2_TH / 2) * W2_TW * 32;          // one share image: [4 tile rows][16 columns][32 channels]
 __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
-    // k-loop: two halo buffers; epilogue: six share images (three per output-row parity) over the same memory
+    // k-loop: two halo buffers; epilogue: four share images (one per wave) over the same memory
     __shared__ __attribute__((aligned(16))) float smem[2 * W4_ABUF];
-    static_assert(6 * W4_IMG <= 2 * W4_ABUF, "LDS plan");
+    static_assert(4 * W4_IMG <= 2 * W4_ABUF, "LDS plan");
     W_STAMP(0)
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     int bid = blockIdx.x;
@@ -503,9 +503,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
 
     // ---- epilogue.  M[v] = acc[v] is row u of the frequency grid.  Column pass first (c0 = M0 + M1 + M2, c1 = M1 - M2 - M3
     // give the two pixels of a tile row); output row 0 of a tile is c(u0) + c(u1) + c(u2), row 1 is c(u1) - c(u2) - c(u3):
-    // every wave writes its signed contribution into share images [4 tile rows][16 columns][32 channels] (three per
-    // output-row parity), then threads owning 4 consecutive channels of a pixel add three images, the rank-1 tables,
-    // the residual and the bias and store 16 bytes.
+    // every wave writes its column-passed row as a share image [4 tile rows][16 columns][32 channels], then threads
+    // owning 4 consecutive channels of a pixel combine three images, add the rank-1 tables, the residual and the bias
+    // and store 16 bytes.
     const float* __restrict__ p_bias = J.bias;
     const float* __restrict__ p_bbias = J.bbias;
     const float* __restrict__ p_rcol = J.rcol;
@@ -516,18 +516,15 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
     __syncthreads();                                     // all patch reads of the last step are done
     W_STAMP(5)
     {
-        // image index: parity 0 <- u0, u1, u2 (images 0, 1, 2); parity 1 <- u1, u2, u3 (images 3, 4, 5)
-        float* img_a = smem + (u < 3 ? u : 5) * W4_IMG + i;             // first image this wave writes
-        float* img_b = smem + (u == 1 ? 3 : 4) * W4_IMG + i;            // second one (u = 1, 2 only)
-        const float sa = u == 3 ? -1.f : 1.f, sb = u == 2 ? -1.f : 1.f;
+        // wave u writes image u: its column-passed row, 32 values per lane (the LDS write port is what this phase waits for:
+        // twelve waves of a CU arrive together)
+        float* img = smem + u * W4_IMG + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r];
-            const float c0 = m0 + m1 + m2, c1 = m1 - m2 - m3;
             const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;
             const int pp = ((ti >> 3) * W2_TW + 2 * (ti & 7)) * 32;
-            img_a[pp] = sa * c0; img_a[pp + 32] = sa * c1;
-            if (u == 1 || u == 2) { img_b[pp] = sb * c0; img_b[pp + 32] = sb * c1; }
+            img[pp] = m0 + m1 + m2; img[pp + 32] = m1 - m2 - m3;
         }
     }
     // finishing thread: channels co4..co4+3 of pixel column xl, rows rsel*4 .. rsel*4+3 of the tile
@@ -544,10 +541,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
     if (p_rcol) {
+        // the column table only depends on the row through its edge variant: away from the top / bottom edge of the image
+        // (a block-uniform test) one load serves the four rows
+        if (ty0 > 0 && ty0 + W2_TH < h) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + 0) * cout + coc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int y = ty0 + rsel * 4 + k;
-            tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + w_edge_variant(y < h ? y : 0, h)) * cout + coc);
+            for (int k = 0; k < 4; ++k) tcol[k] = v0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + w_edge_variant(y < h ? y : 0, h)) * cout + coc);
+            }
         }
     }
     if (p_rrow) {
@@ -571,10 +576,12 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int yl = rsel * 4 + k, y = ty0 + yl;
-        const float* sp = smem + (yl & 1) * 3 * W4_IMG + ((yl >> 1) * W2_TW + xl) * 32 + quad * 4;
+        // output row 0 of a tile = c(u0) + c(u1) + c(u2), row 1 = c(u1) - c(u2) - c(u3)
+        const float* sp = smem + (yl & 1) * W4_IMG + ((yl >> 1) * W2_TW + xl) * 32 + quad * 4;
         const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + W4_IMG),
                     kc = *reinterpret_cast<const f32x4*>(sp + 2 * W4_IMG);
-        const f32x4 v = (((ka + kb) + kc) + base4) + ((tcol[k] + trow[k]) + tres[k]);
+        const f32x4 sum3 = (yl & 1) ? (ka - kb) - kc : (ka + kb) + kc;
+        const f32x4 v = (sum3 + base4) + ((tcol[k] + trow[k]) + tres[k]);
         if (x_ok && y < h) {
             *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
             gs4 += v; gss4 += v * v;
