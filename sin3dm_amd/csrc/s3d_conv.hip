@@ -505,7 +505,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
     if (conv_use_naive()) return launch_conv_naive(kind, a, st);
-    // Tile choice (measured, tools/run_cfgs.sh + tools/conv_ubench.hip): the 64-pixel x 64-cout tile wins at every
+    // Tile choice (measured, tools/conv_ubench.hip and in the step; for 1x1 again after the Winograd rework): the 64-pixel x 64-cout tile wins at every
     // size of this network because three blocks stay resident per CU (47 KB LDS each) and their staggered barriers keep
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
