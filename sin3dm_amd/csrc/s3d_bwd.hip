@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
     constexpr int NT = TAPS == 1 ? 1 : KW * TROWS;                    // taps of this block
     constexpr int NDY = (NP * WG_TR * WG_TC * 8) / 256, NA = (NP * AR * AC * 8 + 255) / 256;
     int p = 0;
-    while (p + 1 < args.njobs && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) p += (k < args.njobs && int(blockIdx.x) >= args.job[k].block_begin) ? 1 : 0;   // independent kernarg loads
     const WgJob& J = args.job[p];
     int local = blockIdx.x - J.block_begin;
     int dr0 = 0;
@@ -379,7 +380,8 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
     __shared__ __attribute__((aligned(16))) float sx[WW_HH * WW_HW * WW_LD];
     __shared__ __attribute__((aligned(16))) float sdy[WW_TH * WW_TW * WW_LD];
     int p = 0;
-    while (p + 1 < args.njobs && int(blockIdx.x) >= args.job[p + 1].block_begin) ++p;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) p += (k < args.njobs && int(blockIdx.x) >= args.job[k].block_begin) ? 1 : 0;   // independent kernarg loads
     const WgwJob& J = args.job[p];
     int local = blockIdx.x - J.block_begin;
     const int ks = local % args.ksplit; local /= args.ksplit;

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
         if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
     }
     int j = 0;
-    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;   // independent kernarg loads
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
     const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
@@ -324,8 +325,9 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     __shared__ __attribute__((aligned(16))) float sA[34 * kR1Ld];
     __shared__ __attribute__((aligned(16))) float sB[2][32 * kR1Ld];
     const int bid = blockIdx.x;
-    int j = 0;
-    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+    int j = 0;                                             // independent kernarg loads (a while loop chains up to five of them)
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
     const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino2(ConvArgs args) {
         if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
     }
     int j = 0;
-    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;   // independent kernarg loads
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
     const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
         if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
     }
     int j = 0;
-    while (j + 1 < args.njobs && bid >= args.job[j + 1].block_begin) ++j;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;   // independent kernarg loads
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
     const int n32 = local % J.n_tiles_n; local /= J.n_tiles_n;
