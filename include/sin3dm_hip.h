@@ -138,6 +138,15 @@ S3D_API int s3d_op_triplane_norm_silu(const float* const in[3], float* const out
  * src/diffusion/unet_triplane.py:106-145, 494-499.  mode 0: avg-pool 2x2, 1: bilinear to (ho[i], wo[i]) */
 S3D_API int s3d_op_triplane_resample(const float* const in[3], float* const out[3], int B, int C, const int hi[3],
                              const int wi[3], const int ho[3], const int wo[3], int mode, void* stream);
+/* timestep_embedding  src/diffusion/nn.py:103-121; t: device [B] float, out: device [B][dim] = cos | sin */
+S3D_API int s3d_op_timestep_embed(const float* t, int B, int dim, float* out, void* stream);
+/* TriplaneResBlock._forward  src/diffusion/unet_triplane.py:269-311 (constructor :175-267), run through the model's own
+ * block code.  emb: device [B][emb_dim] (the time_embed output); parameters by state-dict name relative to the block
+ * ("in_layers.0.norm_xy.weight", "in_layers.2.conv_xy.weight", "emb_layers.1.weight", "out_layers.0...",
+ * "out_layers.2...", "skip_connection.conv_xy.weight" when C != Cout), host pointers in PyTorch layouts */
+S3D_API int s3d_op_triplane_resblock(const float* const in[3], float* const out[3], const float* emb, int B, int C,
+                             int Cout, int H, int W, int D, int emb_dim, int use_scale_shift_norm, int is_rollout,
+                             const char* const* names, const float* const* tensors, int n_tensors, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Decoder: AutoEncoderGroupSkip.decode + ShapeAutoEncoder.decode_batch/decode_grid

@@ -74,6 +74,10 @@ SIGNATURES = {
     "s3d_op_triplane_resample": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int,
                                            C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                            C.POINTER(C.c_int), C.c_int, C.c_void_p]),
+    "s3d_op_timestep_embed": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "s3d_op_triplane_resblock": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     "s3d_decoder_create": (C.c_int, [C.POINTER(DecoderCfg), C.POINTER(C.c_void_p)]),
     "s3d_decoder_destroy": (None, [C.c_void_p]),
     "s3d_decoder_num_params": (C.c_int, [C.c_void_p]),

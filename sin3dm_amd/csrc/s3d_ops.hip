@@ -1,6 +1,6 @@
 // s3d_ops.hip — leaf-operator entry points (NCHW in / NCHW out) so tests can pin each kernel against the
 // reference op it replaces.  They allocate, run and synchronise: test plumbing, not the hot path.
-#include "s3d_common.h"
+#include "s3d_model.h"
 
 using namespace s3d;
 
@@ -153,6 +153,87 @@ int s3d_op_triplane_resample(const float* const in[3], float* const out[3], int 
         for (int p = 0; p < 3; ++p)
             S3D_TRY(launch_bilinear(x.p[p], B, C, gi.h[p], gi.w[p], y.p[p], go.h[p], go.w[p], C, 0, st));
     S3D_TRY(tri_to_nchw(y, B, out, st));
+    S3D_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// timestep_embedding (src/diffusion/nn.py:103-121) alone: the embedding stage of k_linear against an identity weight
+// (one non-zero product per output, the rest exact zeros).
+int s3d_op_timestep_embed(const float* t, int B, int dim, float* out, void* stream) {
+    S3D_CHECK(t && out && B >= 1 && dim >= 1, S3D_ERR_INVALID, "op_timestep_embed: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Scratch sc;
+    std::vector<float> eye(size_t(dim) * dim, 0.f);
+    for (int i = 0; i < dim; ++i) eye[size_t(i) * dim + i] = 1.f;
+    float* w = nullptr;
+    S3D_TRY(sc.alloc(&w, eye.size()));
+    S3D_HIP(hipMemcpyAsync(w, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    S3D_TRY(launch_linear(t, B, dim, w, nullptr, dim, out, 2, 0, st));
+    S3D_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
+// One TriplaneResBlock (src/diffusion/unet_triplane.py:175-311) through exactly the code path of the model's blocks
+// (Fwd::resblock): parameters by their state-dict names relative to the block, host pointers, PyTorch layouts.
+int s3d_op_triplane_resblock(const float* const in[3], float* const out[3], const float* emb, int B, int C, int Cout,
+                             int H, int W, int D, int emb_dim, int use_scale_shift_norm, int is_rollout,
+                             const char* const* names, const float* const* tensors, int n_tensors, void* stream) {
+    S3D_CHECK(in && out && emb && names && tensors, S3D_ERR_INVALID, "op_triplane_resblock: null argument");
+    S3D_CHECK(C % 32 == 0 && Cout % 32 == 0, S3D_ERR_INVALID, "op_triplane_resblock: GroupNorm32 needs channels %% 32 == 0");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::map<std::string, const float*> P;
+    for (int i = 0; i < n_tensors; ++i) P[names[i]] = tensors[i];
+    auto get = [&](const std::string& k) -> const float* { auto it = P.find(k); return it == P.end() ? nullptr : it->second; };
+    const bool ssn = use_scale_shift_norm != 0, roll = is_rollout != 0;
+    s3d_unet m;
+    memset(&m.cfg, 0, sizeof m.cfg);
+    m.cfg.use_scale_shift_norm = ssn; m.cfg.is_rollout = roll;
+    ResBlockW rb;
+    rb.C = C; rb.Cout = Cout; rb.has_skip = C != Cout; rb.film_off = 0;
+    const int eo = ssn ? 2 * Cout : Cout;
+    m.film_total = eo;
+    std::vector<float>& stg = m.stage;
+    const char* missing = nullptr;
+    auto need = [&](const std::string& k) -> const float* { const float* p = get(k); if (!p && !missing) missing = strdup(k.c_str()); return p; };
+    auto norm = [&](const std::string& pre, int c, NormW& nw) {
+        for (int p = 0; p < 3; ++p) {
+            const float* g = need(pre + ".norm_" + kPlane[p] + ".weight"); const float* b = need(pre + ".norm_" + kPlane[p] + ".bias");
+            if (g && b) { nw.gamma[p] = push(stg, g, c); nw.beta[p] = push(stg, b, c); }
+        }
+    };
+    auto tconv = [&](const std::string& pre, int cin, int cout, int k, bool r, ConvW& cw) {
+        const float* Wp[3]; const float* bp[3];
+        bool ok = true;
+        for (int p = 0; p < 3; ++p) {
+            Wp[p] = need(pre + ".conv_" + kPlane[p] + ".weight"); bp[p] = need(pre + ".conv_" + kPlane[p] + ".bias");
+            ok = ok && Wp[p] && bp[p];
+        }
+        if (ok) pack_tconv_raw(stg, Wp, bp, cin, cout, k, r, cw);
+    };
+    norm("in_layers.0", C, rb.n1);
+    tconv("in_layers.2", C, Cout, 3, roll, rb.c1);
+    norm("out_layers.0", Cout, rb.n2);
+    tconv("out_layers.2", Cout, Cout, 3, roll, rb.c2);
+    if (rb.has_skip) tconv("skip_connection", C, Cout, 1, false, rb.skip);
+    const float* ew = need("emb_layers.1.weight"); const float* eb = need("emb_layers.1.bias");
+    if (missing) { set_error("op_triplane_resblock: parameter '%s' missing", missing); free(const_cast<char*>(missing)); return S3D_ERR_MISSING; }
+    const size_t film_w = push(stg, ew, size_t(eo) * emb_dim), film_b = push(stg, eb, eo);
+    S3D_TRY(upload(m.wbuf, stg.data(), stg.size() * sizeof(float)));
+    Scratch sc;
+    const Geo g = Geo::from_hwd(H, W, D);
+    Tri x, o;
+    S3D_TRY(tri_from_nchw(sc, in, B, C, g, x, st));
+    float* film = nullptr;
+    S3D_TRY(sc.alloc(&film, size_t(B) * eo));
+    S3D_TRY(launch_linear(emb, B, emb_dim, m.dev(film_w), m.dev(film_b), eo, film, 1, 0, st));     // emb_layers = SiLU -> Linear
+    Fwd f{&m, B, st, film};
+    m.arena.measuring = true; m.arena.high = 0; m.arena.reset();
+    S3D_TRY(f.resblock(rb, x, o, false));
+    m.arena.measuring = false;
+    S3D_TRY(m.arena.buf.reserve(m.arena.high));
+    m.arena.reset();
+    S3D_TRY(f.resblock(rb, x, o, false));
+    S3D_TRY(tri_to_nchw(o, B, out, st));
     S3D_HIP(hipStreamSynchronize(st));
     return 0;
 }

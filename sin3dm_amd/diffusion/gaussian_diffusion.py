@@ -133,6 +133,11 @@ class GaussianDiffusion:
             return t.float() * (1000.0 / self.num_timesteps)
         return t
 
+    def _model_timesteps(self, t):
+        """The timestep values the denoiser is conditioned on for diffusion indices `t` (SpacedDiffusion maps them back
+        to original indices, respace.py:123-128)."""
+        return self._scale_timesteps(t)
+
     def _noise(self, x):
         return th.randn_like(x) if self.noise_fn is None else self.noise_fn(x)
 
@@ -184,7 +189,8 @@ class GaussianDiffusion:
                              mask=mask.data_ptr() if mask is not None else None,
                              sample=sample.data_ptr() if sample is not None else None, pred_xstart=pred.data_ptr(),
                              mean=mean.data_ptr() if mean is not None else None)
-        _lib.check(_lib.load().s3d_sampler_step(a, _lib.stream_ptr()))
+        with th.cuda.device(x.device):
+            _lib.check(_lib.load().s3d_sampler_step(a, _lib.stream_ptr()))
         return sample, pred, mean
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
@@ -328,7 +334,7 @@ class GaussianDiffusion:
             noise = th.randn_like(x_start)
         H, W, D = (int(model_kwargs[k]) for k in "HWD")
         x_t = self.q_sample_hip(x_start, t, noise)
-        out = model.forward_train(x_t, self._scale_timesteps(t), H, W, D)
+        out = model.forward_train(x_t, self._model_timesteps(t), H, W, D)
         target = self._training_target(x_start, x_t, t, noise).contiguous().float()
         mse = _mse_terms(out, target, H, W, D)
         wgt = (weights.to(out.device, th.float32) / out.shape[0])[:, None].expand(-1, 3).contiguous()

@@ -70,8 +70,23 @@ class SpacedDiffusion(GaussianDiffusion):
     def _step(self, mode, model, *args, **kwargs):
         return super()._step(mode, self._wrap_model(model), *args, **kwargs)
 
+    def training_losses(self, model, *args, **kwargs):
+        """Reference :93-96: training conditions the denoiser on ORIGINAL step indices too."""
+        return super().training_losses(self._wrap_model(model), *args, **kwargs)
+
     def _scale_timesteps(self, t):
         return t          # scaling happens inside the wrapped model
+
+    def _model_timesteps(self, t):
+        """What `_WrappedModel` feeds the denoiser, for the graph-free training path (training_losses_and_grads)."""
+        key = str(t.device)
+        if not hasattr(self, "_map_cache"):
+            self._map_cache = {}
+        m = self._map_cache.get(key)
+        if m is None:
+            m = self._map_cache[key] = th.tensor(self.timestep_map, device=t.device, dtype=th.float32)
+        ts = m[t]
+        return ts * (1000.0 / self.original_num_steps) if self.rescale_timesteps else ts
 
 
 class _WrappedModel:
@@ -86,6 +101,9 @@ class _WrappedModel:
 
     def parameters(self):
         return self.model.parameters()
+
+    def __getattr__(self, name):          # forward_train / backward_flat / flat_parameters of the wrapped denoiser
+        return getattr(self.__dict__["model"], name)
 
     def __call__(self, x, ts, **kwargs):
         # the map is kept in float32: the denoiser embeds float timesteps anyway (nn.py:113), so one gather replaces the

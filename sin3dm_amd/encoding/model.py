@@ -56,12 +56,11 @@ class FlatGroupAdamW:
 
 
 class ShapeAutoEncoder:
-    """Loads `ckpt_final.pth` written by the reference and decodes triplanes on MI355X.
-    Training, encode and mesh/texture export (PyMCubes, xatlas, nvdiffrast) are out of scope."""
+    """Reads and writes `<log_dir>/ckpt_{name}.pth` exactly where the reference does (src/encoding/model.py:143, 161), so an
+    experiment directory trained by either side loads on the other; trains, encodes and decodes on the MI355X."""
 
     def __init__(self, log_dir, cfg, device=None):
         self.log_dir = log_dir
-        self.model_dir = os.path.join(log_dir, "model")
         self.device = device or torch.device(f"cuda:{getattr(cfg, 'gpu_id', 0)}")
         self.net = get_networks(cfg).to(self.device)
         self.aabb = self.net.aabb.clone()
@@ -79,8 +78,11 @@ class ShapeAutoEncoder:
         self.input_grid = None
 
     def load_ckpt(self, name=None):
-        """Reference :158-176 — dict {net, optimizer, scheduler, Ka, Kd, Ks, Ns, aabb, featmap_size}."""
-        path = name if name and os.path.isabs(str(name)) else os.path.join(self.model_dir, f"ckpt_{name}.pth")
+        """Reference :158-176 — `<log_dir>/ckpt_{name}.pth`, dict {net, optimizer, scheduler, Ka, Kd, Ks, Ns, aabb,
+        featmap_size}.  (Directories written by round 1 of this build kept it under `model/`: read as a fallback.)"""
+        path = name if name and os.path.isabs(str(name)) else os.path.join(self.log_dir, f"ckpt_{name}.pth")
+        if not os.path.exists(path) and os.path.exists(os.path.join(self.log_dir, "model", f"ckpt_{name}.pth")):
+            path = os.path.join(self.log_dir, "model", f"ckpt_{name}.pth")
         ckpt = torch.load(path, map_location="cpu", weights_only=False)
         self.net.load_state_dict(ckpt["net"])
         self.aabb = torch.as_tensor(ckpt["aabb"], dtype=torch.float32).to(self.device)
@@ -245,8 +247,8 @@ class ShapeAutoEncoder:
 
     def save_ckpt(self, name):
         """reference :141-156 (the optimizer entry holds this implementation's flat Adam state)."""
-        os.makedirs(self.model_dir, exist_ok=True)
+        os.makedirs(self.log_dir, exist_ok=True)
         sd = {k: v.detach().cpu().clone() for k, v in self.net.state_dict().items()}
         torch.save({"net": sd, "optimizer": self.optimizer.state_dict() if hasattr(self, "optimizer") else None, "scheduler": None,
                     **self.material, "aabb": self.aabb.tolist(), "featmap_size": self.featmap_size},
-                   os.path.join(self.model_dir, f"ckpt_{name}.pth"))
+                   os.path.join(self.log_dir, f"ckpt_{name}.pth"))

@@ -71,3 +71,27 @@ def triplane_downsample2x(fm):
 def triplane_resize(fm, sizes):
     """Bilinear align_corners=False to explicit sizes (TriplaneUpsample2x :106-124, skip resize :494-499)."""
     return _resample(fm, sizes, 1)
+
+
+def timestep_embedding(timesteps, dim):
+    """timestep_embedding (src/diffusion/nn.py:103-121): [B] -> [B, dim] = cos | sin."""
+    _lib.require_gpu(timesteps)
+    t = timesteps.to(th.float32).contiguous()
+    out = th.empty((t.shape[0], dim), device=t.device)
+    _lib.check(_lib.load().s3d_op_timestep_embed(_lib.ptr(t), t.shape[0], dim, _lib.ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def triplane_resblock(fm, emb, params, cout, use_scale_shift_norm=True, is_rollout=True):
+    """TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311); `params`: {state-dict name relative to the
+    block: tensor}; emb: [B, emb_dim] time embedding."""
+    fm, B, Cc, H, W, D = _prep(fm)
+    emb = emb.contiguous().float()
+    host = {k: v.detach().to("cpu", th.float32).contiguous() for k, v in params.items()}
+    names = (C.c_char_p * len(host))(*[k.encode() for k in host])
+    ptrs = (C.c_void_p * len(host))(*[C.c_void_p(v.data_ptr()) for v in host.values()])
+    outs = [th.empty((B, cout) + tuple(f.shape[-2:]), device=f.device) for f in fm]
+    _lib.check(_lib.load().s3d_op_triplane_resblock(_lib.ptr3(fm), _lib.ptr3(outs), _lib.ptr(emb), B, Cc, cout, H, W, D,
+                                                    emb.shape[1], int(bool(use_scale_shift_norm)), int(bool(is_rollout)),
+                                                    names, ptrs, len(host), _lib.stream_ptr()))
+    return outs

@@ -4,7 +4,7 @@
     python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.sample --tag EXP --n_samples 64 ...
 
 Reads EXP/encoding/{args.json,feat.npz}, EXP/diffusion/{args.json,ema_<rate>_<iters>.pt} and the AE checkpoint
-EXP/encoding/model/ckpt_final.pth written by the reference's train.py; writes EXP/<output>/NNN/feat.npz (and
+EXP/encoding/ckpt_final.pth written by the reference's train.py; writes EXP/<output>/NNN/feat.npz (and
 r<reso>_voxel.npz with --vox).  Multi-GPU: sample indices are striped over the ranks (sin3dm_amd/parallel.py).
 Without --vox the decode stage extracts the iso-surface on the device (marching cubes) and writes a vertex-coloured
 object.obj; the reference's UV atlas / baked texture (xatlas, nvdiffrast) is out of scope.

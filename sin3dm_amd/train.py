@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.train --tag EXP --data_path ... --diff_batch_size 4
 
 Stage 1 (src/train.py:8-29): ShapeAutoEncoder.train on the preprocessed shape, then EXP/encoding/{args.json, feat.npz,
-model/ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it, the others wait.
+ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it, the others wait.
 Stage 2 (:32-75): the triplane diffusion UNet (sin3dm_amd/diffusion/train_util.py) -> EXP/diffusion/{args.json,
 ema_<rate>_<step>.pt, opt<step>.pt, progress.jsonl} — the files sample.py of either implementation reads.
 Multi-GPU: --diff_batch_size is PER GPU (the reference's 32 = 8 x 4); gradients are averaged with one all-reduce per
@@ -64,10 +64,11 @@ def train_diffusion(args, rank=0):
 
 def main(argv=None, confirm=input):
     rank, local, world = parallel.env_rank_world()
-    args = train_args(argv, confirm=confirm if rank == 0 else (lambda _: "y"))
+    args = train_args(argv, confirm=confirm, write=rank == 0)        # rank 0 alone creates directories / symlink / args.json
     seed_all(0 + rank)                               # per-rank timestep / noise streams; weights are broadcast from rank 0
     dist_util.setup_dist(local if world > 1 else args.gpu_id)
     parallel.init(device=dist_util.dev())
+    parallel.barrier()                               # the experiment directory exists before anyone reads it
     if args.enc_log is None:
         if rank == 0:
             train_ae(args)

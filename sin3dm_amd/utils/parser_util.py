@@ -150,28 +150,32 @@ def sample_args(argv=None):
     return args
 
 
-def train_args(argv=None, confirm=input):
-    """Training CLI; persists the `encoding` and `diffusion` groups as args.json (reference :102-145)."""
+def train_args(argv=None, confirm=input, write=True):
+    """Training CLI; persists the `encoding` and `diffusion` groups as args.json (reference :102-145).
+    `write=False` (ranks > 0 of a multi-process launch) only parses: the directory, symlink and args.json side effects
+    belong to one process."""
     parser = argparse.ArgumentParser()
     add_base_options(parser)
     add_encoding_training_options(parser)
     add_diffusion_training_options(parser)
     args = parser.parse_args(argv)
-    if os.path.exists(args.tag) and confirm(f'Folder "{args.tag}" already exists, continue? (y/n) ') != "y":
-        raise SystemExit(0)
-    os.makedirs(args.tag, exist_ok=True)
+    if write:
+        if os.path.exists(args.tag) and confirm(f'Folder "{args.tag}" already exists, continue? (y/n) ') != "y":
+            raise SystemExit(0)
+        os.makedirs(args.tag, exist_ok=True)
     enc_dir, diff_dir = encoding_log_dir(args.tag), diffusion_log_dir(args.tag)
     if args.enc_log is not None:
         load_and_overwrite_args(args, os.path.join(args.enc_log, "args.json"))
-        if not os.path.exists(enc_dir):
+        if write and not os.path.lexists(enc_dir):
             os.symlink(os.path.abspath(args.enc_log), enc_dir)
-    else:
+    elif write:
         os.makedirs(enc_dir, exist_ok=True)
         with open(os.path.join(enc_dir, "args.json"), "w") as f:
             json.dump(get_args_by_group(parser, args, "encoding"), f, indent=4)
     n = args.fdim_geo if args.data_type == "sdf" else args.fdim_geo + args.fdim_tex
     args.in_channels = args.out_channels = n
-    os.makedirs(diff_dir, exist_ok=True)
-    with open(os.path.join(diff_dir, "args.json"), "w") as f:
-        json.dump(get_args_by_group(parser, args, "diffusion"), f, indent=4)
+    if write:
+        os.makedirs(diff_dir, exist_ok=True)
+        with open(os.path.join(diff_dir, "args.json"), "w") as f:
+            json.dump(get_args_by_group(parser, args, "diffusion"), f, indent=4)
     return args

@@ -494,10 +494,98 @@ def gen_ae_train():
     torch.set_grad_enabled(False)
 
 
+def gen_respaced_train():
+    """SpacedDiffusion.training_losses (respace.py:93-96) with timestep_respacing="50" and rescale_timesteps=True: the
+    denoiser must be conditioned on timestep_map[t] * 1000 / original_num_steps during TRAINING too."""
+    from diffusion.script_util import create_gaussian_diffusion
+    torch.set_grad_enabled(True)
+    out = {}
+    tag, mc, (B, H, W, D) = "mc32_a", 32, (2, 10, 14, 6)
+    for dtag, resp, rescale, steps in (("r50_rescale", "50", True, 1000), ("s200_rescale", "", True, 200), ("r50", "50", False, 1000)):
+        diffusion = create_gaussian_diffusion(steps=steps, noise_schedule="linear", predict_xstart=True,
+                                              timestep_respacing=resp, rescale_timesteps=rescale)
+        model = make_unet(mc)
+        model.train()
+        x0 = rnd((B, 12, H + D, W + D), 400).clamp(-1, 1)
+        noise = rnd((B, 12, H + D, W + D), 401)
+        t = torch.tensor([diffusion.num_timesteps - 3, 1], dtype=torch.int64)
+        terms = diffusion.training_losses(model, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+        model.zero_grad()
+        (terms["loss"] * torch.ones(B)).mean().backward()
+        out[f"{dtag}.t"] = t
+        out[f"{dtag}.cfg"] = np.asarray([steps, int(rescale), diffusion.num_timesteps])
+        for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+            out[f"{dtag}.{k}"] = terms[k].detach()
+        grad_digest({k: p.grad for k, p in model.named_parameters()}, f"{dtag}.grad", out, full_max=0)
+    out["hwd"] = np.asarray([H, W, D])
+    save("train_respaced", **out)
+    torch.set_grad_enabled(False)
+
+
+def gen_formats():
+    """On-disk formats WRITTEN BY THE REFERENCE'S OWN CODE, kept as files under tests/golden/formats/:
+      feat.npz                 utils.triplane_util.save_triplane_data             (triplane_util.py:38-41)
+      encoding_args.json,      utils.parser_util.train_args() on the reference's parser: get_args_by_group dumps
+      diffusion_args.json      (parser_util.py:102-145; argv below)
+      ema_0.9999_000003.pt     a TriplaneUNetModelSmall.state_dict() saved as TrainLoop.save does (train_util.py:258-270:
+                               `th.save(state_dict, path)` of name -> tensor)
+      loaded.npz               what the reference's own readers return for those files (load_triplane_data composed map;
+                               sample_args() namespace after load_and_overwrite_args)."""
+    import json
+    import shutil
+    import tempfile
+    from utils import parser_util as rpu, triplane_util as rtu
+    dst = os.path.join(HERE, "formats")
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    tmp = tempfile.mkdtemp()
+    tag = os.path.join(tmp, "exp")
+    argv = ["train.py", "--tag", tag, "--data_path", "data/towerruins.npz", "--fm_reso", "64", "--model_channels", "32", "--channel_mult", "1",
+            "--enc_net_type", "skip", "--diff_n_iters", "3", "--ema_rate", "0.9999", "--use_scale_shift_norm", "True",
+            "--enc_lr_split", "0.2", "--timestep_respacing", "100"]
+    old = sys.argv
+    sys.argv = argv
+    try:
+        args = quiet(rpu.train_args)
+    finally:
+        sys.argv = old
+    H, W, D = 6, 8, 5
+    fm = [np.tanh(T.synthetic_noise(s, 970 + i)) for i, s in enumerate(((12, H, W), (12, H, D), (12, W, D)))]
+    rtu.save_triplane_data(rpu.encoding_feat_path(tag), *fm)
+    model = make_unet(32, channel_mult="1")                 # one level: keeps the committed checkpoint at ~1.4 MB
+    torch.save(model.state_dict(), rpu.diffusion_model_path(tag, args.ema_rate, 3))
+    shutil.copy(rpu.encoding_feat_path(tag), os.path.join(dst, "feat.npz"))
+    shutil.copy(os.path.join(rpu.encoding_log_dir(tag), "args.json"), os.path.join(dst, "encoding_args.json"))
+    shutil.copy(os.path.join(rpu.diffusion_log_dir(tag), "args.json"), os.path.join(dst, "diffusion_args.json"))
+    shutil.copy(rpu.diffusion_model_path(tag, args.ema_rate, 3), os.path.join(dst, "ema_0.9999_000003.pt"))
+    # the reference's readers on its own files
+    comp, sizes = rtu.load_triplane_data(rpu.encoding_feat_path(tag), device="cpu")
+    sys.argv = ["sample.py", "--tag", tag, "--n_samples", "2", "--timestep_respacing", "10", "--resize", "1", "1.5", "1"]
+    try:
+        sargs = quiet(rpu.sample_args)
+    finally:
+        sys.argv = old
+    ns = {k: v for k, v in vars(sargs).items() if k != "tag"}
+    with open(os.path.join(dst, "sample_args_namespace.json"), "w") as f:
+        json.dump(ns, f, indent=1, sort_keys=True)
+    tns = {k: v for k, v in vars(args).items() if k != "tag"}
+    with open(os.path.join(dst, "train_args_namespace.json"), "w") as f:
+        json.dump(tns, f, indent=1, sort_keys=True)
+    x = rnd((1, 12, H + D, W + D), 971)
+    y = model(x, torch.tensor([321]), H=H, W=W, D=D)
+    save("formats/loaded", composed=comp, sizes=np.asarray(sizes), x=x, y=y,
+         model_path=np.asarray(os.path.relpath(rpu.diffusion_model_path(tag, args.ema_rate, 3), tag)),
+         feat_path=np.asarray(os.path.relpath(rpu.encoding_feat_path(tag), tag)))
+    shutil.rmtree(tmp)
+    for f in sorted(os.listdir(dst)):
+        print(f"formats/{f}: {os.path.getsize(os.path.join(dst, f)) / 1024:.1f} KiB")
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
-                     ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train), ("ae_train", gen_ae_train)):
+                     ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train), ("ae_train", gen_ae_train), ("respaced", gen_respaced_train),
+                     ("formats", gen_formats)):
         if not only or name in only:
             fn()

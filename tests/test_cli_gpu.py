@@ -20,13 +20,12 @@ def make_experiment(root, hwd=(46, 64, 46), mc=64):
     np.savez_compressed(pu.encoding_feat_path(tag), feat_xy=np.tanh(T.synthetic_noise((12, H, W), 1)),
                         feat_xz=np.tanh(T.synthetic_noise((12, H, D), 2)), feat_yz=np.tanh(T.synthetic_noise((12, W, D), 3)))
     torch.save(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0), pu.diffusion_model_path(tag, 0.9999, 25000))
-    os.makedirs(os.path.join(pu.encoding_log_dir(tag), "model"), exist_ok=True)
     net = T.synthetic_state_dict(T.ae_param_shapes(), 5)
     net["geo_encoder.weight"] = torch.zeros(4, 1, 4, 4, 4); net["geo_encoder.bias"] = torch.zeros(4)
     net["tex_encoder.weight"] = torch.zeros(8, 4, 4, 4, 4); net["tex_encoder.bias"] = torch.zeros(8)
     net["aabb"] = torch.tensor([-0.72, -1.0, -0.72, 0.72, 1.0, 0.72])
     torch.save({"net": net, "aabb": net["aabb"].numpy(), "featmap_size": hwd, "Ka": None, "Kd": None, "Ks": None, "Ns": None},
-               os.path.join(pu.encoding_log_dir(tag), "model", "ckpt_final.pth"))
+               os.path.join(pu.encoding_log_dir(tag), "ckpt_final.pth"))       # the reference's layout (src/encoding/model.py:143)
     return tag
 
 
@@ -88,7 +87,7 @@ def test_train_cli_then_sample(tmp_path):
 
 def test_train_cli_autoencoder_stage(tmp_path):
     """train.py --only_enc on a synthetic preprocessed shape: writes the encoding/ folder sample.py and the diffusion
-    stage read (args.json, feat.npz, model/ckpt_final.pth)."""
+    stage read (args.json, feat.npz, ckpt_final.pth)."""
     from sin3dm_amd import train
     from sin3dm_amd.utils import parser_util as pu
     R = (16, 24, 12)
@@ -105,11 +104,11 @@ def test_train_cli_autoencoder_stage(tmp_path):
     train.main(["--tag", tag, "--data_path", data, "--only_enc", "--fm_reso", "24", "--enc_n_iters", "30", "--enc_batch_size", "1024"],
                confirm=lambda _: "y")
     enc = pu.encoding_log_dir(tag)
-    assert os.path.exists(os.path.join(enc, "args.json")) and os.path.exists(os.path.join(enc, "model", "ckpt_final.pth"))
+    assert os.path.exists(os.path.join(enc, "args.json")) and os.path.exists(os.path.join(enc, "ckpt_final.pth"))
     d = np.load(pu.encoding_feat_path(tag))
     assert d["feat_xy"].shape == (12, 16, 24) and d["feat_xz"].shape == (12, 16, 12) and d["feat_yz"].shape == (12, 24, 12)
     assert all(np.isfinite(d[k]).all() and np.abs(d[k]).max() <= 1.0 for k in d.files)          # tanh range
-    ck = torch.load(os.path.join(enc, "model", "ckpt_final.pth"), weights_only=False)
+    ck = torch.load(os.path.join(enc, "ckpt_final.pth"), weights_only=False)
     assert ck["featmap_size"] == [16, 24, 12] and set(ck["net"]) >= {"geo_encoder.weight", "tex_decoder.second_layers.4.bias", "aabb"}
 
 
@@ -153,3 +152,28 @@ def test_full_pipeline_train_then_sample(tmp_path):
         d = np.load(p)
         assert d["feat_xy"].shape == (12, 16, 24) and all(np.isfinite(d[k]).all() for k in d.files)
         assert os.path.exists(os.path.join(os.path.dirname(p), "object.obj"))
+
+
+def test_reference_written_experiment_directory(tmp_path):
+    """An experiment directory made only of files the REFERENCE wrote (tests/golden/formats/: grouped args.json,
+    feat.npz, ema_*.pt): sample_args -> create_model_and_diffusion_from_args -> load_state_dict -> forward equals the
+    reference's forward with that checkpoint; then the sampling CLI runs on it (diffusion half; --input skips nothing)."""
+    from test_formats import FMT, reference_experiment
+    from sin3dm_amd.diffusion.script_util import create_model_and_diffusion_from_args
+    from sin3dm_amd.utils import parser_util as pu
+    from sin3dm_amd.utils.triplane_util import load_triplane_data
+    from conftest import relerr
+    tag = reference_experiment(str(tmp_path))
+    args = pu.sample_args(["--tag", tag, "--use_ddim", "True", "--timestep_respacing", "5"])
+    model, diffusion = create_model_and_diffusion_from_args(args)
+    model.load_state_dict(torch.load(pu.diffusion_model_path(tag, args.ema_rate, args.diff_n_iters), map_location="cpu"))
+    model.to("cuda:0").eval()
+    ref = np.load(os.path.join(FMT, "loaded.npz"))
+    comp, (H, W, D) = load_triplane_data(pu.encoding_feat_path(tag), device="cuda:0")
+    assert np.array_equal(comp.cpu().numpy(), ref["composed"])
+    with torch.no_grad():
+        y = model(torch.from_numpy(ref["x"]).cuda(), torch.tensor([321.0], device="cuda"), H=H, W=W, D=D)
+    assert relerr(y.cpu().numpy(), ref["y"]) < 1e-4
+    assert diffusion.num_timesteps == 5
+    s = diffusion.ddim_sample_loop(model, (2, 12, H + D, W + D), model_kwargs=dict(H=H, W=W, D=D))
+    assert torch.isfinite(s).all() and float(s[..., H:, W:].abs().max()) == 0.0

@@ -291,3 +291,195 @@ def test_full_size_trajectory_vs_cpu_port(oracle):
             x_cpu, _ = tp.p_sample_update(out, x_cpu, eps, tab, t)
         worst = max(worst, relerr(x_gpu.cpu().numpy(), x_cpu.numpy()))
     assert worst < 1e-4, worst
+
+
+# ------------------------------------------------------------------ a5 / a7 leaves directly from the committed goldens
+@pytest.mark.parametrize("tag,C,Cout,ssn", [("same", 32, 32, True), ("skip", 32, 64, True), ("add", 32, 32, False)])
+def test_leaf_resblock_golden(tag, C, Cout, ssn):
+    """TriplaneResBlock._forward (unet_triplane.py:269-311) alone: FiLM on/off, identity / 1x1 skip."""
+    from sin3dm_amd import ops
+    g = golden("resblock")
+    full = T.unet_param_shapes(model_channels=32, use_scale_shift_norm=ssn)
+    pre = "input_blocks.0.0." if C == Cout else "input_blocks.1.1."
+    shapes = {k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}
+    params = {k: torch.from_numpy(T.synthetic_tensor(k, v, 3)) for k, v in shapes.items()}
+    fm = [cu(g[f"{tag}.in_{p}"]) for p in T.PLANES]
+    out = ops.triplane_resblock(fm, cu(g[f"{tag}.emb"]), params, Cout, use_scale_shift_norm=ssn)
+    for p, y in zip(T.PLANES, out):
+        assert relerr(y.cpu().numpy(), g[f"{tag}.out_{p}"]) < TOL_OP, (tag, p)
+
+
+def test_leaf_timestep_embedding_golden():
+    """timestep_embedding (nn.py:103-121): cos | sin of t * exp(-ln(1e4) i / half).  Arguments reach 999 rad, where one
+    fp32 ulp of the argument is 6e-5: absolute tolerance, as in the CPU oracle's test of the same fixture."""
+    from sin3dm_amd import ops
+    g = golden("temb")
+    for mc in (32, 64):
+        e = ops.timestep_embedding(cu(g["t"].astype(np.float32)), mc).cpu().numpy()
+        assert e.shape == g[f"emb{mc}"].shape
+        np.testing.assert_allclose(e, g[f"emb{mc}"], atol=2e-4, rtol=0)
+        small = g["t"] <= 1                                           # t in {0, 1}: no argument-rounding excuse
+        np.testing.assert_allclose(e[small], g[f"emb{mc}"][small], atol=2e-6, rtol=0)
+
+
+def test_ddim_inpainting_branch(oracle):
+    """ddim_sample's y0 / mask branch (gaussian_diffusion.py:568-577): pred_xstart is replaced by
+    mask * y0 + (1 - mask) * pred_xstart — at every step when is_mask_t0, otherwise only while t != 0."""
+    H, W, D = 10, 14, 6
+    kw = dict(H=H, W=W, D=D)
+    model = make_model(32)
+    diff = make_diffusion("10")
+    shape = (2, 12, H + D, W + D)
+    x, eps = T.synthetic_noise(shape, 21), T.synthetic_noise(shape, 22)
+    y0 = np.tanh(T.synthetic_noise(shape, 23))
+    mask = (T.synthetic_noise(shape, 24) > 0).astype(np.float32)
+    tab, tmap = oracle.schedule_tables(sorted(diff.use_timesteps))
+    sd = oracle.Params(T.synthetic_state_dict(T.unet_param_shapes(model_channels=32), 0, as_torch=False))
+    diff.noise_fn = lambda z: cu(eps)
+    for ti in (7, 0):
+        mo = oracle.unet_forward(sd, x, [tmap[ti]] * 2, H, W, D, 32)
+        plain = np.clip(mo, -1, 1)
+        mixed = mask * y0 + (1 - mask) * plain
+        t = torch.full((2,), ti, device=dev(), dtype=torch.int64)
+        for is_t0 in (False, True):
+            for eta in (0.0, 0.6):
+                with torch.no_grad():
+                    o = diff.ddim_sample(model, cu(x), t, model_kwargs=kw, eta=eta, y0=cu(y0), mask=cu(mask), is_mask_t0=is_t0)
+                x0 = mixed if (is_t0 or ti != 0) else plain
+                # the update of ddim_update() with its x0 replaced: eps is re-derived from the mixed x0 (:579)
+                sr, srm1, ab, abp = (float(tab[k][ti]) for k in ("sqrt_recip", "sqrt_recipm1", "acp", "acp_prev"))
+                e = (np.float32(sr) * x - x0) / np.float32(srm1)
+                sigma = eta * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
+                want = x0 * np.float32(np.sqrt(abp)) + np.float32(np.sqrt(1 - abp - sigma ** 2)) * e + (ti != 0) * np.float32(sigma) * eps
+                assert relerr(o["pred_xstart"].cpu().numpy(), x0) < TOL_FWD, (ti, is_t0, eta)
+                assert relerr(o["sample"].cpu().numpy(), want) < TOL_FWD, (ti, is_t0, eta)
+    # and without y0/mask the branch is inert
+    with torch.no_grad():
+        a = diff.ddim_sample(model, cu(x), t, model_kwargs=kw)
+        b = diff.ddim_sample(model, cu(x), t, model_kwargs=kw, y0=None, mask=None, is_mask_t0=True)
+    assert torch.equal(a["sample"], b["sample"])
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 and 5 at their full sizes
+def tp_ddim(model_out, x, tab, t):
+    """eta = 0 DDIM update on torch tensors (gaussian_diffusion.py:538-600), fp32 like the reference."""
+    x0 = model_out.clamp(-1, 1)
+    f = lambda k: torch.tensor(float(tab[k][t]), dtype=torch.float32)
+    eps = (f("sqrt_recip") * x - x0) / f("sqrt_recipm1")
+    abp = f("acp_prev")
+    return x0 * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps, x0
+
+
+def test_config3_batch8_ddim100(oracle):
+    """BASELINE configs[2]: 128-ch UNet, (128,128,128), DDIM-100, 8 samples per GPU (src/sample.py:33-38 batches
+    bs <= diff_batch_size).  (i) every element of the batch-8 forward is bit-identical to the same sample run alone;
+    (ii) three DDIM-100 steps of the whole batch, element 0 checked against the CPU port of the reference on the same
+    noise-free chain (eta = 0), elements 0 and 5 against their batch-1 runs bit for bit."""
+    sys_path_oracle()
+    mc, hwd, B = 128, (128, 128, 128), 8
+    H, W, D = hwd
+    kw = dict(H=H, W=W, D=D)
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0)
+    model = make_model(mc)
+    diff = make_diffusion("100")
+    assert diff.num_timesteps == 100
+    tab, tmap = oracle.schedule_tables(sorted(diff.use_timesteps))
+    x = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 31))
+    with torch.no_grad():
+        xb = x.to(dev())
+        x0, x5 = x[0:1].to(dev()), x[5:6].to(dev())
+        x_cpu = x[0:1].clone()
+        worst = 0.0
+        for k in range(3):
+            ti = 99 - k
+            t8 = torch.full((B,), ti, device=dev(), dtype=torch.int64)
+            xb = diff.ddim_sample(model, xb, t8, model_kwargs=kw)["sample"]
+            x0 = diff.ddim_sample(model, x0, t8[:1], model_kwargs=kw)["sample"]
+            x5 = diff.ddim_sample(model, x5, t8[:1], model_kwargs=kw)["sample"]
+            assert torch.equal(xb[0:1], x0) and torch.equal(xb[5:6], x5), f"step {k}: batch elements must not interact"
+            import torch_port as tp
+            out = tp.unet_forward(sd, x_cpu, torch.tensor([float(tmap[ti])]), H, W, D, mc)
+            x_cpu, _ = tp_ddim(out, x_cpu, tab, ti)
+            worst = max(worst, relerr(x0.cpu().numpy(), x_cpu.numpy()))
+    assert worst < TOL_FWD, worst
+    assert torch.isfinite(xb).all()
+
+
+def sys_path_oracle():
+    import os, sys
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def test_config5_retargeted_256x256x128(oracle):
+    """BASELINE configs[4], diffusion half: --resize 2 2 1 from a 128^3 encoding -> (H,W,D) = (256,256,128), composed
+    map [12, 384, 384] (src/sample.py:26-38), 128-ch UNet, DDPM-1000: three ancestral steps with identical noise on the
+    HIP path and on the CPU port of the reference; repeatable bits, finite, x0 prediction clamped."""
+    sys_path_oracle()
+    import torch_port as tp
+    mc, hwd = 128, (256, 256, 128)
+    H, W, D = hwd
+    kw = dict(H=H, W=W, D=D)
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0)
+    model = make_model(mc)
+    diff = make_diffusion("")
+    tab, _ = oracle.schedule_tables(None, 1000)
+    g = torch.Generator().manual_seed(5)
+    x_cpu = torch.randn((1, 12, H + D, W + D), generator=g)
+    x_gpu = x_cpu.to(dev())
+    worst = 0.0
+    for k in range(3):
+        t = 999 - k
+        eps = torch.randn(x_cpu.shape, generator=g)
+        diff.noise_fn = lambda z, e=eps: e.to(z.device)
+        with torch.no_grad():
+            tt = torch.tensor([t], device=dev())
+            o = diff.p_sample(model, x_gpu, tt, model_kwargs=kw)
+            if k == 0:
+                o2 = diff.p_sample(model, x_gpu, tt, model_kwargs=kw)
+                assert torch.equal(o["sample"], o2["sample"]), "bit-repeatable"
+            assert float(o["pred_xstart"].abs().max()) <= 1.0
+            x_gpu = o["sample"]
+            out = tp.unet_forward(sd, x_cpu, torch.tensor([float(t)]), H, W, D, mc)
+            x_cpu, _ = tp.p_sample_update(out, x_cpu, eps, tab, t)
+        worst = max(worst, relerr(x_gpu.cpu().numpy(), x_cpu.numpy()))
+    assert worst < TOL_FWD, worst
+    assert torch.isfinite(x_gpu).all()
+
+
+def test_config5_decode_grid_512x512x256(oracle):
+    """BASELINE configs[4], decode half: decode_grid at --reso 512 of a (256,256,128) triplane whose aabb is the 128^3
+    encoding's scaled by (2,2,1) (_resize_aabb, src/encoding/model.py:351-360) -> 512 x 512 x 256 cells
+    (decode_grid :335-349, grid points utils3d.py:13-25).  Shape, finiteness, colour range, and 4096 randomly indexed
+    cells against the C oracle's decode of the same cell centres."""
+    from types import SimpleNamespace
+    from sin3dm_amd.encoding.model import ShapeAutoEncoder
+    up, hid, (H, W, D), reso = 64, 256, (256, 256, 128), 512
+    cfg = SimpleNamespace(enc_net_type="skip", fdim_geo=4, fdim_tex=8, fdim_up=up, hidden_dim=hid, n_hidden_layers=4, data_type="sdftex")
+    ae = ShapeAutoEncoder("/nonexistent", cfg, device=dev())
+    sdt = T.synthetic_state_dict(T.ae_param_shapes(4, 8, up, hid, 4), 5)
+    missing, unexpected = ae.net.load_state_dict(sdt, strict=False)
+    assert not unexpected
+    ae.net.eval()
+    ae.aabb = torch.tensor([-0.5, -0.5, -0.5, 0.5, 0.5, 0.5], device=dev())
+    ae.featmap_size = (128, 128, 128)
+    aabb = ae._resize_aabb((H, W, D))
+    assert np.allclose(aabb.cpu().numpy(), [-1.0, -1.0, -0.5, 1.0, 1.0, 0.5])
+    fm = [0.8 * np.tanh(T.synthetic_noise(s, 60 + i)) for i, s in enumerate(((1, 12, H, W), (1, 12, H, D), (1, 12, W, D)))]
+    grid = ae.decode_grid([cu(f) for f in fm], reso, aabb=aabb)
+    assert tuple(grid.shape) == (512, 512, 256, 4)
+    assert torch.isfinite(grid).all()
+    assert float(grid[..., 1:].min()) >= 0.0 and float(grid[..., 1:].max()) <= 1.0
+    rng = np.random.Generator(np.random.PCG64(77))
+    idx = np.stack([rng.integers(0, n, 4096) for n in (512, 512, 256)], axis=1)
+    idx[:8] = [[0, 0, 0], [511, 511, 255], [0, 511, 0], [511, 0, 255], [0, 0, 255], [511, 511, 0], [255, 256, 127], [256, 255, 128]]
+    a = aabb.cpu().numpy().astype(np.float32)
+    size = a[3:] - a[:3]
+    res = np.array([512, 512, 256], np.float32)
+    pts = ((idx.astype(np.float32) + np.float32(0.5)) / res * size + a[:3]).astype(np.float32)
+    sd = oracle.Params(T.synthetic_state_dict(T.ae_param_shapes(4, 8, up, hid, 4), 5, as_torch=False))
+    want = oracle.ae_decode(sd, pts, *fm, a, 4, 8, up, hid, 4)
+    want[:, 1:] = np.clip(want[:, 1:], 0, 1)
+    got = grid[idx[:, 0], idx[:, 1], idx[:, 2]].cpu().numpy()
+    assert relerr(got, want) < TOL_FWD

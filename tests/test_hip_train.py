@@ -251,3 +251,72 @@ def test_full_size_directional_derivative():
     flat.copy_(base); m.mark_parameters_changed()
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gv) < 2e-2 * abs(gv), (fd, gv, L0, eps)
+
+
+@pytest.mark.parametrize("dtag", ["r50_rescale", "s200_rescale", "r50"])
+def test_respaced_training_conditions_on_original_timesteps(dtag):
+    """SpacedDiffusion.training_losses (reference respace.py:93-96): with --timestep_respacing and/or --rescale_timesteps
+    the denoiser is conditioned on timestep_map[t] (* 1000 / original steps) during TRAINING as well as sampling — loss
+    terms and every gradient against the reference's autograd, on both the autograd and the graph-free path."""
+    import torch
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    g = golden("train_respaced")
+    steps, rescale, n_t = (int(v) for v in g[f"{dtag}.cfg"])
+    resp = "50" if dtag.startswith("r50") else ""
+    diffusion = create_gaussian_diffusion(steps=steps, noise_schedule="linear", predict_xstart=True, timestep_respacing=resp,
+                                          rescale_timesteps=bool(rescale))
+    assert diffusion.num_timesteps == n_t
+    m = _model(32)
+    H, W, D = (int(v) for v in g["hwd"])
+    B = 2
+    dev = torch.device("cuda:0")
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1).to(dev)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 401)).to(dev)
+    t = torch.from_numpy(g[f"{dtag}.t"]).cuda()
+    kw = dict(H=H, W=W, D=D)
+    terms = diffusion.training_losses(m, x0, t, model_kwargs=kw, noise=noise)
+    for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+        assert relerr(terms[k].detach().cpu().numpy(), g[f"{dtag}.{k}"]) < 2e-5, k
+    (terms["loss"] * torch.ones(B, device="cuda")).mean().backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+    w = digest_errors(grads, g, f"{dtag}.grad")
+    assert w["norm"] < 2e-4 and w["proj"] < 2e-4 and w["head"] < 2e-3, w
+    terms2, flat = diffusion.training_losses_and_grads(m, x0, t, torch.ones(B, device="cuda"), kw, noise=noise)
+    assert torch.equal(terms2["loss"], terms["loss"].detach())
+    for name, view in m.split_flat(flat).items():
+        assert torch.equal(view, dict(m.named_parameters())[name].grad), name
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_adamw_ema_kernel_elementwise(wd):
+    """The fused AdamW + EMA kernel element by element against torch.optim.AdamW (what the reference constructs,
+    train_util.py:84) + update_ema (nn.py:55-65) in float64, on gradients bounded away from zero (|g| in [0.1, 2]) so that
+    Adam's g / (sqrt(v) + eps) is well conditioned: pins the bias-correction exponents, the decoupled weight decay, the
+    order lr / step and the EMA lerp, none of which the norm-level check of test_optimizer_steps can see."""
+    import ctypes as C
+    import torch
+    from sin3dm_amd import _lib
+    n, steps, lr, b1, b2, eps, rate = 4099, 4, 3e-3, 0.9, 0.999, 1e-8, 0.97
+    gen = np.random.Generator(np.random.PCG64(5))
+    p0 = gen.normal(0, 1, n).astype(np.float32)
+    grads = [(gen.uniform(0.1, 2.0, n) * gen.choice([-1.0, 1.0], n)).astype(np.float32) for _ in range(steps)]
+    ref = torch.nn.Parameter(torch.from_numpy(p0).double())
+    opt = torch.optim.AdamW([ref], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    ema_ref = torch.from_numpy(p0).double()
+    p = torch.from_numpy(p0).cuda()
+    m, v, ema = torch.zeros_like(p), torch.zeros_like(p), p.clone()
+    lib = _lib.load()
+    for s in range(steps):
+        lr_s = lr * (1 - s / 10)                                      # the linear anneal changes lr between steps
+        for gr in opt.param_groups:
+            gr["lr"] = lr_s
+        ref.grad = torch.from_numpy(grads[s]).double()
+        opt.step()
+        ema_ref.mul_(rate).add_(ref.detach(), alpha=1 - rate)
+        g = torch.from_numpy(grads[s]).cuda()
+        _lib.check(lib.s3d_train_adamw_ema(_lib.ptr(p), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v), (C.c_void_p * 1)(ema.data_ptr()),
+                                           (C.c_float * 1)(rate), 1, n, lr_s, b1, b2, eps, wd, s + 1, _lib.stream_ptr()))
+        dp = (p.double().cpu() - torch.from_numpy(p0).double()).numpy()
+        dref = (ref.detach() - torch.from_numpy(p0).double()).numpy()
+        assert np.max(np.abs(dp - dref)) < 2e-6 * np.max(np.abs(dref)) + 2e-7, (s, np.max(np.abs(dp - dref)))   # fp32 storage of p: ~1e-7 abs
+        assert np.max(np.abs(ema.double().cpu().numpy() - ema_ref.numpy())) < 5e-7, s
