@@ -9,10 +9,19 @@ A "step" is one ancestral denoising step of one sample per GPU: UNet forward + f
 the step's noise draw (device generator, as the reference does on a GPU).  value = samples/s over all ranks
 = N * K / 1000 / t, where t is the max over ranks of the barrier-bracketed wall time of exactly K steps.
 Prints ONE JSON line on rank 0.  Multi-GPU = independent samples per rank (no data-path collective).
+
+`--gpus N` with N > 1 and no torchrun environment: this process touches no GPU; it starts N fresh worker processes
+(one per GPU, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's line and exits
+non-zero if any worker fails.
+
+Before the W warm-up steps the script always runs PREWARM untimed steps of its own: a fresh box needs more than a
+handful of steps to reach steady clocks and warm caches (round 1: 1.145 ms/step after 5 warm-up steps, 1.08 after 100).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +31,9 @@ sys.path.insert(0, REPO)
 MC = 128
 HWD = (128, 128, 128)
 T_STEPS = 1000
+PREWARM = 60
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
+TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
 
 
 def f_dense_per_step(mc, H, W, D, mult=(1, 2)):
@@ -70,8 +81,8 @@ def usable_cores():
 
 
 def cpu_baseline(steps_budget_s=20.0):
-    """oracle/torch_port.py (the reference's algorithm on the reference's own CPU engine, oneDNN) timed on this
-    box's host cores for a bounded number of full-size steps; samples/s = 1 / (1000 * s_per_step)."""
+    """BASELINE.md §3 path (ii): oracle/torch_port.py (the reference's algorithm on the reference's own CPU engine,
+    oneDNN) timed on this box's host cores for a bounded number of full-size steps; samples/s = 1 / (1000 * s_per_step)."""
     import torch
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import torch_port as tp
@@ -98,6 +109,213 @@ def cpu_baseline(steps_budget_s=20.0):
                       f"{cores} threads), {s_per_step * 1e3:.0f} ms/step, extrapolated to 1000 steps"}
 
 
+def cpu_baseline_c_oracle(budget_s=25.0):
+    """BASELINE.md §3 path (i): the plain-C/OpenMP restatement (oracle/sin3dm_oracle.c, literal dense rollout concat,
+    no vendor library) on the same host cores.  One 128-ch step at (64,64,64) — a quarter of the full-size pixels — is
+    timed first; the full-size step only if it fits the budget, otherwise the figure is that step x 4 (the work is
+    proportional to the pixel count) and says so."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import numpy as np
+    import oracle as orc
+    from sin3dm_amd import testing as T
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    sd = orc.Params(T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0, as_torch=False))
+
+    def one(hwd):
+        H, W, D = hwd
+        x = T.synthetic_noise((1, 12, H + D, W + D), 1)
+        t0 = time.perf_counter()
+        orc.unet_forward(sd, x, np.array([500.0], np.float32), H, W, D, MC)
+        return time.perf_counter() - t0
+
+    q = one((64, 64, 64))
+    if 4 * q <= budget_s:
+        s, what = one(HWD), "1 full-size UNet step (128-ch, 128^3, B=1)"
+    else:
+        s, what = 4 * q, f"1 UNet step at (64,64,64) ({q:.1f} s) x 4 for the pixel count of 128^3"
+    return {"value": 1.0 / (T_STEPS * s), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{what} of oracle/sin3dm_oracle.c (plain C, OpenMP, {cores} threads), {s * 1e3:.0f} ms/step, "
+                      f"extrapolated to 1000 steps"}
+
+
+def s3d_switches():
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("S3D_")}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_workers(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: N fresh processes, one per GPU.  The parent never
+    initialises the GPU (no HIP call, no torch.cuda.*), never exec()s, and forwards rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    line = next((l for l in reversed((out0 or "").splitlines()) if l.startswith("{")), None)
+    bad = [i for i, rc in enumerate(rcs) if rc != 0]
+    if bad or line is None:
+        sys.stderr.write(f"bench.py: worker rank(s) {bad} failed (exit codes {rcs}); rank 0 stdout tail: {(out0 or '')[-400:]!r}\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ worker
+def worker(args):
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    H, W, D = HWD
+
+    if args.dry_run:
+        # plumbing check without a GPU (tests/test_bench_launch.py): same rendezvous / barrier / max-over-ranks / JSON
+        # path over gloo, the step replaced by a sleep.  Never a measurement: the line says so.
+        if world > 1:
+            dist.init_process_group("gloo")
+        if args.dry_run_fail_rank == rank:
+            raise SystemExit(3)
+        step = lambda: time.sleep(0.001)
+        sync = lambda: None
+        dev = torch.device("cpu")
+        prof = None
+    else:
+        from sin3dm_amd import _lib, testing as T
+        from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+        from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
+        _lib.require_gpu()
+        torch.cuda.set_device(local)
+        dev = torch.device(f"cuda:{local}")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
+        model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0))
+        model.to(dev).eval()
+        diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True)
+        kw = dict(H=H, W=W, D=D)
+        torch.manual_seed(1000 + rank)
+        state = {"x": torch.randn(1, 12, H + D, W + D, device=dev), "k": 0}
+        all_t = torch.arange(T_STEPS, device=dev, dtype=torch.int64)[:, None].contiguous()     # as GaussianDiffusion._loop does
+
+        def step():
+            i = (T_STEPS - 1 - state["k"]) % T_STEPS
+            state["x"] = diffusion.p_sample(model, state["x"], all_t[i], model_kwargs=kw)["sample"]
+            state["k"] += 1
+        sync = torch.cuda.synchronize
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(PREWARM + args.warmup):
+            step()
+        sync()
+        if not args.dry_run:
+            model.profile(args.profile_every)
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        barrier()
+        dt = time.perf_counter() - t0
+    if not args.dry_run:
+        prof = model.profile_read()
+        model.profile(0)
+        assert torch.isfinite(state["x"]).all()
+
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return 0
+
+    ms_step = dt / args.steps * 1e3
+    value = world * args.steps / T_STEPS / dt
+    fd = f_dense_per_step(MC, H, W, D)
+    switches = s3d_switches()
+    roof = None
+    if prof is not None and prof.launches[0] > 0:
+        sec = prof.ms[0] * 1e-3
+        avg_s = sec / prof.launches[0]
+        executed = prof.mfma_flops[0] / sec / 1e12                 # what the matrix cores multiply: the hardware rate
+        algorithmic = prof.flops[0] / sec / 1e12
+        traffic, traffic_src = None, None
+        if not switches:     # the committed PMC passes were taken with the default kernels
+            try:
+                traffic = json.load(open(os.path.join(REPO, TRAFFIC_PROFILE)))["dominant_traffic_bytes_per_launch"]
+                traffic_src = (f"from_committed_profile {TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command "
+                               "(separate passes, gfx950 2x read correction); not re-measured in this run")
+            except (OSError, KeyError, ValueError):
+                pass
+        roof = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_tflops": round(algorithmic, 2),
+                "hbm_gbs": round(traffic / avg_s / 1e9, 1) if traffic else None,
+                "hbm_frac_of_8TBs": round(traffic / avg_s / 8e12, 4) if traffic else None,
+                "kernel": "the dense 3x3 TriplaneConv kernel (own-channel part of the rollout convolution): "
+                          + {"0": "k_conv_mfma<3x3> direct", "2": "k_conv_wino2 Winograd F(2x2,3x3)", "6": "k_conv_wino6 Winograd F(4x4,3x3)"}.get(
+                              os.environ.get("S3D_WINO", ""), "default 3x3 kernel of sin3dm_amd/csrc/s3d_wino.hip"),
+                "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(prof.launches[0]),
+                "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
+                "mfma_flops_per_launch_avg": prof.mfma_flops[0] / prof.launches[0],
+                "conv3x3_ms_per_step": round(prof.ms[0] / max(prof.forwards, 1), 4),
+                "rank1_ms_per_step": round(prof.ms[2] / max(prof.forwards, 1), 4),
+                "conv1x1_ms_per_step": round(prof.ms[1] / max(prof.forwards, 1), 4),
+                "whole_step_mfma_frac": round((prof.mfma_flops[0] + prof.mfma_flops[1] + prof.mfma_flops[2]) / max(prof.forwards, 1)
+                                              / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                "note": "achieved/frac = flops the matrix cores execute for the launches (Winograd multiplies fewer than the "
+                        "direct count) / HIP-event time on the launch stream inside the timed region / 157.3 TF; "
+                        "algorithmic_tflops = 2*9*C*Cout per output pixel (own channels only: rank-1 rollout exploited) over the "
+                        "same time; the rate on the reference-executed F_dense is effective_dense_tflops"}
+    line = {"metric": "DDPM-1000 triplane samples/sec @128^2 latent", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)",
+            "config": {"workload": "BASELINE configs[1]: 128^2 triplane (H,W,D)=(128,128,128), 128-ch "
+                                   "TriplaneUNetModelSmall, DDPM-1000, batch 1 per GPU; a step = 1 denoising step",
+                       "steps_per_sample": T_STEPS, "batch_per_gpu": 1, "parallelism": f"{world} independent samples",
+                       "prewarm_steps": PREWARM},
+            "f_dense_gflop_per_step": round(fd / 1e9, 2),
+            "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
+            "roofline": roof, "s3d_switches": switches}
+    if args.dry_run:
+        line["data"] = "DRY RUN (no GPU work: launcher / rendezvous plumbing check only)"
+        line["value"] = 0.0
+    elif not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+        line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        try:
+            line["cpu_baseline_c_openmp"] = cpu_baseline_c_oracle()
+        except Exception as e:                                         # the C oracle is a checker; never fail the line for it
+            line["cpu_baseline_c_openmp"] = {"error": repr(e)}
+    print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,115 +323,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8, help="instrument every n-th step with HIP events (0=off)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from sin3dm_amd import _lib, testing as T
-    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
-    from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    _lib.require_gpu()
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-
-    H, W, D = HWD
-    model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
-    model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0))
-    model.to(dev).eval()
-    diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True)
-    kw = dict(H=H, W=W, D=D)
-    torch.manual_seed(1000 + rank)
-    x = torch.randn(1, 12, H + D, W + D, device=dev)
-
-    all_t = torch.arange(T_STEPS, device=dev, dtype=torch.int64)[:, None].contiguous()     # as GaussianDiffusion._loop does
-
-    def run(n, x, start):
-        with torch.no_grad():
-            for k in range(n):
-                i = (T_STEPS - 1 - (start + k)) % T_STEPS
-                x = diffusion.p_sample(model, x, all_t[i], model_kwargs=kw)["sample"]
-        return x
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    x = run(args.warmup, x, 0)
-    torch.cuda.synchronize()
-    model.profile(args.profile_every)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    x = run(args.steps, x, args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = model.profile_read()
-    model.profile(0)
-    assert torch.isfinite(x).all()
-
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        ms_step = dt / args.steps * 1e3
-        value = world * args.steps / T_STEPS / dt
-        fd = f_dense_per_step(MC, H, W, D)
-        roof = None
-        if prof.launches[0] > 0:
-            ach = prof.flops[0] / (prof.ms[0] * 1e-3) / 1e12
-            traffic = None
-            try:    # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH/WRITE_SIZE)
-                traffic = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["dominant_traffic_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                pass
-            wino = os.environ.get("S3D_WINO", "1") != "0"
-            exec_frac = 4.0 / 9.0 if wino else 1.0        # Winograd F(2x2,3x3): 16 MFMA multiplies per 4 outputs instead of 36
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "mfma_executed_tflops": round(ach * exec_frac, 2),
-                    "mfma_executed_frac": round(ach * exec_frac / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x read correction)",
-                    # north_star also asks for the HBM-roofline fraction of the same kernel: PMC bytes / live launch time
-                    "hbm_gbs": round(traffic / (prof.ms[0] / prof.launches[0] * 1e-3) / 1e9, 1) if traffic else None,
-                    "hbm_frac_of_8TBs": round(traffic / (prof.ms[0] / prof.launches[0] * 1e-3) / 8e12, 4) if traffic else None,
-                    "kernel": (("k_conv_wino2" if os.environ.get("S3D_WINO") == "2" else "k_conv_wino4") + " (fused Winograd F(2x2,3x3)" if wino else "k_conv_mfma<3x3> (direct") +
-                              ", dense own-channel part of the rollout TriplaneConv)",
-                    "avg_launch_us": round(prof.ms[0] / prof.launches[0] * 1e3, 2),
-                    "launches_timed": int(prof.launches[0]),
-                    "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
-                    "conv3x3_ms_per_step": round(prof.ms[0] / max(prof.forwards, 1), 4),
-                    "rank1_ms_per_step": round(prof.ms[2] / max(prof.forwards, 1), 4),
-                    "conv1x1_ms_per_step": round(prof.ms[1] / max(prof.forwards, 1), 4),
-                    "note": "achieved = algorithmic flops of the launches (2*9*C*Cout per output pixel, own channels only: "
-                            "rank-1 rollout exploited) / HIP-event time; mfma_executed_* = what the matrix cores really "
-                            "multiply (x4/9 under Winograd); the reference-executed F_dense rate is effective_dense_tflops"}
-        line = {"metric": "DDPM-1000 triplane samples/sec @128^2 latent", "value": value, "unit": "samples/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                "data": "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)",
-                "config": {"workload": "BASELINE configs[1]: 128^2 triplane (H,W,D)=(128,128,128), 128-ch "
-                                       "TriplaneUNetModelSmall, DDPM-1000, batch 1 per GPU; a step = 1 denoising step",
-                           "steps_per_sample": T_STEPS, "batch_per_gpu": 1, "parallelism": f"{world} independent samples"},
-                "f_dense_gflop_per_step": round(fd / 1e9, 2),
-                "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
-                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_workers(args, sys.argv[1:])
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

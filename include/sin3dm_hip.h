@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define S3D_ABI_VERSION 1
+#define S3D_ABI_VERSION 2
 #define S3D_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -79,12 +79,14 @@ S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B,
 /* Live kernel timing for bench.py's roofline line: HIP events are recorded on `stream` around every
  * MFMA convolution launch of each `every`-th forward (0 = off).  s3d_unet_profile_read waits for the
  * recorded events, ADDS their durations to `out` (caller zero-initialises) and recycles them.
- * flops = executed algorithmic flops of the launches, 2*taps*cin*cout*pixels. */
+ * flops = algorithmic flops of the launches, 2*taps*cin*cout*pixels; mfma_flops = what the
+ * matrix cores really multiply for them (Winograd F(2x2,3x3): 4/9 of the direct count, F(4x4,3x3): 1/4). */
 typedef struct {
     double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */
     double flops[3];
     int64_t launches[3];
     int64_t forwards;      /* forwards that were instrumented */
+    double mfma_flops[3];
 } s3d_profile;
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);

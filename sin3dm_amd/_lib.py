@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsin3dm_hip.so")
 c_fp = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 TAB_ROWS = ("sqrt_recip", "sqrt_recipm1", "coef1", "coef2", "logvar", "acp", "acp_prev")
 STEP_DDPM, STEP_DDIM, STEP_MEAN_ONLY = 0, 1, 2
 MEAN_START_X, MEAN_EPSILON = 0, 1
@@ -37,7 +37,7 @@ class SamplerArgs(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("ms", C.c_double * 3), ("flops", C.c_double * 3), ("launches", C.c_int64 * 3),
-                ("forwards", C.c_int64)]
+                ("forwards", C.c_int64), ("mfma_flops", C.c_double * 3)]
 
 
 class AeLossCfg(C.Structure):

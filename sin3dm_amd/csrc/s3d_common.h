@@ -127,6 +127,8 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
 // Selected with S3D_CONV_IMPL=naive; never the default.
 int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st);
 bool conv_use_naive();
+// MFMA flops a launch really issues / its direct-convolution flop count (1 for the direct kernels, 4/9 for Winograd F(2x2,3x3))
+double conv_exec_fraction(ConvKind kind, const ConvArgs& a);
 
 // Packed TriplaneConv parameters: offsets (in floats) into a staging image that is uploaded as one buffer.
 struct ConvW {
@@ -178,6 +180,7 @@ bool conv_use_wino();
 void wino_gn_parts(const Geo& g, int nparts[3]);
 size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
 int launch_conv_wino(ConvArgs& a, hipStream_t st);
+double wino_exec_fraction();
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {

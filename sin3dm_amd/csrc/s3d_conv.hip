@@ -503,6 +503,11 @@ static long long count_tiles(const ConvArgs& a) {
     return t * a.B;
 }
 
+double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
+    if (kind == CONV_3x3 && !conv_use_naive() && conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) return wino_exec_fraction();
+    return 1.0;
+}
+
 int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);

@@ -104,7 +104,7 @@ struct s3d_unet {
     const float* tdev(size_t off) const { return static_cast<const float*>(tbuf.p) + off; }
 
     // optional live timing of the convolution launches (s3d_unet_profile)
-    struct ProfRec { int cls; hipEvent_t e0, e1; double flops; };
+    struct ProfRec { int cls; hipEvent_t e0, e1; double flops, mfma_flops; };
     int prof_every = 0;
     long fwd_count = 0;
     bool prof_now = false;
@@ -123,7 +123,8 @@ struct s3d_unet {
         int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : 25));
         double pix = 0;
         for (int j = 0; j < ca.njobs; ++j) pix += double(ca.job[j].h) * ca.job[j].w;
-        ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B};
+        ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B, 0.0};
+        r.mfma_flops = r.flops * conv_exec_fraction(kind, ca);
         if (r.e0) (void)hipEventRecord(r.e0, st);
         int rc = launch_conv(kind, ca, st);
         if (r.e1) (void)hipEventRecord(r.e1, st);

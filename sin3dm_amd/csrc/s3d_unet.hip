@@ -401,6 +401,7 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
             S3D_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
             out->ms[r.cls] += ms;
             out->flops[r.cls] += r.flops;
+            out->mfma_flops[r.cls] += r.mfma_flops;
             out->launches[r.cls] += 1;
         }
         if (r.e0) m->prof_pool.push_back(r.e0);

@@ -626,6 +626,7 @@ static int wino_variant() {          // 4: one frequency row per wave (default),
     }
     return v;
 }
+double wino_exec_fraction() { return 4.0 / 9.0; }      // F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
 bool conv_use_wino() { return wino_variant() != 0 && !conv_use_naive(); }
 
 void wino_gn_parts(const Geo& g, int nparts[3]) {    // one part per wave of a tile's block(s), both kernels

@@ -1,0 +1,49 @@
+"""CPU-only: `python bench.py --gpus N` without a torchrun environment starts N fresh worker processes (one per GPU),
+relays rank 0's JSON line and fails when a worker fails.  The workers run in --dry-run mode (gloo rendezvous, barrier,
+MAX all-reduce of the wall time, the step replaced by a sleep): the launcher plumbing is what is under test."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+
+def _run(*extra, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "3", "--warmup", "1", "--dry-run", *extra],
+                          capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_plain_multi_gpu_launch_spawns_workers():
+    r = _run("--gpus", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "2 independent samples"
+    assert line["ms_per_step"] >= 1.0                                   # the 1 ms sleeps, max over ranks
+    assert "DRY RUN" in line["data"] and line["value"] == 0.0          # never mistaken for a measurement
+
+
+def test_failed_worker_fails_the_launch():
+    r = _run("--gpus", "2", "--dry-run-fail-rank", "1")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_under_torchrun_environment_no_respawn():
+    """WORLD_SIZE set (torch.distributed.run launched us): run as that rank, do not spawn."""
+    r = _run("--gpus", "1", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
+    r = _run("--gpus", "2", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_switches_are_recorded():
+    r = _run("--gpus", "1", env={"S3D_WINO": "2", "S3D_XCD": "0"})
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["s3d_switches"] == {"S3D_WINO": "2", "S3D_XCD": "0"}

@@ -347,7 +347,7 @@ def test_ddim_inpainting_branch(oracle):
                     o = diff.ddim_sample(model, cu(x), t, model_kwargs=kw, eta=eta, y0=cu(y0), mask=cu(mask), is_mask_t0=is_t0)
                 x0 = mixed if (is_t0 or ti != 0) else plain
                 # the update of ddim_update() with its x0 replaced: eps is re-derived from the mixed x0 (:579)
-                sr, srm1, ab, abp = (float(tab[k][ti]) for k in ("sqrt_recip", "sqrt_recipm1", "acp", "acp_prev"))
+                sr, srm1, ab, abp = (float(tab[r][ti]) for r in (3, 4, 1, 2))     # oracle.TABLE_ROWS
                 e = (np.float32(sr) * x - x0) / np.float32(srm1)
                 sigma = eta * np.sqrt((1 - abp) / (1 - ab)) * np.sqrt(1 - ab / abp)
                 want = x0 * np.float32(np.sqrt(abp)) + np.float32(np.sqrt(1 - abp - sigma ** 2)) * e + (ti != 0) * np.float32(sigma) * eps
@@ -364,9 +364,9 @@ def test_ddim_inpainting_branch(oracle):
 def tp_ddim(model_out, x, tab, t):
     """eta = 0 DDIM update on torch tensors (gaussian_diffusion.py:538-600), fp32 like the reference."""
     x0 = model_out.clamp(-1, 1)
-    f = lambda k: torch.tensor(float(tab[k][t]), dtype=torch.float32)
-    eps = (f("sqrt_recip") * x - x0) / f("sqrt_recipm1")
-    abp = f("acp_prev")
+    f = lambda r: torch.tensor(float(tab[r][t]), dtype=torch.float32)            # rows as oracle.TABLE_ROWS
+    eps = (f(3) * x - x0) / f(4)
+    abp = f(2)
     return x0 * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps, x0
 
 
