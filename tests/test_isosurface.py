@@ -155,3 +155,54 @@ def test_hip_components_and_largest(oracle):
     assert len(vv) == int((ref == best).sum()) and len(tt) == int(counts.max())
     closed, chi = _invariants(vv.cpu().numpy(), tt.cpu().numpy())
     assert closed and chi == 2                                                   # one closed blob is left
+
+
+# ------------------------------------------------------------------ table-free check (oracle/mc_independent.py)
+def _independent():
+    import os, sys
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import mc_independent
+    return mc_independent
+
+
+@pytest.mark.parametrize("kind,pad", [("sphere", 1.0), ("two", 1.0), ("noise", 1.0), ("noise", None), ("smooth_noise", 1.0)])
+def test_oracle_mesh_against_table_free_definition(oracle, kind, pad):
+    """The C restatement (which shares the generated case table with the HIP kernel) against what marching cubes fixes
+    without any table: the vertex set and positions, one cell per triangle, the segments on every cell face
+    (unambiguous faces: the one possible segment; ambiguous faces: two segments, same pairing from both sides),
+    outward orientation.  What this cannot see is which of the two pairings PyMCubes' table picks on an ambiguous face."""
+    mi = _independent()
+    rng = np.random.Generator(np.random.PCG64(12))
+    if kind == "noise":
+        f = rng.standard_normal((9, 8, 7)).astype(np.float32)
+    elif kind == "smooth_noise":
+        c = rng.standard_normal((4, 4, 4))
+        ax = [np.linspace(0, 3, n) for n in (13, 11, 12)]
+        from scipy.ndimage import map_coordinates
+        f = map_coordinates(c, np.meshgrid(*ax, indexing="ij"), order=3, mode="nearest").astype(np.float32)
+    else:
+        f, _ = _field(kind, 14)
+    v, t = oracle.marching_cubes(f, 0.0, pad)
+    stats = mi.check_mesh(f, v, t, 0.0, pad)
+    assert stats["triangles"] == len(t) > 0
+    if kind == "noise":
+        assert stats["ambiguous_faces"] > 50                     # white noise exercises the ambiguous faces
+    if kind == "sphere":
+        n = f.shape[0]
+        scale = (2.0 / (n - 1)) * np.asarray([1, 0.9, 1.1])
+        area, vol = mi.surface_measure(v * scale, t)
+        assert abs(vol - 4 / 3 * np.pi * 0.343) < 0.05 * 4 / 3 * np.pi * 0.343 and area > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pad", [1.0, None])
+def test_hip_mesh_against_table_free_definition(pad):
+    """The same table-free check applied to the DEVICE mesh directly (no C restatement, no shared table in the loop)."""
+    import torch
+    from sin3dm_amd.encoding.isosurface import marching_cubes
+    mi = _independent()
+    rng = np.random.Generator(np.random.PCG64(13))
+    for f in (rng.standard_normal((10, 7, 9)).astype(np.float32), _field("two", 16)[0]):
+        v, t, _ = marching_cubes(torch.from_numpy(f).cuda(), 0.0, pad)
+        stats = mi.check_mesh(f, v.cpu().numpy(), t.cpu().numpy(), 0.0, pad)
+        assert stats["triangles"] == len(t) > 0
