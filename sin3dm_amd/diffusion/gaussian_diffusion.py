@@ -339,7 +339,8 @@ class GaussianDiffusion:
         mse = _mse_terms(out, target, H, W, D)
         wgt = (weights.to(out.device, th.float32) / out.shape[0])[:, None].expand(-1, 3).contiguous()
         g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out)
-        terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2], "loss": mse.sum(1)}
+        terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2]}
+        terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]       # the reference's order (:851), as training_losses
         return terms, g
 
 

@@ -318,5 +318,7 @@ def test_adamw_ema_kernel_elementwise(wd):
                                            (C.c_float * 1)(rate), 1, n, lr_s, b1, b2, eps, wd, s + 1, _lib.stream_ptr()))
         dp = (p.double().cpu() - torch.from_numpy(p0).double()).numpy()
         dref = (ref.detach() - torch.from_numpy(p0).double()).numpy()
-        assert np.max(np.abs(dp - dref)) < 2e-6 * np.max(np.abs(dref)) + 2e-7, (s, np.max(np.abs(dp - dref)))   # fp32 storage of p: ~1e-7 abs
+        # p ~ N(0,1) is stored in fp32 (half an ulp at 4.0 = 2.4e-7 per step); a wrong bias-correction exponent or decay order
+        # moves the update by >= 1e-4
+        assert np.max(np.abs(dp - dref)) < 1.5e-6, (s, np.max(np.abs(dp - dref)))
         assert np.max(np.abs(ema.double().cpu().numpy() - ema_ref.numpy())) < 5e-7, s
