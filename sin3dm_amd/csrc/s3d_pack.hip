@@ -88,6 +88,30 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
                 }
             break;
         }
+        case PK_WINO24: {                        // item = one (cout, cin) filter: G2 g G4^T, fragment order [n32][k8][24][64][4]
+            const int n = int(i / cin), k = int(i % cin);
+            double g[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) g[q] = double(W[((size_t)n * ctot + k) * 9 + q]);
+            const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                     {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+            double t[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) t[u][q] = G2[u][0] * g[0 * 3 + q] + G2[u][1] * g[1 * 3 + q] + G2[u][2] * g[2 * 3 + q];
+            const int k8t = cin / 8;
+            const int nt = n >> 5, jn = n & 31, k8 = k >> 3, hf = (k >> 2) & 1, e = k & 3;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 6; ++v) {
+                    const double uv = t[u][0] * G4[v][0] + t[u][1] * G4[v][1] + t[u][2] * G4[v][2];
+                    dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                }
+            break;
+        }
         case PK_RANK1: {                         // dst [(t*4*cout + var*cout + co)*cin + c]
             const int c = int(i % cin); long long r = i / cin;
             const int co = int(r % cout); r /= cout;
@@ -148,6 +172,7 @@ struct Plan {
             add(PK_DENSE_T, w, wt.dense_T[p], (long long)taps * cout * cin, cout, ctot, cin, taps, 0, 0, 1);
             if (k == 3) {
                 add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
+                if (cw.wino24[p]) add(PK_WINO24, w, cw.wino24[p], (long long)cout * cin, cout, ctot, cin, 9);
                 // transposed operator: cin outputs (padded to 32) x cout inputs
                 wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
                 add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);

@@ -34,6 +34,7 @@ __device__ __forceinline__ wgf4 wg4(const float* p) { return (wgf4)(uintptr_t)p;
 #ifndef W_ABL
 #define W_ABL 0                        // tools/wino_ubench.hip only (k_conv_wino2): 8 weights from one hot 16 KB, 16 no halo loads
 #endif
+constexpr int kDefaultWino = 24;        // S3D_WINO default (see wino_variant)
 constexpr int W_KC = 32;                // channels per chunk
 constexpr int W_LD = W_KC + 4;          // padded LDS pixel row (floats)
 
@@ -617,17 +618,18 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
 }
 
 // ------------------------------------------------------------------ host side
-static int wino_variant() {          // 4: one frequency row per wave (default), 2: two rows per wave, 0: direct kernel
+static int wino_variant() {          // 24: mixed F(2x4,3x3) (s3d_wino24.hip), 4: F(2x2) one frequency row per wave, 2: two rows per wave, 0: direct kernel
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("S3D_WINO");
-        v = e ? atoi(e) : 4;
-        if (v != 0 && v != 2) v = 4;
+        v = e ? atoi(e) : kDefaultWino;
+        if (v != 0 && v != 2 && v != 24) v = 4;
     }
     return v;
 }
 double wino_exec_fraction() { return 4.0 / 9.0; }      // F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36
 bool conv_use_wino() { return wino_variant() != 0 && !conv_use_naive(); }
+bool conv_use_wino24() { return wino_variant() == 24 && !conv_use_naive(); }
 
 void wino_gn_parts(const Geo& g, int nparts[3]) {    // one part per wave of a tile's block(s), both kernels
     for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + W2_TW - 1) / W2_TW) * ((g.h[p] + W2_TH - 1) / W2_TH) * 4;
@@ -661,7 +663,7 @@ size_t pack_wino_weights(std::vector<float>& stage, const float* W, int cout, in
 int launch_conv_wino(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % W_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino conv: bad arguments");
     // one kernel for every shape and batch size: a sample's result must not depend on what it is batched with
-    const bool four = wino_variant() == 4;
+    const bool four = wino_variant() != 2;          // (24: layers the mixed kernel does not take, and the training tier)
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];

@@ -1,0 +1,377 @@
+// s3d_wino24.hip — 3x3 TriplaneConv as a fused MIXED Winograd convolution F(2x4, 3x3) on the fp32 matrix cores:
+// F(2,3) along the rows, F(4,3) along the columns.  A 4x6 input patch gives a 2x4 output tile through 24 "frequency"
+// GEMMs: 3 multiplies per output instead of 4 (F(2x2,3x3), s3d_wino.hip) or 9 (direct) — 25 % fewer MFMA flops than
+// k_conv_wino4 in a k-loop that was already matrix-pipe bound.
+//
+//   Y = A2^T [ (G2 g G4^T) .* (B2^T d B4) ] A4        B2/G2/A2: F(2,3) (points 0, +-1, inf),  B4/G4/A4: F(4,3) (0, +-1, +-2, inf)
+//
+// fp32 error against an fp64 direct convolution, measured on this network's layer shapes: 0.9-1.2e-6 relative
+// (F(2x2): 2-3e-7, direct fp32: 2.5-4.7e-7, full F(4x4): 3.6-4.9e-6) — three decades inside the 1e-3 gate.
+//
+// Data flow (same skeleton as k_conv_wino4; what changes is noted):
+//   * block = 16x16 output pixels = 8x4 tiles of 2x4 = one 32-row MFMA tile, x 32 output channels; four waves, wave u owns
+//     row u of the 4x6 frequency grid: 6 accumulators of 32x32 (96 registers) -> two blocks per CU, two waves per SIMD;
+//   * the 18x18-pixel input halo of a 16-channel chunk sits in LDS (20 floats per pixel, channel quads XOR-swizzled with
+//     the tile row so that the 4x6-patch reads of a lane group hit 16 distinct 16-byte slots: conflict-free); two buffers.
+//     A chunk is two k-steps of 8 channels; the halo of chunk c+1 is fetched half in step (c-1,1), half in step (c,0), with ONE
+//     barrier per chunk (after step 0);
+//   * a lane owns one tile: per k-step it reads 2 patch rows x 6 columns (ds_read_b128), combines them for its wave's row
+//     frequency (t = x + s*y) and runs the 6-point column transform (12 vector operations) -> A operands of 6 frequencies x
+//     4 channels, each used by four MFMAs;
+//   * weights G2 g G4^T are packed (host, in double) in MFMA fragment order [n32][k8][24 freq][64 lanes][4]: one coalesced
+//     1 KB load per (frequency, 8 channels), through a register ring, no LDS;
+//   * the k-step is 24 pinned slots {one MFMA + a piece of the other work};
+//   * epilogue: each wave applies the 6 -> 4 column pass to its frequency row and writes it as a share image
+//     [8 tile rows][16 columns][32 channels]; pixel-quad threads combine three images (row pass), add bias / rank-1
+//     rollout terms / residual, store 16 bytes and reduce the GroupNorm partial sums.
+#include "s3d_common.h"
+
+namespace s3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X_KC = 16;                           // channels per chunk
+constexpr int X_LD = X_KC + 4;                     // LDS floats per halo pixel
+constexpr int X_TH = 16, X_TW = 16;                // output pixels of a block: 8 x 4 tiles of 2 x 4
+constexpr int X_HH = X_TH + 2, X_HW = X_TW + 2;    // halo
+constexpr int X_PIX = X_HH * X_HW;                 // 324
+constexpr int X_ITEMS = X_PIX * (X_KC / 4);        // float4 items per chunk (1296)
+constexpr int X_ITEMS_PT = (X_ITEMS + 255) / 256;  // per thread (6; the sixth round covers 16 items)
+constexpr int X_ABUF = X_PIX * X_LD;               // floats per halo buffer
+constexpr int X_IMG = (X_TH / 2) * X_TW * 32;      // one share image
+
+__device__ __forceinline__ int x_edge_variant(int idx, int n) { return n == 1 ? 3 : (idx == 0 ? 1 : (idx == n - 1 ? 2 : 0)); }
+
+__global__ __launch_bounds__(256, 2) void k_conv_wino24(ConvArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * X_IMG];              // 64 KB: two halo buffers in the k-loop, four share images after it
+    static_assert(2 * X_ABUF <= 4 * X_IMG, "LDS plan");
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    int bid = blockIdx.x;
+    if (args.xcd_swizzle & 1) {
+        const int chunk = int(gridDim.x) >> 3;
+        if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
+    }
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int n32 = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int tile_idx = local;
+    const int ty0 = (local / J.tiles_x) * X_TH, tx0 = (local % J.tiles_x) * X_TW;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);                 // row frequency of this wave
+    const int i = lane & 31, half = lane >> 5;
+    const int tr = i >> 2, tc = i & 3;
+    // wave u needs patch rows (x, y): t = x + s*y with (x, y, s) = (d0,d2,-), (d1,d2,+), (d2,d1,-), (d1,d3,-)
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(u == 1 ? 0x3F800000 : 0xBF800000));
+    // byte addresses of the lane's patch rows in a halo buffer, for the first / second 8 channels of a chunk:
+    // pixel (2*tr + row, 4*tc + c), logical quad q = 2*kk + half stored at quad q ^ ((2*tr + row) >> 1 & 3)
+    const int ex = half ^ ((tr + (xrow >> 1)) & 3), ey = half ^ ((tr + (yrow >> 1)) & 3);
+    const int bx = ((2 * tr + xrow) * X_HW + 4 * tc) * X_LD * 4, by = ((2 * tr + yrow) * X_HW + 4 * tc) * X_LD * 4;
+    const int ax0 = bx + 16 * ex, ax1 = bx + 16 * (ex ^ 2), ay0 = by + 16 * ey, ay1 = by + 16 * (ey ^ 2);
+
+    const int k8_total = cin / 8;
+    const float* ub = J.wgt + ((size_t(n32) * k8_total) * 24 + u * 6) * 256;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, k8_total * 24 * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wfrag = [&](int step, int f) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (step * 24 + f) * 1024, 0));
+    };
+    const float* inb = J.in + size_t(b) * h * w * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, h * w * cin * 4, 0x00020000);
+    // halo staging: item = it*256 + tid -> (pixel item>>2, channel quad item&3); out-of-image pixels (and items past the
+    // halo) get an offset beyond the descriptor's range: the hardware returns zeros = the convolution's padding
+    unsigned goff[X_ITEMS_PT];
+    int loff[X_ITEMS_PT];
+#pragma unroll
+    for (int it = 0; it < X_ITEMS_PT; ++it) {
+        const int item = it * 256 + tid;
+        const int pix = item >> 2, q = item & 3;
+        const int hy = pix / X_HW, hx = pix - hy * X_HW;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = item < X_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        goff[it] = ok ? unsigned((gy * w + gx) * cin + q * 4) * 4u : 0x80000000u;
+        loff[it] = pix * X_LD + ((q ^ ((hy >> 1) & 3)) << 2);
+    }
+    const bool last_ok = (X_ITEMS_PT - 1) * 256 + tid < X_ITEMS;
+    auto item_load = [&](int it, int ch) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], ch * (X_KC * 4), 0));
+    };
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        if (it < X_ITEMS_PT - 1 || last_ok) *reinterpret_cast<f32x4*>(smem + buf * X_ABUF + loff[it]) = v;
+    };
+
+    f32x16 acc[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    const int nchunks = cin / X_KC;
+    f32x4 VA[6], VB[6], ring[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) { ring[f] = wfrag(0, f); __builtin_amdgcn_sched_barrier(0); }
+    {
+        const int c1 = nchunks > 1 ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < X_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+#pragma unroll
+        for (int it = 0; it < 3; ++it) item_store(it, 1, item_load(it, c1));
+    }
+    __syncthreads();
+#define X_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
+#define X_PIN(v) asm volatile("" : "+v"(v))
+    // column transform B4^T of the row-combined vector t[0..5] (F(4,3), points 0, +-1, +-2, inf):
+    //   V0 = 4 t0 - 5 t2 + t4        V1 = s1 + s2, V2 = s1 - s2   with s1 = t4 - 4 t2, s2 = t3 - 4 t1
+    //   V5 = 4 t1 - 5 t3 + t5        V3 = s3 + 2 s4, V4 = s3 - 2 s4 with s3 = t4 - t2,  s4 = t3 - t1
+    {
+        f32x4 t[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const f32x4 x = X_LDS4(ax0 + c * (X_LD * 4)), y = X_LDS4(ay0 + c * (X_LD * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c][e] = fmaf(sgn, y[e], x[e]);
+        }
+        const f32x4 s1 = t[4] - 4.f * t[2], s2 = t[3] - 4.f * t[1], s3 = t[4] - t[2], s4 = t[3] - t[1];
+        VA[0] = 4.f * t[0] + (t[4] - 5.f * t[2]);
+        VA[1] = s1 + s2; VA[2] = s1 - s2;
+        VA[3] = s3 + 2.f * s4; VA[4] = s3 - 2.f * s4;
+        VA[5] = 4.f * t[1] + (t[5] - 5.f * t[3]);
+    }
+
+    // One k-step = 24 slots of {one MFMA + a piece of the other work}.  For the NEXT step's operands: 12 patch reads
+    // (slots of f = 0..2), the six row combinations (f = 0..2), the column transform (f = 3, 4); 6 weight fragments (one per
+    // f), 3 halo loads whose data is only touched by the ds_write at the end of the step.
+    //   RA/RB: byte address sets of the patch to read (same buffer, second channel half in step 0; other buffer, first half in step 1)
+#define W24_STEP(Vc, Vn, KK)                                                                                          \
+    {                                                                                                                 \
+        const int step = chunk * 2 + (KK);                                                                            \
+        const int nstep = step + 1 < k8_total ? step + 1 : step;                                                      \
+        const int rx = ((KK) == 0 ? ax1 : ax0) + ((KK) == 0 ? cur : (cur ^ tog)) * 1;                                 \
+        const int ry = ((KK) == 0 ? ay1 : ay0) + ((KK) == 0 ? cur : (cur ^ tog)) * 1;                                 \
+        constexpr int it0 = (KK) == 0 ? 3 : 0;                                                                        \
+        const int lch = (KK) == 0 ? cn1 : cn2;                                                                        \
+        f32x4 pf[3], cx0, cy0, cx1, cy1, t0, t1, t2, t3, t4, t5, s1, s2, s3, s4;                                      \
+        _Pragma("unroll") for (int f = 0; f < 6; ++f) {                                                               \
+            const f32x4 bq = ring[f];                                                                                 \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][0], bq[0], acc[f], 0, 0, 0);                          \
+            if (f < 3) {                                                                                              \
+                cx0 = X_LDS4(rx + (2 * f) * (X_LD * 4)); cy0 = X_LDS4(ry + (2 * f) * (X_LD * 4));                     \
+                cx1 = X_LDS4(rx + (2 * f + 1) * (X_LD * 4)); cy1 = X_LDS4(ry + (2 * f + 1) * (X_LD * 4));             \
+            }                                                                                                         \
+            if (f == 3) { s1 = t4 - 4.f * t2; X_PIN(s1); s2 = t3 - 4.f * t1; X_PIN(s2); }                             \
+            if (f == 4) { s3 = t4 - t2; X_PIN(s3); s4 = t3 - t1; X_PIN(s4); }                                         \
+            if (f == 5) { Vn[5] = 4.f * t1 + (t5 - 5.f * t3); X_PIN(Vn[5]); }                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][1], bq[1], acc[f], 0, 0, 0);                          \
+            ring[f] = wfrag(nstep, f);                                                                                \
+            if (f == 1) { pf[0] = item_load(it0, lch); pf[1] = item_load(it0 + 1, lch); pf[2] = item_load(it0 + 2, lch); } \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][2], bq[2], acc[f], 0, 0, 0);                          \
+            if (f == 0) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t0[e] = fmaf(sgn, cy0[e], cx0[e]); X_PIN(t0); } \
+            if (f == 1) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t2[e] = fmaf(sgn, cy0[e], cx0[e]); X_PIN(t2); } \
+            if (f == 2) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t4[e] = fmaf(sgn, cy0[e], cx0[e]); X_PIN(t4); } \
+            if (f == 3) { Vn[1] = s1 + s2; X_PIN(Vn[1]); Vn[2] = s1 - s2; X_PIN(Vn[2]); }                             \
+            if (f == 4) { Vn[3] = s3 + 2.f * s4; X_PIN(Vn[3]); Vn[4] = s3 - 2.f * s4; X_PIN(Vn[4]); }                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vc[f][3], bq[3], acc[f], 0, 0, 0);                          \
+            if (f == 0) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t1[e] = fmaf(sgn, cy1[e], cx1[e]); X_PIN(t1); } \
+            if (f == 1) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t3[e] = fmaf(sgn, cy1[e], cx1[e]); X_PIN(t3); } \
+            if (f == 2) { _Pragma("unroll") for (int e = 0; e < 4; ++e) t5[e] = fmaf(sgn, cy1[e], cx1[e]); X_PIN(t5); } \
+            if (f == 3) { Vn[0] = 4.f * t0 + (t4 - 5.f * t2); X_PIN(Vn[0]); }                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+        }                                                                                                             \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) item_store(it0 + t, (KK) == 0 ? (chunk + 1) & 1 : chunk & 1, pf[t]); \
+        if ((KK) == 0) __syncthreads();                                                                               \
+    }
+
+    int cur = 0;                                  // byte offset of the buffer that holds the current chunk
+    const int tog = X_ABUF * 4;
+    __builtin_amdgcn_s_setprio(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cn1 = chunk + 1 < nchunks ? chunk + 1 : nchunks - 1;
+        const int cn2 = chunk + 2 < nchunks ? chunk + 2 : nchunks - 1;
+        W24_STEP(VA, VB, 0)
+        W24_STEP(VB, VA, 1)
+        cur ^= tog;
+    }
+#undef W24_STEP
+#undef X_LDS4
+#undef X_PIN
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+
+    // ---- epilogue.  acc[v] = M[u][v].  Column pass A4^T (6 -> the 4 pixels of a tile row):
+    //   c0 = m0 + p + r, c1 = q + 2 s, c2 = p + 4 r, c3 = q + 8 s + m5   with p = m1 + m2, q = m1 - m2, r = m3 + m4, s = m3 - m4
+    // then the F(2,3) row pass over the waves: tile row 0 = c(u0) + c(u1) + c(u2), row 1 = c(u1) - c(u2) - c(u3).
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    __syncthreads();                                     // all patch reads and halo stores of the last step are done
+    {
+        float* img = smem + u * X_IMG + i;               // lane (i, half) holds output channel n32*32 + i of tiles ti(r)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+            const float p = m1 + m2, q = m1 - m2, rr = m3 + m4, s = m3 - m4;
+            const int ti = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int pp = ((ti >> 2) * X_TW + 4 * (ti & 3)) * 32;
+            img[pp] = (m0 + p) + rr; img[pp + 32] = fmaf(2.f, s, q); img[pp + 64] = fmaf(4.f, rr, p); img[pp + 96] = fmaf(8.f, s, q) + m5;
+        }
+    }
+    // finishing thread: channels co4..co4+3 of pixel column xl, rows rsel*8 .. rsel*8+7 of the tile (two batches of four)
+    const int quad = tid & 7, xl = (tid >> 3) & 15, rsel = tid >> 7;
+    const int co4 = n32 * 32 + quad * 4;
+    const bool c_ok = co4 < cout;
+    const int coc = c_ok ? co4 : 0;
+    const int x = tx0 + xl;
+    const bool x_ok = x < w && c_ok;
+    const int xc = x < w ? x : 0;
+    f32x4 base4 = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+    if (p_bbias) base4 += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+    const bool interior_rows = ty0 > 0 && ty0 + X_TH < h;
+    const int vx = x_edge_variant(xc, w);
+    f32x4 tcol[4], trow[4], tres[4];
+    auto fetch = [&](int batch) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
+        if (p_rcol) {
+            if (interior_rows) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + 0) * cout + coc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tcol[k] = v0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = ty0 + rsel * 8 + batch * 4 + k;
+                    tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc);
+                }
+            }
+        }
+        if (p_rrow) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 8 + batch * 4 + k;
+                trow[k] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
+            }
+        }
+        if (p_res) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 8 + batch * 4 + k;
+                tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+            }
+        }
+    };
+    fetch(0);
+    __syncthreads();                                     // the share images are complete
+    f32x4 gs4 = zero4, gss4 = zero4;
+#pragma unroll
+    for (int batch = 0; batch < 2; ++batch) {
+        if (batch == 1) fetch(1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yl = rsel * 8 + batch * 4 + k, y = ty0 + yl;
+            const float* sp = smem + (yl & 1) * X_IMG + ((yl >> 1) * X_TW + xl) * 32 + quad * 4;
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + X_IMG),
+                        kc = *reinterpret_cast<const f32x4*>(sp + 2 * X_IMG);
+            const f32x4 sum3 = (yl & 1) ? (ka - kb) - kc : (ka + kb) + kc;
+            const f32x4 v = (sum3 + base4) + ((tcol[k] + trow[k]) + tres[k]);
+            if (x_ok && y < h) {
+                *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
+                gs4 += v; gss4 += v * v;
+            }
+        }
+    }
+    if (p_gn) {
+        // per wave: 8 pixel columns (lanes l, l+8, ..) x 8 rows of 8 channel quads; one part per wave
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
+        const int sg = args.gn_sg;
+        const int part = tile_idx * 4 + u;
+        auto put = [&](int sub, float s, float ss) {            // partial layout [b][plane][sub][part][2]
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+            dst[0] = double(s); dst[1] = double(ss);
+        };
+        if (sg >= 4) {
+            float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
+            for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+            if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, s, ss);
+        } else if (lane < 8 && c_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                if (sg == 2) put((co4 + e) / 2, gs4[e] + gs4[e + 1], gss4[e] + gss4[e + 1]);
+                else { put(co4 + e, gs4[e], gss4[e]); put(co4 + e + 1, gs4[e + 1], gss4[e + 1]); }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+void wino24_gn_parts(const Geo& g, int nparts[3]) {      // one part per wave of a tile's block
+    for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + X_TW - 1) / X_TW) * ((g.h[p] + X_TH - 1) / X_TH) * 4;
+}
+
+static const double kG2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+static const double kG4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+
+size_t wino24_packed_floats(int cout, int cin) { return size_t((cout + 31) / 32) * (cin / 8) * 24 * 256; }
+
+// U = G2 g G4^T in double, stored in MFMA fragment order [n32][k8][24][64 lanes][4]; W is OIHW [cout][ctot][3][3],
+// only input channels [0, cin) are used (the plane's own channels).
+size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin) {
+    const int k8t = cin / 8;
+    const size_t total = wino24_packed_floats(cout, cin);
+    const size_t off = push(stage, nullptr, total);
+    float* d = stage.data() + off;
+    std::fill(d, d + total, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = W + (size_t(co) * ctot + c) * 9;
+            double t[4][3];
+            for (int u = 0; u < 4; ++u)
+                for (int k = 0; k < 3; ++k) t[u][k] = kG2[u][0] * g[0 * 3 + k] + kG2[u][1] * g[1 * 3 + k] + kG2[u][2] * g[2 * 3 + k];
+            const int nt = co >> 5, jn = co & 31, k8 = c >> 3, hf = (c >> 2) & 1, e = c & 3;
+            for (int u = 0; u < 4; ++u)
+                for (int v = 0; v < 6; ++v) {
+                    const double uv = t[u][0] * kG4[v][0] + t[u][1] * kG4[v][1] + t[u][2] * kG4[v][2];
+                    d[(((size_t(nt) * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                }
+        }
+    return off;
+}
+
+int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % X_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24 conv: bad arguments");
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        S3D_CHECK(size_t(J.h) * J.w * a.cin * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wino24 conv: a plane of one sample must stay below 2 GiB");
+        J.tiles_x = (J.w + X_TW - 1) / X_TW;
+        J.tiles_per_img = J.tiles_x * ((J.h + X_TH - 1) / X_TH);
+        J.n_tiles_n = (a.cout + 31) / 32;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
+    a.xcd_swizzle = xcd;
+    hipLaunchKernelGGL(k_conv_wino24, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace s3d

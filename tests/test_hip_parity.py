@@ -99,25 +99,30 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["2", "0"])
+@pytest.mark.parametrize("variant", ["24", "4", "2", "0"])
 def test_unet_forward_golden_other_conv_kernels(variant):
-    """The 3x3 kernels that are not the default (S3D_WINO=2: two frequency rows per wave, S3D_WINO=0: direct MFMA
-    convolution) against the same golden vectors; the choice is read once per process, hence the subprocess."""
+    """Every 3x3 kernel, forced onto the small golden planes (S3D_WINO=24 with S3D_WINO24_MIN_BLOCKS=0: mixed Winograd
+    F(2x4,3x3) on every layer; 4 / 2: F(2x2) with one / two frequency rows per wave; 0: direct MFMA convolution) against the
+    same golden vectors, leaf convolutions and ragged shapes included; the choice is read once per process, hence the
+    subprocess."""
     import os, subprocess, sys
     code = (
         "import numpy as np, torch, sys\n"
         "sys.path.insert(0, 'tests')\n"
         "from conftest import golden, relerr\n"
+        "import conftest, test_hip_parity as tp\n"
+        "tp.test_leaf_ops('a', 32); tp.test_leaf_ops('b', 64)\n"
+        "sys.path.insert(0, 'oracle'); import oracle as orc; orc.lib(); tp.test_conv_edge_shapes(orc)\n"
         "from test_hip_parity import make_model, cu, UNET_CASES\n"
         "g = golden('unet_fwd')\n"
-        "for tag, mc, raw, ssn, cm in UNET_CASES[:3]:\n"
+        "for tag, mc, raw, ssn, cm in UNET_CASES:\n"
         "    H, W, D = (int(v) for v in g[f'{tag}.hwd'])\n"
         "    with torch.no_grad():\n"
         "        y = make_model(mc, raw, ssn, cm)(cu(g[f'{tag}.x']), cu(g[f'{tag}.t']), H=H, W=W, D=D).cpu().numpy()\n"
         "    e = relerr(y, g[f'{tag}.y'])\n"
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
-    env = dict(os.environ, S3D_WINO=variant)
+    env = dict(os.environ, S3D_WINO=variant, S3D_WINO24_MIN_BLOCKS="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
