@@ -99,7 +99,8 @@ struct ConvJob {
     const float* in;      // [B][h][w][cin] NHWC
     const float* wgt;     // packed [taps][cout][cin]
     const float* wgt_wino;// 3x3 only: Winograd-transformed weights in MFMA fragment order (s3d_wino.hip) or null
-    const float* wgt_wino24;// 3x3 only: the F(2x4,3x3) image (s3d_wino24.hip) or null (null: the F(2x2) kernels are used)
+    const float* wgt_wino24;// 3x3 only: the F(2x4,3x3) image of the 16x16-pixel kernel (s3d_wino24.hip) or null
+    const float* wgt_wino24s;// 3x3 only: the F(2x4,3x3) image of the 8x16-pixel kernel or null (both null: the F(2x2) kernels are used)
     const float* bias;    // [cout] or null
     const float* bbias;   // [B][bbias_stride] per-sample bias (h + emb path) or null
     const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
@@ -138,7 +139,8 @@ struct ConvW {
     size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3][4*cout][C]
     size_t rcol[3] = {0, 0, 0};       // rank-1 weights for the column-varying mean vector
     size_t wino[3] = {0, 0, 0};       // 3x3: G g G^T in fragment order (0 = not packed)
-    size_t wino24[3] = {0, 0, 0};     // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in fragment order
+    size_t wino24[3] = {0, 0, 0};     // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24
+    size_t wino24s[3] = {0, 0, 0};    // ... and of k_conv_wino24s
     int cin = 0, cout = 0, k = 0;
     bool rollout = false;
 };
@@ -176,7 +178,7 @@ inline int gn_subgroup(int C) {   // largest power of two dividing C/32, at most
 int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st);   // out: maxparts=kGnChunks, nsub=32
 int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnStats out, hipStream_t st);
 // how many parts per plane a convolution epilogue writes for a given geometry (must match s3d_conv.hip's tiling)
-void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], bool wino24 = false);
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24 = 0);
 // Winograd F(2x2,3x3) path for the 3x3 convolutions (s3d_wino.hip); S3D_WINO=0 selects the direct kernel
 bool conv_use_wino();
 void wino_gn_parts(const Geo& g, int nparts[3]);
@@ -185,11 +187,14 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st);
 double wino_exec_fraction();
 // mixed Winograd F(2x4,3x3) (s3d_wino24.hip): the default 3x3 kernel of the inference forward (S3D_WINO=4 / 2 / 0 select the others)
 bool conv_use_wino24();
-bool conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout);   // these planes / channels (not the batch size) take the mixed kernel
+// which mixed kernel these planes / channels (not the batch size) take: 0 none (F(2x2)), 1 the 8x16-pixel form, 2 the 16x16-pixel form
+int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout);
 void wino24_gn_parts(const Geo& g, int nparts[3]);
 size_t wino24_packed_floats(int cout, int cin);
 size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
 int launch_conv_wino24(ConvArgs& a, hipStream_t st);
+size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
+int launch_conv_wino24s(ConvArgs& a, hipStream_t st);
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {

@@ -442,10 +442,10 @@ int launch_rank1(ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], bool wino24) {
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
-    if (wino24 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }
+    if (wino24 == 2 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }      // (the 8x16-pixel form tiles like the F(2x2) kernels)
     if (conv_use_wino()) { wino_gn_parts(g, nparts); return; }
     using CFG = ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>;
     for (int p = 0; p < 3; ++p)
@@ -504,23 +504,24 @@ static long long count_tiles(const ConvArgs& a) {
     return t * a.B;
 }
 
-// The mixed kernel owns 16x16-pixel x 32-channel blocks, two per CU (208 VGPRs): it wins once a launch has clearly more
-// blocks than the 512 slots of the chip (58 vs 64 us at 128 -> 128 @128^2, 142 vs 160 us at 384 -> 128), and loses on the
-// half-resolution layers of a batch-1 step (384 blocks: half the CUs run two, half one: 66 vs 59 us).  Both kernels give the
-// same result for a sample whatever it is batched with ONLY if the choice does not depend on B: it is made on the per-sample
-// block count.
-bool conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout) {
-    if (!(conv_use_wino24() && cout % 4 == 0 && cin % 16 == 0)) return false;
-    static const int min_blocks = getenv("S3D_WINO24_MIN_BLOCKS") ? atoi(getenv("S3D_WINO24_MIN_BLOCKS")) : 700;
+// Mixed Winograd F(2x4,3x3): the 8x16-pixel kernel (three blocks per CU, as many blocks as the F(2x2) kernel) is the default;
+// the 16x16-pixel kernel (two blocks per CU, half the halo and weight traffic per flop) takes over from
+// S3D_WINO24_BIG_MIN_BLOCKS per-sample blocks of its own size.  The choice must not depend on the batch size: a sample's
+// result may not depend on what it is batched with.
+int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout) {
+    if (!(conv_use_wino24() && cout % 4 == 0 && cin % 32 == 0)) return 0;
+    static const long long big_min = getenv("S3D_WINO24_BIG_MIN_BLOCKS") ? atoll(getenv("S3D_WINO24_BIG_MIN_BLOCKS")) : (1LL << 60);
     long long blocks = 0;
     for (int j = 0; j < nplanes; ++j) blocks += (long long)((w[j] + 15) / 16) * ((h[j] + 15) / 16) * ((cout + 31) / 32);
-    return blocks >= min_blocks;
+    return blocks >= big_min ? 2 : 1;
 }
-static bool takes_wino24(const ConvArgs& a) {
-    if (!a.job[0].wgt_wino24) return false;
+static int takes_wino24(const ConvArgs& a) {
     int h[kMaxConvJobs], w[kMaxConvJobs];
     for (int j = 0; j < a.njobs; ++j) { h[j] = a.job[j].h; w[j] = a.job[j].w; }
-    return conv_wino24_geo(h, w, a.njobs, a.cin, a.cout);
+    const int k = conv_wino24_geo(h, w, a.njobs, a.cin, a.cout);
+    if (k == 2 && a.job[0].wgt_wino24) return 2;
+    if (k >= 1 && a.job[0].wgt_wino24s) return 1;
+    return 0;
 }
 double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
     if (kind == CONV_3x3 && !conv_use_naive() && takes_wino24(a)) return 1.0 / 3.0;      // 24 multiplies per 2x4 outputs instead of 72
@@ -537,9 +538,9 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
-            if (takes_wino24(a)) {
-                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino24;
-                return launch_conv_wino24(a, st);
+            if (const int k24 = takes_wino24(a)) {
+                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = k24 == 2 ? a.job[j].wgt_wino24 : a.job[j].wgt_wino24s;
+                return k24 == 2 ? launch_conv_wino24(a, st) : launch_conv_wino24s(a, st);
             }
             if (conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) {   // (its epilogue moves channel quads; GroupNorm'd layers always qualify)
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino;

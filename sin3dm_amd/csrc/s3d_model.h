@@ -58,7 +58,7 @@ struct ConvWT {
     size_t rcol_T[3] = {0, 0, 0};
 };
 struct ResBlockWT { ConvWT c1, c2, skip; };
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD };
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD };
 struct PackDesc {                     // one device-side repacking job: flat reference-layout parameter -> packed image
     int kind, cout, ctot, cin, slot, taps, col_varying, to_tbuf;
     long long src, dst, n;
@@ -266,7 +266,7 @@ struct Fwd {
         want_stats = want_stats && cw.k == 3 && !conv_use_naive();
         // the mixed Winograd kernel serves the inference forward; the training tier (forward_train + dgrad) stays on the
         // F(2x2) kernels, whose transposed operators the backward pass has
-        const bool w24 = cw.k == 3 && !tape && cw.wino24[0] != 0 && conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout);
+        const int w24 = cw.k == 3 && !tape && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout) : 0;
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);
@@ -285,6 +285,7 @@ struct Fwd {
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
             J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
             J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
+            J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = m->film_total;
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
                 }
             break;
         }
-        case PK_WINO24: {                        // item = one (cout, cin) filter: G2 g G4^T, fragment order [n32][k8][24][64][4]
+        case PK_WINO24S:
+        case PK_WINO24: {                        // item = one (cout, cin) filter: G2 g G4^T, fragment order [n32][k8][24][64][4] / [n32][k16][24][2][64][4]
             const int n = int(i / cin), k = int(i % cin);
             double g[9];
 #pragma unroll
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
 #pragma unroll
                 for (int v = 0; v < 6; ++v) {
                     const double uv = t[u][0] * G4[v][0] + t[u][1] * G4[v][1] + t[u][2] * G4[v][2];
-                    dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                    if (d.kind == PK_WINO24) dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
+                    else dst[(((((size_t)nt * (cin / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
                 }
             break;
         }
@@ -173,6 +175,7 @@ struct Plan {
             if (k == 3) {
                 add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
                 if (cw.wino24[p]) add(PK_WINO24, w, cw.wino24[p], (long long)cout * cin, cout, ctot, cin, 9);
+                if (cw.wino24s[p]) add(PK_WINO24S, w, cw.wino24s[p], (long long)cout * cin, cout, ctot, cin, 9);
                 // transposed operator: cin outputs (padded to 32) x cout inputs
                 wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
                 add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);

@@ -101,7 +101,10 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
             for (int co = 0; co < cout; ++co)
                 for (int c = 0; c < cin; ++c) d[(size_t(t) * cout + co) * cin + c] = W[(size_t(co) * ctot + c) * taps + t];
         if (k == 3) cw.wino[p] = pack_wino_weights(stage, W, cout, ctot, cin);
-        if (k == 3 && cin % 16 == 0) cw.wino24[p] = pack_wino24_weights(stage, W, cout, ctot, cin);
+        if (k == 3 && cin % 32 == 0) {
+            cw.wino24[p] = pack_wino24_weights(stage, W, cout, ctot, cin);
+            cw.wino24s[p] = pack_wino24s_weights(stage, W, cout, ctot, cin);
+        }
         if (!roll) continue;
         const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
         for (int slot = 1; slot <= 2; ++slot) {

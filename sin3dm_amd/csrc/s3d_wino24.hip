@@ -319,6 +319,287 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino24(ConvArgs args) {
     }
 }
 
+// ------------------------------------------------------------------ the small-block form: three waves per SIMD
+// Same arithmetic (bit-identical results: the same products are added in the same order), blocked like k_conv_wino4: a block
+// owns 8x16 output pixels = 4x4 tiles of 2x4 and 32 output channels, on v_mfma_f32_16x16x4_f32: a lane owns one tile AND one
+// channel quad of a 16-channel k-step (lane = 16 * quad + tile); the accumulators are 6 frequencies x 2 blocks of 16 output
+// channels x 4 registers = 48 -> <= 168 VGPRs, three blocks per CU, and a launch has as many blocks as with the F(2x2)
+// kernel (768 on the half-resolution layers of a batch-1 step: one full round of the chip, where the 16x16-pixel form above
+// leaves a quarter of it idle).
+// LDS: two halo buffers of 10 x 18 pixels x 36 floats (a 32-channel chunk = two k-steps; one barrier per chunk — with
+// 16-channel chunks and a barrier per k-step the loop ran at 80 % of the matrix pipe); the channel quad q of pixel row r
+// is stored at quad q ^ 2*((r >> 1) & 3): the patch reads of every ds_read_b128 lane group hit 16 distinct 16-byte slots.
+// Weights: [n32][k16][24 freq][2 x 16 couts][64 lanes][4], a six-deep register ring of 1 KB fragments, each requested half a
+// step before its use.  The A operands of the next step overwrite the current ones frequency by frequency as soon as their
+// MFMAs have been issued.
+constexpr int C_KC = 32, C_LD = C_KC + 4;
+constexpr int C_TH = 8, C_TW = 16;
+constexpr int C_HH = C_TH + 2, C_HW = C_TW + 2;
+constexpr int C_ITEMS = C_HH * C_HW * (C_KC / 4);            // 1440 float4 items per chunk
+constexpr int C_ITEMS_PT = (C_ITEMS + 255) / 256;            // 6 (the sixth round covers 160 items)
+constexpr int C_ABUF = C_HH * C_HW * C_LD;                   // floats per halo buffer (6480)
+constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image [4 tile rows][16 columns][32 channels]
+
+__global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];             // 51.8 KB: two halo buffers; four share images after the loop
+    static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    int bid = blockIdx.x;
+    if (args.xcd_swizzle & 1) {
+        const int chunk = int(gridDim.x) >> 3;
+        if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
+    }
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int n32 = local % J.n_tiles_n; local /= J.n_tiles_n;
+    const int b = local / J.tiles_per_img; local %= J.tiles_per_img;
+    const int tile_idx = local;
+    const int ty0 = (local / J.tiles_x) * C_TH, tx0 = (local % J.tiles_x) * C_TW;
+    const int h = J.h, w = J.w, cin = args.cin, cout = args.cout;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);                 // row frequency of this wave
+    const int t16 = lane & 15, g = lane >> 4;                               // tile of the lane, channel quad of the lane
+    const int tr = t16 >> 2, tc = t16 & 3;
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(u == 1 ? 0x3F800000 : 0xBF800000));
+    // byte addresses of the lane's two patch rows for the first / second 16 channels of a chunk (logical quad kk*4 + g)
+    const int qx = g ^ (((tr + (xrow >> 1)) & 3) << 1), qy = g ^ (((tr + (yrow >> 1)) & 3) << 1);
+    const int bx = ((2 * tr + xrow) * C_HW + 4 * tc) * C_LD * 4, by = ((2 * tr + yrow) * C_HW + 4 * tc) * C_LD * 4;
+    const int ax0 = bx + 16 * qx, ax1 = bx + 16 * (qx ^ 4), ay0 = by + 16 * qy, ay1 = by + 16 * (qy ^ 4);
+
+    const int k16_total = cin / 16;
+    const float* ub = J.wgt + ((size_t(n32) * k16_total) * 48 + u * 12) * 256;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ub), 0, k16_total * 48 * 1024, 0x00020000);
+    const int wlane = lane * 16;
+    auto wfrag = [&](int step, int s) -> f32x4 {                            // s = 2 * frequency + cout block
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wlane, (step * 48 + s) * 1024, 0));
+    };
+    const float* inb = J.in + size_t(b) * h * w * cin;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, h * w * cin * 4, 0x00020000);
+    unsigned goff[C_ITEMS_PT];
+    int loff[C_ITEMS_PT];
+#pragma unroll
+    for (int it = 0; it < C_ITEMS_PT; ++it) {
+        const int item = it * 256 + tid;
+        const int pix = item >> 3, q = item & 7;
+        const int hy = pix / C_HW, hx = pix - hy * C_HW;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = item < C_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
+        goff[it] = ok ? unsigned((gy * w + gx) * cin + q * 4) * 4u : 0x80000000u;
+        loff[it] = pix * C_LD + ((q ^ (((hy >> 1) & 3) << 1)) << 2);
+    }
+    const bool last_ok = (C_ITEMS_PT - 1) * 256 + tid < C_ITEMS;
+    auto item_load = [&](int it, int ch) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, goff[it], ch * (C_KC * 4), 0));
+    };
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        if (it < C_ITEMS_PT - 1 || last_ok) *reinterpret_cast<f32x4*>(smem + buf * C_ABUF + loff[it]) = v;
+    };
+
+    f32x4 acc[6][2];
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[f][nb] = zero4;
+
+    const int nchunks = cin / C_KC;
+    f32x4 V[6], ring[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) { ring[s] = wfrag(0, s); __builtin_amdgcn_sched_barrier(0); }
+    {
+        const int c1 = nchunks > 1 ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < C_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+#pragma unroll
+        for (int it = 0; it < 3; ++it) item_store(it, 1, item_load(it, c1));
+    }
+    __syncthreads();
+#define C_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
+#define C_PIN(v) asm volatile("" : "+v"(v))
+    {
+        f32x4 t[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const f32x4 x = C_LDS4(ax0 + c * (C_LD * 4)), y = C_LDS4(ay0 + c * (C_LD * 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c][e] = fmaf(sgn, y[e], x[e]);
+        }
+        const f32x4 s1 = t[4] - 4.f * t[2], s2 = t[3] - 4.f * t[1], s3 = t[4] - t[2], s4 = t[3] - t[1];
+        V[0] = 4.f * t[0] + (t[4] - 5.f * t[2]);
+        V[1] = s1 + s2; V[2] = s1 - s2;
+        V[3] = s3 + 2.f * s4; V[4] = s3 - 2.f * s4;
+        V[5] = 4.f * t[1] + (t[5] - 5.f * t[3]);
+    }
+
+    // One k-step (16 channels) = 12 groups {four MFMAs on one A operand + a piece of the other work}, pinned.
+#define C_GROUP(F, NB, WORK)                                                                                          \
+    {                                                                                                                 \
+        constexpr int s_ = 2 * (F) + (NB);                                                                            \
+        const f32x4 bq = ring[s_ % 6];                                                                                \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][0], bq[0], acc[F][NB], 0, 0, 0);                       \
+        ring[s_ % 6] = s_ + 6 < 12 ? wfrag(step, s_ + 6) : wfrag(nstep, s_ - 6);                                      \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][1], bq[1], acc[F][NB], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        WORK                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][2], bq[2], acc[F][NB], 0, 0, 0);                       \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][3], bq[3], acc[F][NB], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+#define C_COMB(T, X, Y) { _Pragma("unroll") for (int e = 0; e < 4; ++e) T[e] = fmaf(sgn, Y[e], X[e]); C_PIN(T); }
+    //   KK = 0: the next operands are the second 16 channels of the current buffer; halo items 3..5 of chunk c+1 go to the
+    //           other buffer, then the chunk's barrier.   KK = 1: the next operands are the first 16 channels of the other
+    //           buffer; halo items 0..2 of chunk c+2 go to the current buffer (whose last reads were before the barrier).
+#define C_STEP(KK)                                                                                                    \
+    {                                                                                                                 \
+        const int step = chunk * 2 + (KK);                                                                            \
+        const int nstep = step + 1 < k16_total ? step + 1 : step;                                                     \
+        const int rx = ((KK) == 0 ? ax1 + cur : ax0 + (cur ^ tog)), ry = ((KK) == 0 ? ay1 + cur : ay0 + (cur ^ tog)); \
+        constexpr int it0 = (KK) == 0 ? 3 : 0;                                                                        \
+        const int lch = (KK) == 0 ? cn1 : cn2;                                                                        \
+        f32x4 pf[3], cx0, cy0, cx1, cy1, t0, t1, t2, t3, t4, t5, s1, s2, s3, s4, v5n;                                 \
+        C_GROUP(0, 0, cx0 = C_LDS4(rx); cy0 = C_LDS4(ry); cx1 = C_LDS4(rx + C_LD * 4); cy1 = C_LDS4(ry + C_LD * 4);)  \
+        C_GROUP(0, 1, C_COMB(t0, cx0, cy0) C_COMB(t1, cx1, cy1)                                                       \
+                      pf[0] = item_load(it0, lch); pf[1] = item_load(it0 + 1, lch); pf[2] = item_load(it0 + 2, lch);) \
+        C_GROUP(1, 0, cx0 = C_LDS4(rx + 2 * C_LD * 4); cy0 = C_LDS4(ry + 2 * C_LD * 4); cx1 = C_LDS4(rx + 3 * C_LD * 4); cy1 = C_LDS4(ry + 3 * C_LD * 4);) \
+        C_GROUP(1, 1, C_COMB(t2, cx0, cy0) C_COMB(t3, cx1, cy1))                                                      \
+        C_GROUP(2, 0, cx0 = C_LDS4(rx + 4 * C_LD * 4); cy0 = C_LDS4(ry + 4 * C_LD * 4); cx1 = C_LDS4(rx + 5 * C_LD * 4); cy1 = C_LDS4(ry + 5 * C_LD * 4);) \
+        C_GROUP(2, 1, C_COMB(t4, cx0, cy0) C_COMB(t5, cx1, cy1))                                                      \
+        /* from here on V[0..2] are free: their MFMAs have been issued */                                             \
+        C_GROUP(3, 0, s1 = t4 - 4.f * t2; C_PIN(s1); s2 = t3 - 4.f * t1; C_PIN(s2); V[1] = s1 + s2; C_PIN(V[1]); V[2] = s1 - s2; C_PIN(V[2]);) \
+        C_GROUP(3, 1, V[0] = 4.f * t0 + (t4 - 5.f * t2); C_PIN(V[0]); s3 = t4 - t2; C_PIN(s3); s4 = t3 - t1; C_PIN(s4);) \
+        C_GROUP(4, 0, V[3] = s3 + 2.f * s4; C_PIN(V[3]);)                                                             \
+        C_GROUP(4, 1, v5n = 4.f * t1 + (t5 - 5.f * t3); C_PIN(v5n);)                                                  \
+        C_GROUP(5, 0, V[4] = s3 - 2.f * s4; C_PIN(V[4]);)                                                             \
+        C_GROUP(5, 1, ;)                                                                                              \
+        V[5] = v5n;                                                                                                   \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) item_store(it0 + t, (KK) == 0 ? (chunk + 1) & 1 : chunk & 1, pf[t]); \
+        if ((KK) == 0) __syncthreads();                                                                               \
+    }
+
+    int cur = 0;                                  // byte offset of the buffer that holds the current chunk
+    const int tog = C_ABUF * 4;
+    __builtin_amdgcn_s_setprio(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int cn1 = chunk + 1 < nchunks ? chunk + 1 : nchunks - 1;
+        const int cn2 = chunk + 2 < nchunks ? chunk + 2 : nchunks - 1;
+        C_STEP(0)
+        C_STEP(1)
+        cur ^= tog;
+    }
+#undef C_STEP
+#undef C_GROUP
+#undef C_COMB
+#undef C_LDS4
+#undef C_PIN
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    __syncthreads();                                     // all patch reads and halo stores of the last step are done
+
+    // ---- epilogue: as k_conv_wino24; lane (g, t16) holds output channel nb*16 + t16 of the tiles (tile row g, tile column r)
+    const float* __restrict__ p_bias = J.bias;
+    const float* __restrict__ p_bbias = J.bbias;
+    const float* __restrict__ p_rcol = J.rcol;
+    const float* __restrict__ p_rrow = J.rrow;
+    const float* __restrict__ p_res = J.res;
+    float* __restrict__ p_out = J.out;
+    double* p_gn = J.gn_part;
+    {
+        float* img = smem + u * C_IMG + t16;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r], m4 = acc[4][nb][r], m5 = acc[5][nb][r];
+                const float p = m1 + m2, q = m1 - m2, rr = m3 + m4, s = m3 - m4;
+                const int pp = (g * C_TW + 4 * r) * 32 + nb * 16;
+                img[pp] = (m0 + p) + rr; img[pp + 32] = fmaf(2.f, s, q); img[pp + 64] = fmaf(4.f, rr, p); img[pp + 96] = fmaf(8.f, s, q) + m5;
+            }
+    }
+    const int quad = tid & 7, xl = (tid >> 3) & 15, rsel = tid >> 7;
+    const int co4 = n32 * 32 + quad * 4;
+    const bool c_ok = co4 < cout;
+    const int coc = c_ok ? co4 : 0;
+    const int x = tx0 + xl;
+    const bool x_ok = x < w && c_ok;
+    const int xc = x < w ? x : 0;
+    f32x4 base4 = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+    if (p_bbias) base4 += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+    f32x4 tcol[4], trow[4], tres[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
+    if (p_rcol) {
+        if (ty0 > 0 && ty0 + C_TH < h) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + 0) * cout + coc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tcol[k] = v0;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc);
+            }
+        }
+    }
+    if (p_rrow) {
+        const int vx = x_edge_variant(xc, w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ty0 + rsel * 4 + k;
+            trow[k] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
+        }
+    }
+    if (p_res) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = ty0 + rsel * 4 + k;
+            tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+        }
+    }
+    __syncthreads();                                     // the share images are complete
+    f32x4 gs4 = zero4, gss4 = zero4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int yl = rsel * 4 + k, y = ty0 + yl;
+        const float* sp = smem + (yl & 1) * C_IMG + ((yl >> 1) * C_TW + xl) * 32 + quad * 4;
+        const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + C_IMG),
+                    kc = *reinterpret_cast<const f32x4*>(sp + 2 * C_IMG);
+        const f32x4 sum3 = (yl & 1) ? (ka - kb) - kc : (ka + kb) + kc;
+        const f32x4 v = (sum3 + base4) + ((tcol[k] + trow[k]) + tres[k]);
+        if (x_ok && y < h) {
+            *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
+            gs4 += v; gss4 += v * v;
+        }
+    }
+    if (p_gn) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
+        const int sg = args.gn_sg;
+        const int part = tile_idx * 4 + u;
+        auto put = [&](int sub, float s, float ss) {
+            double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+            dst[0] = double(s); dst[1] = double(ss);
+        };
+        if (sg >= 4) {
+            float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
+            for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+            if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, s, ss);
+        } else if (lane < 8 && c_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                if (sg == 2) put((co4 + e) / 2, gs4[e] + gs4[e + 1], gss4[e] + gss4[e + 1]);
+                else { put(co4 + e, gs4[e], gss4[e]); put(co4 + e + 1, gs4[e + 1], gss4[e + 1]); }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host side
 void wino24_gn_parts(const Geo& g, int nparts[3]) {      // one part per wave of a tile's block
     for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + X_TW - 1) / X_TW) * ((g.h[p] + X_TH - 1) / X_TH) * 4;
@@ -352,6 +633,49 @@ size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, 
                 }
         }
     return off;
+}
+
+// the small-block kernel's image: [n32][k16][24 freq][2 x 16 couts][64 lanes = 16 * channel quad + cout][4 channels]
+size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin) {
+    const int k16t = cin / 16;
+    const size_t total = wino24_packed_floats(cout, cin);
+    const size_t off = push(stage, nullptr, total);
+    float* d = stage.data() + off;
+    std::fill(d, d + total, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int c = 0; c < cin; ++c) {
+            const float* g = W + (size_t(co) * ctot + c) * 9;
+            double t[4][3];
+            for (int u = 0; u < 4; ++u)
+                for (int k = 0; k < 3; ++k) t[u][k] = kG2[u][0] * g[0 * 3 + k] + kG2[u][1] * g[1 * 3 + k] + kG2[u][2] * g[2 * 3 + k];
+            const int nt = co >> 5, nb = (co >> 4) & 1, jn = co & 15, k16 = c >> 4, q = (c >> 2) & 3, e = c & 3;
+            for (int u = 0; u < 4; ++u)
+                for (int v = 0; v < 6; ++v) {
+                    const double uv = t[u][0] * kG4[v][0] + t[u][1] * kG4[v][1] + t[u][2] * kG4[v][2];
+                    d[((((size_t(nt) * k16t + k16) * 24 + (u * 6 + v)) * 2 + nb) * 64 + (q * 16 + jn)) * 4 + e] = float(uv);
+                }
+        }
+    return off;
+}
+
+int launch_conv_wino24s(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24s conv: bad arguments");
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        S3D_CHECK(size_t(J.h) * J.w * a.cin * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wino24s conv: a plane of one sample must stay below 2 GiB");
+        J.tiles_x = (J.w + C_TW - 1) / C_TW;
+        J.tiles_per_img = J.tiles_x * ((J.h + C_TH - 1) / C_TH);
+        J.n_tiles_n = (a.cout + 31) / 32;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
+    a.xcd_swizzle = xcd;
+    hipLaunchKernelGGL(k_conv_wino24s, dim3(blocks), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
