@@ -85,12 +85,15 @@ struct Geo {
     size_t pixels() const { return size_t(h[0]) * w[0] + size_t(h[1]) * w[1] + size_t(h[2]) * w[2]; }
 };
 
+// GroupNorm partial sums left by a producer (layout: see "GroupNorm statistics" below)
+struct GnPartials { double* p; int maxparts; int nparts[3]; int nsub; };
 // A triplane activation in the library's layout: per plane NHWC fp32 [B][h][w][C].
 struct Tri {
     float* p[3] = {nullptr, nullptr, nullptr};
     int C = 0;
     Geo g{};
     float* gn = nullptr;      // GroupNorm {mean, rstd} [B][3][32][2] of this tensor when its producer already reduced them
+    GnPartials part{nullptr, 0, {0, 0, 0}, 0};   // ... or only the partial sums (a tensor that is normalised later as part of a concat)
 };
 
 // ------------------------------------------------------------------ MFMA conv (s3d_conv.hip)
@@ -106,6 +109,7 @@ struct ConvJob {
     const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
     const float* rcol;    // [B][w][4][cout] rank-1 rollout term indexed by pixel column, variant by row; or null
     const float* res;     // [B][h][w][cout] residual or null
+    int res_up;           // direct kernels only: res is [B][h/2][w/2][cout] and is upsampled 2x bilinearly (align_corners=False) on the way in
     float* out;           // [B][h][w][cout]
     int h, w;
     int bbias_stride;
@@ -168,7 +172,6 @@ int launch_in_conv(const float* x, int B, int Cin, int H, int W, int D, const fl
 // "subgroup" is sg consecutive channels of one group.  Stage 2 (launch_gn_finalize) adds the parts in index order
 // and writes {mean, rstd} per (b, plane, group): deterministic, no float atomics.
 constexpr int kGnChunks = 256;    // parts per (b, plane) written by launch_gn_partials (128: +0.7 % per step, 512: +0.4 %)
-struct GnPartials { double* p; int maxparts; int nparts[3]; int nsub; };
 struct GnStats { float* mr; };    // [B][3][32 groups][2] = {mean, rstd}
 inline int gn_subgroup(int C) {   // largest power of two dividing C/32, at most 32
     int cg = C / 32, sg = 1;
@@ -177,6 +180,13 @@ inline int gn_subgroup(int C) {   // largest power of two dividing C/32, at most
 }
 int launch_gn_partials(const Tri& x, int B, GnPartials out, hipStream_t st);   // out: maxparts=kGnChunks, nsub=32
 int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnStats out, hipStream_t st);
+// GroupNorm statistics of the VIRTUAL tensor [bilinear2x(u) | sk] (TriplaneUpsample2x + concat, unet_triplane.py:106-124,
+// 501-503) without materialising it: launch_gn_partials_up reduces the upsampled half per subgroup of `sg` channels
+// (out: nparts from gn_up_parts, nsub = u.C / sg), the skip half brings the partials its producing convolution left
+// (same subgroup size), and launch_gn_finalize_cat adds both in sub / part order.
+void gn_up_parts(const Geo& out_g, int nparts[3]);             // parts per plane launch_gn_partials_up writes (8x8 output tiles)
+int launch_gn_partials_up(const Tri& u, int B, int sg, GnPartials out, hipStream_t st);
+int launch_gn_finalize_cat(const GnPartials& pu, const GnPartials& ps, const Geo& g, int C, int B, GnStats out, hipStream_t st);
 // how many parts per plane a convolution epilogue writes for a given geometry (must match s3d_conv.hip's tiling)
 void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24 = 0);
 // Winograd F(2x2,3x3) path for the 3x3 convolutions (s3d_wino.hip); S3D_WINO=0 selects the direct kernel
@@ -212,6 +222,9 @@ struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a ti
 // means of a raw input.
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                   hipStream_t st);
+// the same on the virtual concat [bilinear2x(u) | sk] (y.C = u.C + sk.C, y.g = sk.g = 2 * u.g)
+int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
+                      hipStream_t st);
 // finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
 struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);

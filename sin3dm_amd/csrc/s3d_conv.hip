@@ -244,11 +244,31 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                     addv[mt][r] += ok[mt][r] ? t : 0.f;
                 }
         }
-        if (p_res) {
+        if (p_res && !J.res_up) {
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) addv[mt][r] += p_res[oidx[mt][r]];      // index 0 when !ok: finite, unused
+        }
+        if (p_res && J.res_up) {                  // residual = exact-2x bilinear upsample of a half-resolution tensor (F.interpolate arithmetic)
+            const int hi = h >> 1, wi = w >> 1;
+            const float* rb = p_res + size_t(b) * hi * wi * cout + coc;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int y = min(ty0 + p / TW, h - 1), x = min(tx0 + p % TW, w - 1);
+                    float fy = 0.5f * (float(y) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+                    float fx = 0.5f * (float(x) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+                    int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+                    int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+                    const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+                    const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+                    const float v00 = rb[(size_t(y0) * wi + x0) * cout], v01 = rb[(size_t(y0) * wi + x1) * cout];
+                    const float v10 = rb[(size_t(y1) * wi + x0) * cout], v11 = rb[(size_t(y1) * wi + x1) * cout];
+                    addv[mt][r] += ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+                }
         }
         float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
 #pragma unroll
@@ -303,7 +323,19 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
             if (J.bbias) v += J.bbias[size_t(b) * J.bbias_stride + co];
             if (J.rcol) v += J.rcol[((size_t(b) * J.w + x) * 4 + edge_variant(y, J.h)) * args.cout + co];
             if (J.rrow) v += J.rrow[((size_t(b) * J.h + y) * 4 + edge_variant(x, J.w)) * args.cout + co];
-            if (J.res) v += J.res[i];
+            if (J.res && !J.res_up) v += J.res[i];
+            if (J.res && J.res_up) {
+                const int hi = J.h / 2, wi = J.w / 2;
+                float fy = 0.5f * (float(y) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+                float fx = 0.5f * (float(x) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+                int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+                int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+                const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+                const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+                const float* rb = J.res + size_t(b) * hi * wi * args.cout + co;
+                v += ly0 * (lx0 * rb[(size_t(y0) * wi + x0) * args.cout] + lx1 * rb[(size_t(y0) * wi + x1) * args.cout]) +
+                     ly1 * (lx0 * rb[(size_t(y1) * wi + x0) * args.cout] + lx1 * rb[(size_t(y1) * wi + x1) * args.cout]);
+            }
             if (args.relu) v = fmaxf(v, 0.f);
             J.out[i] = v;
         }

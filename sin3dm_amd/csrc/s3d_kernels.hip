@@ -307,6 +307,164 @@ int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnSta
     return 0;
 }
 
+// exact-2x bilinear sample (align_corners=False) of a low-resolution NHWC plane at output pixel (yo, xo), channel quad q:
+// the arithmetic of k_upcat / F.interpolate (src = 0.5 * (dst + 0.5) - 0.5 clamped at 0, neighbour clamped to the edge)
+__device__ __forceinline__ float4 up2x_sample(const float4* __restrict__ src, int hi, int wi, int cuq, int yo, int xo) {
+    float fy = 0.5f * (float(yo) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+    float fx = 0.5f * (float(xo) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+    int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+    const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+    const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+    const float4 v00 = src[(size_t(y0) * wi + x0) * cuq], v01 = src[(size_t(y0) * wi + x1) * cuq];
+    const float4 v10 = src[(size_t(y1) * wi + x0) * cuq], v11 = src[(size_t(y1) * wi + x1) * cuq];
+    float4 o;
+    o.x = ly0 * (lx0 * v00.x + lx1 * v01.x) + ly1 * (lx0 * v10.x + lx1 * v11.x);
+    o.y = ly0 * (lx0 * v00.y + lx1 * v01.y) + ly1 * (lx0 * v10.y + lx1 * v11.y);
+    o.z = ly0 * (lx0 * v00.z + lx1 * v01.z) + ly1 * (lx0 * v10.z + lx1 * v11.z);
+    o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
+    return o;
+}
+
+// Eight consecutive output rows i0..i0+7 (i0 a multiple of 8) of output column j: the six low-resolution rows they touch
+// are interpolated horizontally once (12 loads instead of 32) and combined with the per-row weights of the exact formula;
+// the values equal up2x_sample's bit for bit (same products, same order).
+struct Up8Rows { int rk[6]; float ly0[8], ly1[8]; };
+__device__ __forceinline__ Up8Rows up8_rows(int i0, int hi) {
+    Up8Rows R;
+    const int base = (i0 >> 1) - 1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const int r = base + k; R.rk[k] = r < 0 ? 0 : (r > hi - 1 ? hi - 1 : r); }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        float fy = 0.5f * (float(i0 + r) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+        R.ly1[r] = fy - float(y0); R.ly0[r] = 1.f - R.ly1[r];
+    }
+    return R;
+}
+__device__ __forceinline__ void up8_column(const float4* __restrict__ src, int wi, int cuq, const Up8Rows& R, int j, float4 out[8]) {
+    float fx = 0.5f * (float(j) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+    const int x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+    const float lx1 = fx - float(x0), lx0 = 1.f - lx1;
+    float4 hl[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float4 a = src[(size_t(R.rk[k]) * wi + x0) * cuq], b = src[(size_t(R.rk[k]) * wi + x1) * cuq];
+        hl[k].x = lx0 * a.x + lx1 * b.x; hl[k].y = lx0 * a.y + lx1 * b.y; hl[k].z = lx0 * a.z + lx1 * b.z; hl[k].w = lx0 * a.w + lx1 * b.w;
+    }
+    // output row r uses low-resolution rows (base + ka, base + ka + 1): ka = (r + 1) >> 1
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float4 p = hl[(r + 1) >> 1], q = hl[((r + 1) >> 1) + 1];
+        out[r].x = R.ly0[r] * p.x + R.ly1[r] * q.x; out[r].y = R.ly0[r] * p.y + R.ly1[r] * q.y;
+        out[r].z = R.ly0[r] * p.z + R.ly1[r] * q.z; out[r].w = R.ly0[r] * p.w + R.ly1[r] * q.w;
+    }
+}
+
+// GroupNorm partials of bilinear2x(u) per subgroup of sg channels; one part per 8x8 tile of the OUTPUT.
+struct GnPartUpArgs {
+    const float* u[3];
+    int hi[3], wi[3];
+    int C, cq, pl, sg, nsub, maxparts;
+    double* part;   // [B][3][nsub][maxparts][2]
+};
+__global__ void k_gn_partials_up(GnPartUpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sm = reinterpret_cast<double*>(smem_raw);        // [pl][C][2]
+    const int p = blockIdx.y, b = blockIdx.z;
+    const int hi = a.hi[p], wi = a.wi[p], h = 2 * hi, w = 2 * wi;
+    const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
+    if (int(blockIdx.x) >= ntc * ntr) return;
+    const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+    const int i0 = tr * kActRows, j0 = tc * kActCols, i1 = min(h, i0 + kActRows), j1 = min(w, j0 + kActCols);
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float4* src = reinterpret_cast<const float4*>(a.u[p] + size_t(b) * hi * wi * a.C) + q;
+    const Up8Rows R = up8_rows(i0, hi);
+    for (int j = j0 + l; j < j1; j += a.pl) {
+        float4 v[8];
+        up8_column(src, wi, a.cq, R, j, v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) if (i0 + r < i1) gn_acc(s, ss, v[r]);
+    }
+    for (int k = 0; k < 4; ++k) {
+        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 0] = s[k];
+        sm[(size_t(l) * a.C + 4 * q + k) * 2 + 1] = ss[k];
+    }
+    __syncthreads();
+    for (int sub = threadIdx.x; sub < a.nsub; sub += blockDim.x) {
+        double S = 0, SS = 0;
+        for (int ll = 0; ll < a.pl; ++ll)
+            for (int c = sub * a.sg; c < (sub + 1) * a.sg; ++c) { S += sm[(size_t(ll) * a.C + c) * 2]; SS += sm[(size_t(ll) * a.C + c) * 2 + 1]; }
+        double* o = a.part + (((size_t(b) * 3 + p) * a.nsub + sub) * a.maxparts + blockIdx.x) * 2;
+        o[0] = S; o[1] = SS;
+    }
+}
+void gn_up_parts(const Geo& out_g, int nparts[3]) {
+    for (int p = 0; p < 3; ++p) nparts[p] = cdiv(out_g.h[p], kActRows) * cdiv(out_g.w[p], kActCols);
+}
+int launch_gn_partials_up(const Tri& u, int B, int sg, GnPartials out, hipStream_t st) {
+    GnPartUpArgs a;
+    int maxtiles = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.u[p] = u.p[p]; a.hi[p] = u.g.h[p]; a.wi[p] = u.g.w[p];
+        maxtiles = std::max(maxtiles, cdiv(2 * u.g.h[p], kActRows) * cdiv(2 * u.g.w[p], kActCols));
+    }
+    a.C = u.C; thread_shape(u.C, a.cq, a.pl); a.sg = sg; a.nsub = u.C / sg; a.part = out.p; a.maxparts = out.maxparts;
+    S3D_CHECK(u.C % sg == 0 && a.cq <= 1024 && out.nsub == a.nsub && out.maxparts >= maxtiles, S3D_ERR_INVALID, "gn_partials_up: layout");
+    if (!maxtiles || !B) return 0;
+    hipLaunchKernelGGL(k_gn_partials_up, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), size_t(a.pl) * a.C * 2 * sizeof(double), st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+// {mean, rstd} per (b, plane, group) of the concat [up | skip]: the group's subgroups come first from the up partials,
+// then from the skip partials; parts added in index order, in double.
+struct GnFinCatArgs {
+    const double* pu; const double* ps; float* mr;
+    int maxparts_u, maxparts_s, nparts_u[3], nparts_s[3], nsub_u, nsub_s, subs_per_group;
+    double count[3];
+};
+__global__ void k_gn_finalize_cat(GnFinCatArgs a) {
+    __shared__ double sm[128][2];
+    const int g = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    double S = 0, SS = 0;
+    for (int k = 0; k < a.subs_per_group; ++k) {
+        const int sub = g * a.subs_per_group + k;
+        const bool up = sub < a.nsub_u;
+        const double* row = up ? a.pu + (((size_t(b) * 3 + p) * a.nsub_u + sub) * a.maxparts_u) * 2
+                               : a.ps + (((size_t(b) * 3 + p) * a.nsub_s + (sub - a.nsub_u)) * a.maxparts_s) * 2;
+        const int n = up ? a.nparts_u[p] : a.nparts_s[p];
+        for (int part = tid; part < n; part += 128) { S += row[2 * part]; SS += row[2 * part + 1]; }
+    }
+    sm[tid][0] = S; sm[tid][1] = SS;
+    __syncthreads();
+    for (int s = 64; s >= 1; s >>= 1) {
+        if (tid < s) { sm[tid][0] += sm[tid + s][0]; sm[tid][1] += sm[tid + s][1]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double m = sm[0][0] / a.count[p];
+        double var = sm[0][1] / a.count[p] - m * m;
+        if (var < 0) var = 0;
+        float* o = a.mr + ((size_t(b) * 3 + p) * 32 + g) * 2;
+        o[0] = float(m);
+        o[1] = float(1.0 / sqrt(var + 1e-5));
+    }
+}
+int launch_gn_finalize_cat(const GnPartials& pu, const GnPartials& ps, const Geo& g, int C, int B, GnStats out, hipStream_t st) {
+    GnFinCatArgs a;
+    a.pu = pu.p; a.ps = ps.p; a.mr = out.mr; a.maxparts_u = pu.maxparts; a.maxparts_s = ps.maxparts; a.nsub_u = pu.nsub; a.nsub_s = ps.nsub;
+    S3D_CHECK((pu.nsub + ps.nsub) % 32 == 0, S3D_ERR_INVALID, "gn_finalize_cat: nsub=%d+%d", pu.nsub, ps.nsub);
+    a.subs_per_group = (pu.nsub + ps.nsub) / 32;
+    for (int p = 0; p < 3; ++p) { a.nparts_u[p] = pu.nparts[p]; a.nparts_s[p] = ps.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
+    if (!B) return 0;
+    hipLaunchKernelGGL(k_gn_finalize_cat, dim3(32, 3, B), dim3(128), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ GN-apply (+FiLM) + SiLU (+ rollout partial means)
 // TriplaneNorm + TriplaneSiLU (src/diffusion/unet_triplane.py:63-95), with the FiLM modulation
 // h*(1+scale)+shift of TriplaneResBlock._forward (:285-297) applied between them, and the axis sums the
@@ -417,6 +575,129 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y,
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
     hipLaunchKernelGGL(k_gn_act, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// k_gn_act on the virtual tensor [bilinear2x(u) | sk]: the concat of TriplaneUNetModelSmall.forward (:494-503) is never
+// written; its upsampled half is sampled from the low-resolution tensor on the way in.
+struct GnActCatArgs {
+    GnActArgs base;                  // x unused; C / cq / pl describe the concat
+    const float* u[3]; const float* sk[3];
+    int cuq, csq;
+};
+__global__ void k_gn_act_cat(GnActCatArgs ca) {
+    const GnActArgs& a = ca.base;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* sm = reinterpret_cast<float*>(smem_raw);
+    const int p = blockIdx.y, b = blockIdx.z;
+    const int h = a.h[p], w = a.w[p];
+    const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
+    if (int(blockIdx.x) >= ntc * ntr) return;
+    const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
+    if (threadIdx.x < 32) {
+        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
+        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
+    }
+    __syncthreads();
+    // threads of the upsampled half first (cuq quads x pl pixel lanes), then the skip half: with cuq a multiple of 64 every
+    // wave runs one of the two load paths only
+    const int nup = ca.cuq * a.pl;
+    const int q = int(threadIdx.x) < nup ? int(threadIdx.x) % ca.cuq : ca.cuq + (int(threadIdx.x) - nup) % ca.csq;
+    const int l = int(threadIdx.x) < nup ? int(threadIdx.x) / ca.cuq : (int(threadIdx.x) - nup) / ca.csq;
+    const int cg = a.C / 32;
+    float A[4], Bc[4], sc[4], sh[4];
+    const bool film = a.film != nullptr;
+    for (int k = 0; k < 4; ++k) {
+        const int c = 4 * q + k, g = c / cg;
+        const float scale = sm[32 + g] * a.gamma[p][c];
+        A[k] = scale;
+        Bc[k] = a.beta[p][c] - scale * sm[g];
+        sc[k] = film ? 1.0f + a.film[size_t(b) * a.film_stride + c] : 1.0f;
+        sh[k] = film ? a.film[size_t(b) * a.film_stride + a.C + c] : 0.0f;
+    }
+    __syncthreads();
+    const int i0 = tr * kActRows, j0 = tc * kActCols;
+    const int i1 = min(h, i0 + kActRows), j1 = min(w, j0 + kActCols);
+    const bool is_up = q < ca.cuq;
+    const int hi = h / 2, wi = w / 2;
+    const float4* us = reinterpret_cast<const float4*>(ca.u[p] + size_t(b) * hi * wi * ca.cuq * 4) + q;
+    const float4* ss = reinterpret_cast<const float4*>(ca.sk[p] + size_t(b) * h * w * ca.csq * 4) + (q - ca.cuq);
+    float4* ys = reinterpret_cast<float4*>(a.y[p] + size_t(b) * h * w * a.C) + q;
+    float4 rowacc[kActRows];
+#pragma unroll
+    for (int r = 0; r < kActRows; ++r) rowacc[r] = make_float4(0, 0, 0, 0);
+    static_assert(kActRows == 8, "up8_column produces eight rows");
+    const Up8Rows R = up8_rows(i0, hi);
+    for (int j = j0 + l; j < j1; j += a.pl) {
+        float4 colacc = make_float4(0, 0, 0, 0);
+        float4 xin[kActRows];
+        if (is_up) up8_column(us, wi, ca.cuq, R, j, xin);
+        else {
+#pragma unroll
+            for (int r = 0; r < kActRows; ++r) xin[r] = ss[(size_t(min(i0 + r, i1 - 1)) * w + j) * ca.csq];
+        }
+#pragma unroll
+        for (int r = 0; r < kActRows; ++r) {
+            const int i = i0 + r;
+            if (i < i1) {
+                const size_t off = (size_t(i) * w + j) * a.cq;
+                const float4 v = xin[r];
+                float4 o;
+                o.x = fmaf(v.x, A[0], Bc[0]); o.y = fmaf(v.y, A[1], Bc[1]);
+                o.z = fmaf(v.z, A[2], Bc[2]); o.w = fmaf(v.w, A[3], Bc[3]);
+                if (film) {
+                    o.x = o.x * sc[0] + sh[0]; o.y = o.y * sc[1] + sh[1];
+                    o.z = o.z * sc[2] + sh[2]; o.w = o.w * sc[3] + sh[3];
+                }
+                o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
+                ys[off] = o;
+                colacc.x += o.x; colacc.y += o.y; colacc.z += o.z; colacc.w += o.w;
+                rowacc[r].x += o.x; rowacc[r].y += o.y; rowacc[r].z += o.z; rowacc[r].w += o.w;
+            }
+        }
+        if (a.with_means)
+            reinterpret_cast<float4*>(a.colpart[p] + ((size_t(b) * ntr + tr) * w + j) * a.C)[q] = colacc;
+    }
+    if (!a.with_means) return;
+    float4* smr = reinterpret_cast<float4*>(sm);
+#pragma unroll
+    for (int r = 0; r < kActRows; ++r) smr[(size_t(l) * kActRows + r) * a.cq + q] = rowacc[r];
+    __syncthreads();
+    const int nthr = a.cq * a.pl;
+    for (int it = threadIdx.x; it < kActRows * a.cq; it += nthr) {
+        const int r = it / a.cq, qq = it % a.cq;
+        const int i = i0 + r;
+        if (i >= i1) continue;
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int ll = 0; ll < a.pl; ++ll) {
+            const float4 v = smr[(size_t(ll) * kActRows + r) * a.cq + qq];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(a.rowpart[p] + ((size_t(b) * ntc + tc) * h + i) * a.C)[qq] = s;
+    }
+}
+int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
+                      hipStream_t st) {
+    GnActCatArgs ca;
+    GnActArgs& a = ca.base;
+    int maxtiles = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = nullptr; a.y[p] = y.p[p]; a.h[p] = y.g.h[p]; a.w[p] = y.g.w[p];
+        ca.u[p] = u.p[p]; ca.sk[p] = sk.p[p];
+        a.gamma[p] = aa.gamma[p]; a.beta[p] = aa.beta[p];
+        a.rowpart[p] = mp ? mp->rowpart[p] : nullptr;
+        a.colpart[p] = mp ? mp->colpart[p] : nullptr;
+        maxtiles = std::max(maxtiles, cdiv(a.h[p], kActRows) * cdiv(a.w[p], kActCols));
+        S3D_CHECK(y.g.h[p] == 2 * u.g.h[p] && y.g.w[p] == 2 * u.g.w[p] && sk.g.h[p] == y.g.h[p] && sk.g.w[p] == y.g.w[p], S3D_ERR_INVALID, "gn_act_cat: geometry");
+    }
+    ca.cuq = u.C / 4; ca.csq = sk.C / 4;
+    a.mr = stats.mr; a.film = aa.film; a.film_stride = aa.film_stride;
+    a.C = y.C; thread_shape(y.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
+    S3D_CHECK(y.C == u.C + sk.C && y.C % 32 == 0 && a.cq <= 1024 && stats.mr, S3D_ERR_INVALID, "gn_act_cat: C=%d unsupported", y.C);
+    if (!maxtiles || !B) return 0;
+    size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
+    hipLaunchKernelGGL(k_gn_act_cat, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, ca);
     S3D_HIP(hipGetLastError());
     return 0;
 }

@@ -23,6 +23,10 @@ struct ResBlockW {
     int C, Cout;
     NormW n1, n2;
     ConvW c1, c2, skip;
+    // output blocks that take [upsampled | skip]: the 1x1 skip_connection split by input half (inference): since a 1x1
+    // convolution commutes with bilinear upsampling, skip(cat[up(h), s]) = up(W_a h) + W_b s + bias
+    ConvW skip_a, skip_b;
+    int c_up = 0;                      // channels of the upsampled half (0: the block's input is not a concat)
     bool has_skip;
     int film_off;                      // offset of this block's emb_layers output in the concatenated FiLM row
 };
@@ -58,7 +62,7 @@ struct ConvWT {
     size_t rcol_T[3] = {0, 0, 0};
 };
 struct ResBlockWT { ConvWT c1, c2, skip; };
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD };
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD };
 struct PackDesc {                     // one device-side repacking job: flat reference-layout parameter -> packed image
     int kind, cout, ctot, cin, slot, taps, col_varying, to_tbuf;
     long long src, dst, n;
@@ -210,6 +214,38 @@ struct Fwd {
 
     // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and
     // the rank-1 tables its epilogue needs.  Returns activated tensor; fills rrow/rcol table pointers.
+    // workspace of a rollout convolution's rank-1 terms for the activated tensor y: axis-sum partials, mean vectors, tables
+    int roll_buffers(const Tri& y, const ConvW& cw, bool roll, MeanPartials& mp, MeanVecs& mv, const float* rrow[3], const float* rcol[3]) {
+        for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
+        if (!roll) return 0;
+        for (int p = 0; p < 3; ++p) {
+            const int h = y.g.h[p], w = y.g.w[p];
+            const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
+            mp.rowpart[p] = ar().alloc<float>(size_t(B) * ntc * h * y.C);
+            mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * y.C);
+            mv.rowmean[p] = ar().alloc<float>(size_t(B) * h * y.C);
+            mv.colmean[p] = ar().alloc<float>(size_t(B) * w * y.C);
+            rrow[p] = ar().alloc<float>(size_t(B) * h * 4 * cw.cout);
+            rcol[p] = ar().alloc<float>(size_t(B) * w * 4 * cw.cout);
+        }
+        return 0;
+    }
+    // th.mean over the axes + the six 1-D convolutions of the mean vectors (one launch each)
+    int rank1_tables(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
+        S3D_TRY(launch_means_finalize(y.g, y.C, B, mp, mv, st));
+        ConvArgs ca; memset(&ca, 0, sizeof ca);
+        ca.B = B; ca.cin = y.C; ca.cout = 4 * cw.cout; ca.njobs = 6;
+        // row-varying / column-varying vector of each plane
+        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
+        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
+        for (int p = 0; p < 3; ++p) {
+            ConvJob& jr = ca.job[2 * p];
+            jr.in = rowvec[p]; jr.wgt = m->dev(cw.rrow[p]); jr.out = const_cast<float*>(rrow[p]); jr.h = 1; jr.w = y.g.h[p];
+            ConvJob& jc = ca.job[2 * p + 1];
+            jc.in = colvec[p]; jc.wgt = m->dev(cw.rcol[p]); jc.out = const_cast<float*>(rcol[p]); jc.h = 1; jc.w = y.g.w[p];
+        }
+        return m->timed_conv(2, CONV_1x3_VEC, ca, st);
+    }
     int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
                  const float* rcol[3], NormTape* nt = nullptr) {
         const bool measuring = ar().measuring;
@@ -222,48 +258,23 @@ struct Fwd {
         aa.film = film_ptr; aa.film_stride = m->film_total;
         const bool roll = cw && cw->rollout;
         MeanPartials mp; MeanVecs mv;
-        float* tab_row[3]; float* tab_col[3];
-        for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
-        if (roll) {
-            for (int p = 0; p < 3; ++p) {
-                const int h = x.g.h[p], w = x.g.w[p];
-                const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
-                mp.rowpart[p] = ar().alloc<float>(size_t(B) * ntc * h * x.C);
-                mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * x.C);
-                mv.rowmean[p] = ar().alloc<float>(size_t(B) * h * x.C);
-                mv.colmean[p] = ar().alloc<float>(size_t(B) * w * x.C);
-                tab_row[p] = ar().alloc<float>(size_t(B) * h * 4 * cw->cout);
-                tab_col[p] = ar().alloc<float>(size_t(B) * w * 4 * cw->cout);
-                rrow[p] = tab_row[p]; rcol[p] = tab_col[p];
-            }
-        }
+        if (roll) S3D_TRY(roll_buffers(y, *cw, true, mp, mv, rrow, rcol));
+        else for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
         if (nt && roll) nt->mv = mv;
         if (measuring) return 0;
         S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st));
         if (!roll) return 0;
-        S3D_TRY(launch_means_finalize(x.g, x.C, B, mp, mv, st));
-        // rank-1 rollout terms: six 1-D convolutions of the mean vectors, all in one launch
-        ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = B; ca.cin = x.C; ca.cout = 4 * cw->cout; ca.njobs = 6;
-        // row-varying / column-varying vector of each plane
-        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
-        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
-        for (int p = 0; p < 3; ++p) {
-            ConvJob& jr = ca.job[2 * p];
-            jr.in = rowvec[p]; jr.wgt = m->dev(cw->rrow[p]); jr.out = tab_row[p]; jr.h = 1; jr.w = x.g.h[p];
-            ConvJob& jc = ca.job[2 * p + 1];
-            jc.in = colvec[p]; jc.wgt = m->dev(cw->rcol[p]); jc.out = tab_col[p]; jc.h = 1; jc.w = x.g.w[p];
-        }
-        S3D_TRY(m->timed_conv(2, CONV_1x3_VEC, ca, st));
-        return 0;
+        return rank1_tables(y, *cw, mp, mv, rrow, rcol);
     }
 
     // want_stats: also reduce the GroupNorm statistics of the output in the epilogue (3x3 MFMA path only)
+    // want_stats: 1 = reduce the GroupNorm statistics of the output (partials in the epilogue + finalize), 2 = leave only
+    // the partials with the tensor (it is normalised later as the skip half of a concat)
     int conv(const Tri& y, const ConvW& cw, const float* bbias, const float* const rrow[3], const float* const rcol[3],
-             const Tri* res, Tri& out, bool want_stats = false, hipStream_t on = nullptr) {
+             const Tri* res, Tri& out, int want_stats = 0, hipStream_t on = nullptr, bool no_bias = false, bool res_up = false) {
         hipStream_t st = on ? on : this->st;
         out = alloc_tri(cw.cout, y.g);
-        want_stats = want_stats && cw.k == 3 && !conv_use_naive();
+        if (!(cw.k == 3 && !conv_use_naive())) want_stats = 0;
         // the mixed Winograd kernel serves the inference forward; the training tier (forward_train + dgrad) stays on the
         // F(2x2) kernels, whose transposed operators the backward pass has
         const int w24 = cw.k == 3 && !tape && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout) : 0;
@@ -273,8 +284,8 @@ struct Fwd {
             part.maxparts = std::max(part.nparts[0], std::max(part.nparts[1], part.nparts[2]));
             part.nsub = cw.cout / gn_subgroup(cw.cout);
             part.p = ar().alloc<double>(size_t(B) * 3 * part.maxparts * part.nsub * 2);
-            gs.mr = ar().alloc<float>(size_t(B) * 3 * 64);
-            out.gn = gs.mr;
+            if (want_stats == 1) { gs.mr = ar().alloc<float>(size_t(B) * 3 * 64); out.gn = gs.mr; }
+            else out.part = part;
         }
         if (ar().measuring) return 0;
         ConvArgs ca; memset(&ca, 0, sizeof ca);
@@ -282,22 +293,67 @@ struct Fwd {
         if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
         for (int p = 0; p < 3; ++p) {
             ConvJob& J = ca.job[p];
-            J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = m->dev(cw.bias[p]);
+            J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = no_bias ? nullptr : m->dev(cw.bias[p]);
             J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
             J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
             J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = m->film_total;
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
-            J.res = res ? res->p[p] : nullptr; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
+            J.res = res ? res->p[p] : nullptr; J.res_up = res && res_up ? 1 : 0; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
             J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
         }
         S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
-        if (want_stats) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
+        if (want_stats == 1) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
+        return 0;
+    }
+
+    // the same block on the VIRTUAL input [bilinear2x(u) | sk] (:494-503 + :269-311), inference only: the concat is never
+    // written.  Statistics: the upsampled half by one read pass over u, the skip half from its producer's partials; the
+    // first norm samples u on the fly; the 1x1 skip_connection runs per half (W_a at low resolution, then upsampled).
+    int resblock_cat(const ResBlockW& rb, const Tri& u, const Tri& sk, Tri& out, int out_stats) {
+        const bool ssn = m->cfg.use_scale_shift_norm != 0;
+        const float* film_ptr = film ? film + rb.film_off : nullptr;
+        const bool measuring = ar().measuring;
+        const int C = u.C + sk.C, sg = gn_subgroup(C);
+        // statistics of the virtual tensor
+        GnPartials pu; GnStats stats;
+        pu.nsub = u.C / sg;
+        gn_up_parts(sk.g, pu.nparts);
+        pu.maxparts = std::max(pu.nparts[0], std::max(pu.nparts[1], pu.nparts[2]));
+        pu.p = ar().alloc<double>(size_t(B) * 3 * pu.nsub * pu.maxparts * 2);
+        stats.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+        // skip path: z = W_a u (low resolution), up(z), then W_b sk + bias + up(z)
+        Tri z, skip;
+        S3D_TRY(conv(u, rb.skip_a, nullptr, nullptr, nullptr, nullptr, z, 0, nullptr, true));
+        S3D_TRY(conv(sk, rb.skip_b, nullptr, nullptr, nullptr, &z, skip, 0, nullptr, false, true));     // + up(z) in the epilogue
+        if (!measuring) {
+            S3D_TRY(launch_gn_partials_up(u, B, sg, pu, st));
+            S3D_TRY(launch_gn_finalize_cat(pu, sk.part, sk.g, C, B, stats, st));
+        }
+        // first norm + rollout tables on the virtual tensor
+        Tri y1, h1, y2;
+        y1 = alloc_tri(C, sk.g);
+        const float *rr[3], *rc[3];
+        {
+            ActArgs aa;
+            for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(rb.n1.gamma[p]); aa.beta[p] = m->dev(rb.n1.beta[p]); }
+            aa.film = nullptr; aa.film_stride = m->film_total;
+            const bool roll = rb.c1.rollout;
+            MeanPartials mp; MeanVecs mv;
+            S3D_TRY(roll_buffers(y1, rb.c1, roll, mp, mv, rr, rc));
+            if (!measuring) {
+                S3D_TRY(launch_gn_act_cat(u, sk, B, stats, aa, y1, roll ? &mp : nullptr, st));
+                if (roll) S3D_TRY(rank1_tables(y1, rb.c1, mp, mv, rr, rc));
+            }
+        }
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 1));
+        S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, nullptr));
+        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, &skip, out, out_stats));
         return 0;
     }
 
     // TriplaneResBlock._forward (src/diffusion/unet_triplane.py:269-311)
-    int resblock(const ResBlockW& rb, const Tri& x, Tri& out, bool out_feeds_norm) {
+    int resblock(const ResBlockW& rb, const Tri& x, Tri& out, bool out_feeds_norm, int out_stats_override = -1) {
         const bool ssn = m->cfg.use_scale_shift_norm != 0;
         const float* film_ptr = film ? film + rb.film_off : nullptr;
         Tri y1, h1, y2;
@@ -316,10 +372,10 @@ struct Fwd {
         RBTape rt;
         RBTape* T = tape ? &rt : nullptr;
         S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc, T ? &T->n1 : nullptr));
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, true));   // (!ssn: h = h + emb_out, :298-303)
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 1));      // (!ssn: h = h + emb_out, :298-303)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, T ? &T->n2 : nullptr));
         if (fork) S3D_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
-        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_feeds_norm));
+        S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_stats_override >= 0 ? out_stats_override : (out_feeds_norm ? 1 : 0)));
         if (T) {
             rt.rb = &rb; rt.x = x; rt.y1 = y1; rt.h1 = h1; rt.y2 = y2;
             last_rb = rt;

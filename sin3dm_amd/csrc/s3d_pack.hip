@@ -42,6 +42,11 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             dst[i] = W[((size_t)co * ctot + c) * taps + t];
             break;
         }
+        case PK_DENSE_SLICE: {                   // 1x1: dst [co*cin + c] = W[co][slot + c] (an input-channel slice, Fwd::resblock_cat)
+            const int c = int(i % cin), co = int(i / cin);
+            dst[i] = W[(size_t)co * ctot + d.slot + c];
+            break;
+        }
         case PK_DENSE_T: {                       // dst [(t*cin + c)*cout + co]: the dgrad operator as a forward conv
             const int co = int(i % cout); long long r = i / cout;
             const int c = int(r % cin), t = int(r / cin);
@@ -218,6 +223,14 @@ int build_pack_plan(s3d_unet* m) {
         P.norm(rb.prefix + ".out_layers.0", rb.Cout, rb.n2);
         P.tconv(rb.prefix + ".out_layers.2", rb.c2, wt.c2);
         if (rb.has_skip) P.tconv(rb.prefix + ".skip_connection", rb.skip, wt.skip);
+        if (rb.has_skip && rb.c_up > 0 && rb.skip_a.dense[0]) {
+            static const char* kQ[3] = {"xy", "xz", "yz"};
+            for (int p = 0; p < 3; ++p) {
+                const size_t w = P.flat_of(rb.prefix + ".skip_connection.conv_" + kQ[p] + ".weight");
+                P.add(PK_DENSE_SLICE, w, rb.skip_a.dense[p], (long long)rb.Cout * rb.c_up, rb.Cout, rb.C, rb.c_up, 1, 0);
+                P.add(PK_DENSE_SLICE, w, rb.skip_b.dense[p], (long long)rb.Cout * (rb.C - rb.c_up), rb.Cout, rb.C, rb.C - rb.c_up, 1, rb.c_up);
+            }
+        }
     };
     for (size_t i = 0; i < m->in_blocks.size(); ++i) block(m->in_blocks[i], m->in_blocks_t[i]);
     for (size_t i = 0; i < m->out_blocks.size(); ++i) block(m->out_blocks[i], m->out_blocks_t[i]);

@@ -61,6 +61,7 @@ static int build_specs(s3d_unet* m) {
         ResBlockW rb;
         rb.prefix = "output_blocks." + std::to_string(oi) + ".0";
         rb.C = ch + ich; rb.Cout = cout; rb.has_skip = rb.C != cout; rb.film_off = film;
+        rb.c_up = ich > 0 ? ch : 0;
         film += ssn ? 2 * cout : cout;
         add_resblock(s, rb.prefix, rb.C, cout, ted, ssn, roll);
         m->out_blocks.push_back(rb);
@@ -166,6 +167,24 @@ int pack_all(s3d_unet* m) {
         pack_norm(m, rb.prefix + ".out_layers.0", rb.Cout, rb.n2);
         pack_tconv(m, rb.prefix + ".out_layers.2", rb.Cout, rb.Cout, 3, roll, rb.c2);
         if (rb.has_skip) pack_tconv(m, rb.prefix + ".skip_connection", rb.C, rb.Cout, 1, false, rb.skip);
+        if (rb.has_skip && rb.c_up > 0) {                       // the 1x1 skip split by input half (Fwd::resblock_cat)
+            const int cs = rb.C - rb.c_up;
+            rb.skip_a = ConvW(); rb.skip_b = ConvW();
+            rb.skip_a.cin = rb.c_up; rb.skip_b.cin = cs;
+            rb.skip_a.cout = rb.skip_b.cout = rb.Cout; rb.skip_a.k = rb.skip_b.k = 1;
+            for (int p = 0; p < 3; ++p) {
+                const float* W = H(m, rb.prefix + ".skip_connection.conv_" + kPlane[p] + ".weight").data();     // [cout][C]
+                rb.skip_a.dense[p] = push(m->stage, nullptr, size_t(rb.Cout) * rb.c_up);
+                rb.skip_b.dense[p] = push(m->stage, nullptr, size_t(rb.Cout) * cs);
+                float* da = m->stage.data() + rb.skip_a.dense[p];
+                float* db = m->stage.data() + rb.skip_b.dense[p];
+                for (int co = 0; co < rb.Cout; ++co) {
+                    memcpy(da + size_t(co) * rb.c_up, W + size_t(co) * rb.C, rb.c_up * sizeof(float));
+                    memcpy(db + size_t(co) * cs, W + size_t(co) * rb.C + rb.c_up, cs * sizeof(float));
+                }
+                rb.skip_a.bias[p] = rb.skip_b.bias[p] = rb.skip.bias[p];
+            }
+        }
     };
     for (auto& rb : m->in_blocks) pack_block(rb);
     for (auto& rb : m->out_blocks) pack_block(rb);
@@ -250,7 +269,9 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             h = d;
         }
         Tri o;
-        S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1));   // the deepest output goes straight into a norm
+        // the deepest output goes straight into a norm; the others become the skip half of a concat later: in the
+        // inference forward their producing convolution leaves the GroupNorm partials with them (Fwd::resblock_cat)
+        S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1, level == c.n_levels - 1 ? -1 : (tape ? 0 : 2)));
         if (tape) { f.last_rb.index = level; f.last_rb.is_out = false; tape->in_rb.push_back(f.last_rb); }
         h = o;
         hs.push_back(o);
@@ -264,8 +285,20 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             // previous block's output `h` -> TriplaneUpsample2x (:106-124) -> resize to the skip's size when it
             // differs (:494-499) -> concat [h, skip] (:501-503), written straight into the concat buffer
             Tri sk = hs.back(); hs.pop_back();
-            inp = f.alloc_tri(h.C + sk.C, sk.g);
             const Geo up = h.g.twice();
+            {
+                const ResBlockW& rb = m->out_blocks[oi];
+                static const bool vcat_on = !(getenv("S3D_VCAT") && strcmp(getenv("S3D_VCAT"), "0") == 0);
+                const int Cc = h.C + sk.C;
+                if (vcat_on && !tape && up == sk.g && sk.part.p && rb.has_skip && rb.c_up == h.C && rb.skip_a.dense[0] &&
+                    gn_subgroup(Cc) == gn_subgroup(sk.C) && sk.part.nsub == sk.C / gn_subgroup(Cc) && h.C % gn_subgroup(Cc) == 0) {
+                    Tri o;
+                    S3D_TRY(f.resblock_cat(rb, h, sk, o, oi == c.n_levels - 1 ? 1 : 0));
+                    h = o;
+                    continue;
+                }
+            }
+            inp = f.alloc_tri(h.C + sk.C, sk.g);
             if (up == sk.g) {                                       // the common case: one fused pass for all planes
                 int np[3];
                 if (upcat_gn_parts(inp.g, inp.C, np)) {

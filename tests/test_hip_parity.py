@@ -99,12 +99,14 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["24", "24big", "4", "2", "0"])
+@pytest.mark.parametrize("variant", ["24", "24big", "4", "2", "0", "novcat", "oldhead"])
 def test_unet_forward_golden_other_conv_kernels(variant):
     """Every 3x3 kernel on the golden planes (S3D_WINO=24: mixed Winograd F(2x4,3x3), 8x16-pixel blocks — the default;
     24big: its 16x16-pixel form forced onto every layer with S3D_WINO24_BIG_MIN_BLOCKS=0; 4 / 2: F(2x2) with one / two
     frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors, leaf convolutions and ragged
-    shapes included; the choice is read once per process, hence the subprocess."""
+    shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual concat of
+    Fwd::resblock_cat; oldhead: S3D_OUT_HEAD=0, the thread-per-quad output head.  The choices are read once per process,
+    hence the subprocess."""
     import os, subprocess, sys
     code = (
         "import numpy as np, torch, sys\n"
@@ -122,7 +124,9 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    e = relerr(y, g[f'{tag}.y'])\n"
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
-    env = dict(os.environ, S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0") if variant == "24big" else dict(os.environ, S3D_WINO=variant)
+    env = {"24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
+           "oldhead": dict(S3D_OUT_HEAD="0")}.get(variant, dict(S3D_WINO=variant))
+    env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
