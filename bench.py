@@ -5,8 +5,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one ancestral denoising step of one sample per GPU: UNet forward + fused sampler update +
-the step's noise draw (device generator, as the reference does on a GPU).  value = samples/s over all ranks
+A "step" is one iteration of GaussianDiffusion.p_sample_loop_progressive (the loop src/sample.py drives) for one sample per
+GPU: UNet forward + fused sampler update + the step's noise draw (device generator, as the reference does on a GPU).  value = samples/s over all ranks
 = N * K / 1000 / t, where t is the max over ranks of the barrier-bracketed wall time of exactly K steps.
 Prints ONE JSON line on rank 0.  Multi-GPU = independent samples per rank (no data-path collective).
 
@@ -212,13 +212,15 @@ def worker(args):
         diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True)
         kw = dict(H=H, W=W, D=D)
         torch.manual_seed(1000 + rank)
-        state = {"x": torch.randn(1, 12, H + D, W + D, device=dev), "k": 0}
-        all_t = torch.arange(T_STEPS, device=dev, dtype=torch.int64)[:, None].contiguous()     # as GaussianDiffusion._loop does
+        state = {"x": None}
 
-        def step():
-            i = (T_STEPS - 1 - state["k"]) % T_STEPS
-            state["x"] = diffusion.p_sample(model, state["x"], all_t[i], model_kwargs=kw)["sample"]
-            state["k"] += 1
+        def sampler():          # the public sampling loop, sample after sample (src/sample.py:38 calls p_sample_loop)
+            while True:
+                for out in diffusion.p_sample_loop_progressive(model, (1, 12, H + D, W + D), model_kwargs=kw):
+                    state["x"] = out["sample"]
+                    yield
+        gen = sampler()
+        step = lambda: next(gen)
         sync = torch.cuda.synchronize
 
     def barrier():

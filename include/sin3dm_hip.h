@@ -76,6 +76,16 @@ S3D_API int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data,
 S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D,
                      float* out, void* stream);
 
+/* The timestep path alone and a forward that takes its result.  emb -> FiLM only depends on the timestep values (and the
+ * weights): a sampling loop that knows them on the host (GaussianDiffusion._loop) computes each table once and reuses it
+ * for every sample.  s3d_unet_film: timestep_embedding -> time_embed -> all emb_layers (nn.py:103-121,
+ * unet_triplane.py:371-375, 232-238, 477, 281) for n timestep values t (device fp32) -> film [n][s3d_unet_film_width()].
+ * s3d_unet_forward_film: forward() with that table; film_stride = width (one row per sample) or 0 (all samples share row 0). */
+S3D_API int s3d_unet_film_width(const s3d_unet* m);
+S3D_API int s3d_unet_film(s3d_unet* m, const float* t, int n, float* film, void* stream);
+S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film, int film_stride, int B, int H, int W, int D,
+                          float* out, void* stream);
+
 /* Live kernel timing for bench.py's roofline line: HIP events are recorded on `stream` around every
  * MFMA convolution launch of each `every`-th forward (0 = off).  s3d_unet_profile_read waits for the
  * recorded events, ADDS their durations to `out` (caller zero-initialises) and recycles them.

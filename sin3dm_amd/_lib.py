@@ -62,6 +62,10 @@ SIGNATURES = {
     "s3d_unet_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, c_i64p, C.c_int]),
     "s3d_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
+    "s3d_unet_film_width": (C.c_int, [C.c_void_p]),
+    "s3d_unet_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "s3d_unet_forward_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
     "s3d_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "s3d_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "s3d_sampler_step": (C.c_int, [C.POINTER(SamplerArgs), C.c_void_p]),

@@ -89,6 +89,7 @@ struct s3d_unet {
     std::vector<ResBlockW> in_blocks, out_blocks;
 
     Arena arena;
+    DevBuf film_ws;                                      // s3d_unet_film: the two hidden vectors of the timestep MLP
     long long inf_key[4] = {-1, -1, -1, -1};             // (B,H,W,D) of the last measured inference forward ...
     size_t inf_high = 0;                                 // ... and the workspace it needs
 
@@ -164,14 +165,17 @@ namespace s3d {
 
 int pack_all(s3d_unet* m);
 int launch_repack_generic(const PackDesc* descs_dev, int ndesc, int blocks, const float* flat, float* wbuf, float* tbuf, hipStream_t st);
+// ext_film != null: the FiLM table [B or 1][film_total] is given (s3d_unet_film), t is not read
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape);
+                Tape* tape, const float* ext_film = nullptr, int ext_film_stride = 0);
 
 struct Fwd {
     s3d_unet* m;
     int B;
     hipStream_t st;
-    const float* film;      // [B][film_total]
+    const float* film;      // [B][film_total] (row b at film + b * film_stride)
+    int film_stride = -1;   // -1: m->film_total; 0: one row shared by the whole batch (s3d_unet_forward_film)
+    int fstride() const { return film_stride >= 0 ? film_stride : m->film_total; }
     Tape* tape = nullptr;   // training: record what the backward pass needs
     RBTape last_rb;         // filled by resblock() when tape is set
     Arena& ar() { return m->arena; }
@@ -255,7 +259,7 @@ struct Fwd {
         y = alloc_tri(x.C, x.g);
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(nw.gamma[p]); aa.beta[p] = m->dev(nw.beta[p]); }
-        aa.film = film_ptr; aa.film_stride = m->film_total;
+        aa.film = film_ptr; aa.film_stride = fstride();
         const bool roll = cw && cw->rollout;
         MeanPartials mp; MeanVecs mv;
         if (roll) S3D_TRY(roll_buffers(y, *cw, true, mp, mv, rrow, rcol));
@@ -297,7 +301,7 @@ struct Fwd {
             J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
             J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
             J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
-            J.bbias = bbias; J.bbias_stride = m->film_total;
+            J.bbias = bbias; J.bbias_stride = fstride();
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.res_up = res && res_up ? 1 : 0; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
             J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
@@ -337,7 +341,7 @@ struct Fwd {
         {
             ActArgs aa;
             for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(rb.n1.gamma[p]); aa.beta[p] = m->dev(rb.n1.beta[p]); }
-            aa.film = nullptr; aa.film_stride = m->film_total;
+            aa.film = nullptr; aa.film_stride = fstride();
             const bool roll = rb.c1.rollout;
             MeanPartials mp; MeanVecs mv;
             S3D_TRY(roll_buffers(y1, rb.c1, roll, mp, mv, rr, rc));

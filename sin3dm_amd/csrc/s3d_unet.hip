@@ -222,7 +222,7 @@ int pack_all(s3d_unet* m) {
 // ------------------------------------------------------------------ forward
 
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape) {
+                Tape* tape, const float* ext_film, int ext_film_stride) {
     const s3d_unet_cfg& c = m->cfg;
     const int mc = c.model_channels, ted = 4 * mc;
     Fwd f{m, B, st, nullptr};
@@ -237,7 +237,8 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
     float* emb = ar.alloc<float>(size_t(B) * ted);
     float* film = ar.alloc<float>(size_t(B) * m->film_total);
     f.film = film;
-    if (!meas) {
+    if (ext_film) { f.film = ext_film; f.film_stride = ext_film_stride; }
+    if (!meas && !ext_film) {
         // training keeps the pre-activation of time_embed.0 (SiLU is applied on the way into the next layer instead)
         S3D_TRY(launch_linear(t, B, mc, m->dev(m->te0_w), m->dev(m->te0_b), ted, e1, 2, tape ? 0 : 1, st));
         S3D_TRY(launch_linear(e1, B, ted, m->dev(m->te2_w), m->dev(m->te2_b), ted, emb, tape ? 1 : 0, 0, st));
@@ -390,8 +391,42 @@ int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data, const i
     return S3D_ERR_INVALID;
 }
 
+static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
+                        const float* ext_film, int ext_film_stride);
+
 int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream) {
     S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "unet_forward: null argument");
+    return forward_impl(m, x, t, B, H, W, D, out, stream, nullptr, 0);
+}
+
+int s3d_unet_film_width(const s3d_unet* m) { return m ? m->film_total : S3D_ERR_INVALID; }
+
+int s3d_unet_film(s3d_unet* m, const float* t, int n, float* film, void* stream) {
+    S3D_CHECK(m && t && film && n >= 1, S3D_ERR_INVALID, "unet_film: bad argument");
+    if (!m->packed) S3D_TRY(pack_all(m));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int mc = m->cfg.model_channels, ted = 4 * mc;
+    const size_t need = size_t(2) * n * ted * sizeof(float);
+    if (need > m->film_ws.cap) { S3D_HIP(hipStreamSynchronize(st)); S3D_TRY(m->film_ws.reserve(need)); }
+    float* e1 = static_cast<float*>(m->film_ws.p);
+    float* emb = e1 + size_t(n) * ted;
+    S3D_TRY(launch_linear(t, n, mc, m->dev(m->te0_w), m->dev(m->te0_b), ted, e1, 2, 1, st));
+    S3D_TRY(launch_linear(e1, n, ted, m->dev(m->te2_w), m->dev(m->te2_b), ted, emb, 0, 0, st));
+    S3D_TRY(launch_linear(emb, n, ted, m->dev(m->film_w), m->dev(m->film_b), m->film_total, film, 1, 0, st));
+    return 0;
+}
+
+int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film, int film_stride, int B, int H, int W, int D, float* out,
+                          void* stream) {
+    S3D_CHECK(m && x && film && out, S3D_ERR_INVALID, "unet_forward_film: null argument");
+    S3D_CHECK(film_stride == 0 || film_stride == m->film_total, S3D_ERR_INVALID, "unet_forward_film: film_stride must be 0 or %d", m->film_total);
+    return forward_impl(m, x, nullptr, B, H, W, D, out, stream, film, film_stride);
+}
+
+}  // extern "C"
+
+static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
+                        const float* ext_film, int ext_film_stride) {
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "unet_forward: B,H,W,D must be >= 1");
     if (!m->packed) S3D_TRY(pack_all(m));
     m->tape.valid = false;                    // the workspace is shared with the training tape
@@ -404,7 +439,7 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
     if (!same || m->inf_high > m->arena.buf.cap) {
         m->arena.measuring = true;
         m->arena.high = 0;
-        rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
+        rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride);
         m->arena.measuring = false;
         if (rc) return rc;
         m->inf_high = m->arena.high;
@@ -417,10 +452,12 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
     m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
     ++m->fwd_count;
     if (m->prof_now) ++m->prof_forwards;
-    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr);
+    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride);
     m->prof_now = false;
     return rc;
 }
+
+extern "C" {
 
 int s3d_unet_profile(s3d_unet* m, int every) {
     S3D_CHECK(m && every >= 0, S3D_ERR_INVALID, "unet_profile: bad argument");

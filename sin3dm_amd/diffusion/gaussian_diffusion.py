@@ -60,6 +60,33 @@ class LossType(enum.Enum):
         return self in (LossType.KL, LossType.RESCALED_KL)
 
 
+class HostTimesteps(th.Tensor):
+    """A device timestep tensor whose values are also known on the host (`.host_values`, a tuple).
+
+    The sampling loops generate their own timesteps, so they know them without a device round trip; the respacing
+    wrapper and the UNet use that to skip per-step work whose result only depends on the timestep values: the
+    `timestep_map[ts]` gather of _WrappedModel (reference respace.py:124-125) and the timestep MLP
+    (embedding -> time_embed -> emb_layers) become cached per value.  For any other tensor nothing changes; results are
+    identical either way (the same kernels compute the cached tables)."""
+
+    @staticmethod
+    def __new__(cls, data, host_values):
+        r = th.Tensor._make_subclass(cls, data, False)
+        r.host_values = tuple(host_values)
+        return r
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        # results of torch ops are plain tensors: the host copy describes this tensor only
+        with th._C.DisableTorchFunctionSubclass():
+            out = func(*args, **(kwargs or {}))
+        return out
+
+
+def host_values_of(t):
+    return getattr(t, "host_values", None) if isinstance(t, HostTimesteps) else None
+
+
 class GaussianDiffusion:
     """Schedule tables + MI355X sampling steps.  Constructor arguments as in the reference (:119-127)."""
 
@@ -231,8 +258,11 @@ class GaussianDiffusion:
             indices = tqdm(indices)
         # every step's timestep batch as a row of one tensor built up front (a th.full per step is a kernel launch)
         all_t = th.arange(self.num_timesteps, device=device, dtype=th.int64)[:, None].expand(-1, shape[0]).contiguous()
+        prepare = getattr(self, "_prepare_loop", None)
+        if prepare is not None:
+            prepare(model, shape[0], device)         # per-schedule caches (timestep map, FiLM tables) in one go
         for i in indices:
-            t = all_t[i]
+            t = HostTimesteps(all_t[i], (i,) * shape[0])
             with th.no_grad():
                 out = step_fn(model, img, t, **kw)
                 yield out

@@ -4,7 +4,7 @@ from __future__ import annotations
 import numpy as np
 import torch as th
 
-from .gaussian_diffusion import GaussianDiffusion
+from .gaussian_diffusion import GaussianDiffusion, HostTimesteps, host_values_of
 
 
 def space_timesteps(num_timesteps, section_counts):
@@ -67,6 +67,9 @@ class SpacedDiffusion(GaussianDiffusion):
             self._map_cache = {}
         return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps, self._map_cache)
 
+    def _prepare_loop(self, model, batch, device):
+        self._wrap_model(model).prepare_loop(self.num_timesteps, batch, device)
+
     def _step(self, mode, model, *args, **kwargs):
         return super()._step(mode, self._wrap_model(model), *args, **kwargs)
 
@@ -102,6 +105,29 @@ class _WrappedModel:
     def parameters(self):
         return self.model.parameters()
 
+    def _mapped(self, v):
+        m = float(self.timestep_map[v])
+        return m * (1000.0 / self.original_num_steps) if self.rescale_timesteps else m
+
+    def prepare_loop(self, num_timesteps, batch, device):
+        """Called by the sampling loops before their first step: the mapped timesteps of the whole schedule as ONE device
+        tensor (row i = the batch's timesteps of loop index i) and, if the denoiser offers it, its per-timestep tables in
+        one batched launch — instead of a host-to-device copy and three small launches on the first visit of every index."""
+        key = str(device)
+        sched = ("schedule", key, batch)
+        if sched in self._maps:
+            return
+        vals = [self._mapped(i) for i in range(num_timesteps)]
+        col = th.tensor(vals, device=device, dtype=th.float32)
+        rows = col[:, None].expand(-1, batch).contiguous()
+        for i, v in enumerate(vals):
+            hv = (v,) * batch
+            self._maps[(key, hv)] = HostTimesteps(rows[i], hv)
+        self._maps[sched] = rows
+        prep = getattr(self.model, "prepare_timesteps", None)
+        if prep is not None:
+            prep(vals, col)
+
     def __getattr__(self, name):          # forward_train / backward_flat / flat_parameters of the wrapped denoiser
         return getattr(self.__dict__["model"], name)
 
@@ -109,6 +135,15 @@ class _WrappedModel:
         # the map is kept in float32: the denoiser embeds float timesteps anyway (nn.py:113), so one gather replaces the
         # reference's integer gather + cast (exact: indices < 2^24)
         key = str(ts.device)
+        hv = host_values_of(ts)
+        if hv is not None:
+            # the loop told us the values: map them on the host, one cached device tensor per distinct batch of values
+            mapped = tuple(self._mapped(v) for v in hv)
+            ck = (key, mapped)
+            new_ts = self._maps.get(ck)
+            if new_ts is None:
+                new_ts = self._maps[ck] = HostTimesteps(th.tensor(mapped, device=ts.device, dtype=th.float32), mapped)
+            return self.model(x, new_ts, **kwargs)
         m = self._maps.get(key)
         if m is None:
             m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=th.float32)

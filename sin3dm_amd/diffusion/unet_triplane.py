@@ -68,6 +68,8 @@ class _TriplaneUNetBase(nn.Module):
         self._handle = None
         self._synced = None
         self._plist = None
+        self._film_cache = {}       # host-known timestep values -> FiLM table (dropped whenever the parameters change)
+        self._film_sched = None     # the last schedule announced by a sampling loop (prepare_timesteps)
         self._flat = None           # training: flat master parameters on the device (see _ensure_flat)
         self._flat_layout = None    # [(name, offset, numel, shape)]
         self._flat_dirty = False
@@ -112,6 +114,8 @@ class _TriplaneUNetBase(nn.Module):
             named = dict(self.named_parameters())
             self._plist = [named[n] for n in self._param_names]
         stamp = tuple(p._version for p in self._plist)
+        if stamp != self._synced or self._flat_dirty:
+            self._film_cache.clear()
         if self._flat is not None:
             if stamp != self._synced or self._flat_dirty:          # parameters changed on the device: repack there
                 params = dict(self.named_parameters())
@@ -135,6 +139,8 @@ class _TriplaneUNetBase(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)      # .to(), .cuda(), .float(): the parameter storage moves
+        self._film_cache = {}
+        self._film_sched = None
         self._synced = None
         self._flat = None
         self._plist = None
@@ -264,11 +270,54 @@ class _TriplaneUNetBase(nn.Module):
         h, t, out = self._prep(x, timesteps, H, W, D)
         B = h.shape[0]
         lib = self._ensure_handle()
+        hv = getattr(timesteps, "host_values", None)
         with th.cuda.device(h.device):
-            _lib.check(lib.s3d_unet_forward(self._handle, _lib.ptr(h), _lib.ptr(t), B, int(H), int(W), int(D),
-                                            _lib.ptr(out), _lib.stream_ptr()))
+            if hv is not None and len(hv) == B:
+                # timestep values known on the host (the sampling loops): the FiLM table of these values is computed once
+                # per weight version and reused by every later step / sample with the same values
+                film, stride = self._film_for(lib, hv, t)
+                _lib.check(lib.s3d_unet_forward_film(self._handle, _lib.ptr(h), _lib.ptr(film), stride, B, int(H), int(W),
+                                                     int(D), _lib.ptr(out), _lib.stream_ptr()))
+            else:
+                _lib.check(lib.s3d_unet_forward(self._handle, _lib.ptr(h), _lib.ptr(t), B, int(H), int(W), int(D),
+                                                _lib.ptr(out), _lib.stream_ptr()))
         assert out.shape == x.shape or y is not None
         return out
+
+    def prepare_timesteps(self, values, t_dev):
+        """The FiLM tables of a whole schedule (host values + the same values on the device) in one batched launch; the
+        sampling loops call this before their first step.  Remembered, so that a weight update refills the cache in one go."""
+        self._film_sched = (tuple(values), t_dev)
+        lib = self._ensure_handle()
+        dkey = str(t_dev.device)
+        if all((dkey, v) in self._film_cache for v in values):
+            return
+        width = lib.s3d_unet_film_width(self._handle)
+        t = t_dev.to(th.float32).contiguous()
+        film = th.empty((len(values), width), device=t.device, dtype=th.float32)
+        with th.cuda.device(t.device):
+            _lib.check(lib.s3d_unet_film(self._handle, _lib.ptr(t), len(values), _lib.ptr(film), _lib.stream_ptr()))
+        for k, v in enumerate(values):
+            self._film_cache[(dkey, v)] = film[k:k + 1]
+
+    def _film_for(self, lib, hv, t):
+        """(device FiLM table, row stride) for host-known timestep values: one row when the batch shares a value."""
+        same = all(v == hv[0] for v in hv)
+        key = (str(t.device), hv[0] if same else hv)
+        film = self._film_cache.get(key)
+        if film is None and same and self._film_sched is not None and hv[0] in self._film_sched[0] \
+                and str(self._film_sched[1].device) == str(t.device):
+            self.prepare_timesteps(*self._film_sched)          # (the weights changed: refill the schedule's tables at once)
+            film = self._film_cache.get(key)
+        if film is None:
+            if len(self._film_cache) > 4096:
+                self._film_cache.clear()
+            n = 1 if same else len(hv)
+            width = lib.s3d_unet_film_width(self._handle)
+            film = th.empty((n, width), device=t.device, dtype=th.float32)
+            _lib.check(lib.s3d_unet_film(self._handle, _lib.ptr(t[:n].contiguous()), n, _lib.ptr(film), _lib.stream_ptr()))
+            self._film_cache[key] = film
+        return film, (0 if same else film.shape[1])
 
     def _prep(self, x, timesteps, H, W, D):
         h = x.contiguous().float()

@@ -492,3 +492,47 @@ def test_config5_decode_grid_512x512x256(oracle):
     want[:, 1:] = np.clip(want[:, 1:], 0, 1)
     got = grid[idx[:, 0], idx[:, 1], idx[:, 2]].cpu().numpy()
     assert relerr(got, want) < TOL_FWD
+
+
+def test_host_known_timesteps_change_nothing():
+    """The sampling loops hand the model HostTimesteps (values known on the host): the timestep_map gather and the
+    timestep MLP are then served from per-value caches.  Bit-identical to plain tensors, per sample and per batch with
+    mixed values, across respacing; and the cache follows the weights."""
+    from sin3dm_amd.diffusion.gaussian_diffusion import HostTimesteps
+    H, W, D = 10, 14, 6
+    kw = dict(H=H, W=W, D=D)
+    model = make_model(32)
+    x = cu(T.synthetic_noise((2, 12, H + D, W + D), 71))
+    eps = cu(T.synthetic_noise((2, 12, H + D, W + D), 72))
+    for resp in ("", "10"):
+        diff = make_diffusion(resp)
+        diff.noise_fn = lambda z: eps
+        for vals in ((3, 3), (diff.num_timesteps - 1, 1)):
+            t = torch.tensor(vals, device=dev(), dtype=torch.int64)
+            with torch.no_grad():
+                a = diff.p_sample(model, x, t, model_kwargs=kw)
+                b = diff.p_sample(model, x, HostTimesteps(t, vals), model_kwargs=kw)
+                c = diff.p_sample(model, x, HostTimesteps(t, vals), model_kwargs=kw)       # served from the caches
+            assert torch.equal(a["sample"], b["sample"]) and torch.equal(a["sample"], c["sample"]), (resp, vals)
+    # the loop API (which uses them) against manual stepping with plain tensors
+    diff = make_diffusion("5")
+    noise = iter([cu(T.synthetic_noise((2, 12, H + D, W + D), 80 + k)) for k in range(10)])
+    diff.noise_fn = lambda z: next(noise)
+    xT = cu(T.synthetic_noise((2, 12, H + D, W + D), 79))
+    with torch.no_grad():
+        got = diff.p_sample_loop(model, tuple(xT.shape), noise=xT.clone(), model_kwargs=kw)
+        noise = iter([cu(T.synthetic_noise((2, 12, H + D, W + D), 80 + k)) for k in range(10)])
+        y = xT.clone()
+        for i in range(4, -1, -1):
+            y = diff.p_sample(model, y, torch.full((2,), i, device=dev(), dtype=torch.int64), model_kwargs=kw)["sample"]
+    assert torch.equal(got, y)
+    # weights change -> the cached FiLM tables must not survive
+    t = torch.tensor((3, 3), device=dev(), dtype=torch.int64)
+    diff = make_diffusion("")
+    diff.noise_fn = lambda z: eps
+    with torch.no_grad():
+        before = diff.p_sample(model, x, HostTimesteps(t, (3, 3)), model_kwargs=kw)["sample"]
+        dict(model.named_parameters())["time_embed.2.bias"].add_(0.25)
+        after_h = diff.p_sample(model, x, HostTimesteps(t, (3, 3)), model_kwargs=kw)["sample"]
+        after_p = diff.p_sample(model, x, t, model_kwargs=kw)["sample"]
+    assert torch.equal(after_h, after_p) and not torch.equal(before, after_h)

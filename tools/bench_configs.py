@@ -17,7 +17,10 @@ CONFIGS = [  # name, model_channels, (H,W,D), batch, respacing, ddim, steps time
     ("C5 128-ch (256,256,128) DDPM B=1", 128, (256, 256, 128), 1, "", False, 50),
 ]
 dev = torch.device("cuda:0")
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None          # substring of a config name
 for name, mc, (H, W, D), B, resp, ddim, steps in CONFIGS:
+    if ONLY and ONLY not in name:
+        continue
     model = TriplaneUNetModelSmall(12, mc, 12, use_scale_shift_norm=True)
     model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0))
     model.to(dev).eval()
