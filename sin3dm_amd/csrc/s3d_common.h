@@ -126,7 +126,8 @@ struct ConvArgs {
     int relu;                                 // direct kernels only: ReLU in the epilogue (the decoder MLPs as 1x1 convs)
     int xcd_swizzle;                          // Winograd kernel: logical block order contiguous per XCD (set by the launcher)
 };
-enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3 };
+// CONV_1x3_ROLL: the forward rollout tables — args.cout = the convolution's cout, out [B][pos][4 variants][cout] (k_rank1<true>)
+enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3, CONV_1x3_ROLL = 4 };
 // Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.
 int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
 // Debug/triangulation path: a plain one-thread-per-output direct convolution (no MFMA, no LDS).
@@ -140,7 +141,7 @@ double conv_exec_fraction(ConvKind kind, const ConvArgs& a);
 struct ConvW {
     size_t dense[3] = {0, 0, 0};      // [taps][cout][cin_own]
     size_t bias[3] = {0, 0, 0};
-    size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3][4*cout][C]
+    size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3 taps][ceil(cout/8)*24][C], row (co/8)*24 + o*8 + co%8
     size_t rcol[3] = {0, 0, 0};       // rank-1 weights for the column-varying mean vector
     size_t wino[3] = {0, 0, 0};       // 3x3: G g G^T in fragment order (0 = not packed)
     size_t wino24[3] = {0, 0, 0};     // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24

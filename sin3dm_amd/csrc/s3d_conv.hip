@@ -352,7 +352,13 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
 // 512-byte rows of the vector (with its +-1 halo, loaded once per chunk) and of the weights are staged in LDS with
 // coalesced loads, register-prefetched one stage ahead; inside a stage the four waves each contract a quarter of the
 // chunk, and their partial accumulators are added through LDS in wave order at the end.
+// ROLL3 (CONV_1x3_ROLL, the forward rollout tables): the four edge variants of a table entry are sums over subsets of the
+// three taps o of the SUMMED-OUT axis (interior o0+o1+o2, first o1+o2, last o0+o1, single o1), so only the three per-tap
+// products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
+// 8 output channels = 24 weight rows (a quarter fewer weight bytes than four pre-summed variants: the kernel is bound by
+// streaming them once) — and the variants are formed while the four waves' partials are added.
 constexpr int kR1Chunk = 128, kR1Ld = kR1Chunk + 4;
+template <bool ROLL3>
 __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     __shared__ __attribute__((aligned(16))) float sA[34 * kR1Ld];
     __shared__ __attribute__((aligned(16))) float sB[2][32 * kR1Ld];
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
     constexpr int q4 = kR1Chunk / 4;                        // float4 slots per staged row
     const float* vb = J.in + size_t(b) * L * cin;
-    const size_t tapStride = size_t(cout4) * cin;
+    const size_t tapStride = ROLL3 ? size_t(J.n_tiles_n) * 24 * cin : size_t(cout4) * cin;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x16 acc;
 #pragma unroll
@@ -394,8 +400,8 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
 #pragma unroll
         for (int it = 0; it < NB; ++it) {
             const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            const int n = ntile * 32 + row;
-            const bool ok = row < 32 && n < cout4 && q < wq;
+            const int n = ROLL3 ? ntile * 24 + row : ntile * 32 + row;
+            const bool ok = (ROLL3 ? row < 24 && ntile * 8 + (row & 7) < cout4 : row < 32 && n < cout4) && q < wq;
             rb[it] = to_global4(J.wgt + tap * tapStride + size_t(ok ? n : 0) * cin + c0 + (ok ? q : 0) * 4)[0];
             if (!ok) rb[it] = zero4;
         }
@@ -449,6 +455,23 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
+    if (ROLL3) {
+        // thread = (position, channel of the block's eight): MFMA row p sits in register (p&3) + 4*(p>>3) of lane half (p>>2)&1
+        const int p = tid >> 3, c8 = tid & 7;
+        const int r = (p & 3) + 4 * (p >> 3), lh = ((p >> 2) & 1) * 32;
+        float u[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const int l = lh + o * 8 + c8;
+            u[o] = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+        }
+        const int row = mtile * 32 + p, co = ntile * 8 + c8;
+        if (row < L && co < cout4) {
+            float* o4 = J.out + (size_t(b) * L + row) * 4 * cout4 + co;      // [pos][variant][cout]
+            o4[0] = (u[0] + u[1]) + u[2]; o4[cout4] = u[1] + u[2]; o4[2 * cout4] = u[0] + u[1]; o4[3 * cout4] = u[1];
+        }
+        return;
+    }
     for (int it = tid; it < 1024; it += 256) {
         const int r = it >> 6, l = it & 63;
         const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
@@ -457,19 +480,51 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     }
 }
 
-int launch_rank1(ConvArgs& a, hipStream_t st) {
+// S3D_CONV_IMPL=naive counterpart of the ROLL3 form: one thread per table entry, plain loops over the same weight image
+__global__ void k_rank1_roll_naive(ConvArgs args) {
+    for (int j = 0; j < args.njobs; ++j) {
+        const ConvJob& J = args.job[j];
+        const int L = J.w, cout = args.cout, cin = args.cin, nt = (cout + 7) / 8;
+        const long long n = (long long)args.B * L * cout;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int co = int(i % cout), pos = int((i / cout) % L), b = int(i / cout / L);
+            float u[3] = {0.f, 0.f, 0.f};
+            for (int o = 0; o < 3; ++o)
+                for (int t = 0; t < 3; ++t) {
+                    const int q = pos + t - 1;
+                    if (q < 0 || q >= L) continue;
+                    const float* v = J.in + (size_t(b) * L + q) * cin;
+                    const float* wr = J.wgt + (size_t(t) * nt * 24 + (co / 8) * 24 + o * 8 + (co & 7)) * cin;
+                    for (int c = 0; c < cin; ++c) u[o] = fmaf(v[c], wr[c], u[o]);
+                }
+            float* o4 = J.out + (size_t(b) * L + pos) * 4 * cout + co;
+            o4[0] = (u[0] + u[1]) + u[2]; o4[cout] = u[1] + u[2]; o4[2 * cout] = u[0] + u[1]; o4[3 * cout] = u[1];
+        }
+    }
+}
+
+int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % KC == 0, S3D_ERR_INVALID, "rank1: bad arguments");
-    if (conv_use_naive()) return launch_conv_naive(CONV_1x3_VEC, a, st);
+    if (conv_use_naive()) {
+        if (!roll3) return launch_conv_naive(CONV_1x3_VEC, a, st);
+        hipLaunchKernelGGL(k_rank1_roll_naive, dim3(512), dim3(256), 0, st, a);
+        S3D_HIP(hipGetLastError());
+        return 0;
+    }
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
         J.tiles_x = J.tiles_per_img = (J.w + 31) / 32;
-        J.n_tiles_n = (a.cout + 31) / 32;
+        J.n_tiles_n = roll3 ? (a.cout + 7) / 8 : (a.cout + 31) / 32;
         J.block_begin = blocks;
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    hipLaunchKernelGGL(k_rank1, dim3(blocks), dim3(256), 0, st, a);
+    // (measured in round 2 and dropped: whole-chunk stages with two chunks of loads in flight, and eight waves per block —
+    // 9.4 / 14.7 / 18.7 us at 128 / 256 / 384 channels either way: the launch is bound by the ~21 MB per 128-channel chunk that
+    // 384 blocks pull through L2 at once, not by its stage latency or its MFMA chains)
+    if (roll3) hipLaunchKernelGGL(k_rank1<true>, dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_rank1<false>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -497,7 +552,7 @@ static void kind_taps(ConvKind kind, int& KH, int& KW) {
     switch (kind) {
         case CONV_3x3: KH = 3; KW = 3; break;
         case CONV_1x1: KH = 1; KW = 1; break;
-        case CONV_1x3_VEC: KH = 1; KW = 3; break;
+        case CONV_1x3_VEC: case CONV_1x3_ROLL: KH = 1; KW = 3; break;
         default: KH = 5; KW = 5; break;
     }
 }
@@ -582,7 +637,9 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
         case CONV_1x1:
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
         case CONV_1x3_VEC:
-            return launch_rank1(a, st);
+            return launch_rank1(a, st, false);
+        case CONV_1x3_ROLL:
+            return launch_rank1(a, st, true);
         case CONV_5x5:
             return launch_cfg<ConvCfg<8, 8, 5, 5, 2, 2, 1, 1>>(a, st);
     }

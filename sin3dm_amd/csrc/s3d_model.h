@@ -125,7 +125,7 @@ struct s3d_unet {
     int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
         if (!prof_now) return launch_conv(kind, ca, st);
         // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
-        int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : 25));
+        int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : (kind == CONV_1x3_ROLL ? 9 : 25)));
         double pix = 0;
         for (int j = 0; j < ca.njobs; ++j) pix += double(ca.job[j].h) * ca.job[j].w;
         ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B, 0.0};
@@ -238,7 +238,7 @@ struct Fwd {
     int rank1_tables(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
         S3D_TRY(launch_means_finalize(y.g, y.C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = B; ca.cin = y.C; ca.cout = 4 * cw.cout; ca.njobs = 6;
+        ca.B = B; ca.cin = y.C; ca.cout = cw.cout; ca.njobs = 6;
         // row-varying / column-varying vector of each plane
         const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
         const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
@@ -248,7 +248,7 @@ struct Fwd {
             ConvJob& jc = ca.job[2 * p + 1];
             jc.in = colvec[p]; jc.wgt = m->dev(cw.rcol[p]); jc.out = const_cast<float*>(rcol[p]); jc.h = 1; jc.w = y.g.w[p];
         }
-        return m->timed_conv(2, CONV_1x3_VEC, ca, st);
+        return m->timed_conv(2, CONV_1x3_ROLL, ca, st);
     }
     int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
                  const float* rcol[3], NormTape* nt = nullptr) {

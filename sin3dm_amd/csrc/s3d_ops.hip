@@ -81,7 +81,7 @@ int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, i
         S3D_TRY(launch_gn_act(x, B, GnStats{nullptr}, aa, y, &mp, st));          // identity copy + axis sums
         S3D_TRY(launch_means_finalize(g, C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
-        ca.B = B; ca.cin = C; ca.cout = 4 * Cout; ca.njobs = 6;
+        ca.B = B; ca.cin = C; ca.cout = Cout; ca.njobs = 6;
         const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};
         const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};
         for (int p = 0; p < 3; ++p) {
@@ -90,7 +90,7 @@ int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, i
             ConvJob& jc = ca.job[2 * p + 1];
             jc.in = colvec[p]; jc.wgt = wdev + cw.rcol[p]; jc.out = tab_col[p]; jc.h = 1; jc.w = g.w[p];
         }
-        S3D_TRY(launch_conv(CONV_1x3_VEC, ca, st));
+        S3D_TRY(launch_conv(CONV_1x3_ROLL, ca, st));
     }
     ConvArgs ca; memset(&ca, 0, sizeof ca);
     ca.B = B; ca.cin = C; ca.cout = Cout; ca.njobs = 3;

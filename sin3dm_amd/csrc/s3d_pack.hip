@@ -10,10 +10,6 @@
 namespace s3d {
 
 
-__device__ __forceinline__ bool var_tap(int var, int o) {
-    // taps of the summed-out axis that stay inside the image, by edge variant (0 interior, 1 first, 2 last, 3 single)
-    return o == 1 || (o == 0 && (var == 0 || var == 2)) || (o == 2 && (var == 0 || var == 1));
-}
 
 __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ descs, int ndesc, const float* __restrict__ flat,
                                                 float* __restrict__ wbuf, float* __restrict__ tbuf) {
@@ -113,23 +109,19 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int v = 0; v < 6; ++v) {
-                    const double uv = t[u][0] * G4[v][0] + t[u][1] * G4[v][1] + t[u][2] * G4[v][2];
+                    const double uv = fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2]));       // as pack_wino24_weights
                     if (d.kind == PK_WINO24) dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
                     else dst[(((((size_t)nt * (cin / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
                 }
             break;
         }
-        case PK_RANK1: {                         // dst [(t*4*cout + var*cout + co)*cin + c]
+        case PK_RANK1: {                         // item (t, o, co, c) -> dst [(t*n3 + (co/8)*24 + o*8 + co%8)*cin + c], n3 = ceil(cout/8)*24
             const int c = int(i % cin); long long r = i / cin;
             const int co = int(r % cout); r /= cout;
-            const int var = int(r % 4), t = int(r / 4);
-            double s = 0;
-            for (int o = 0; o < 3; ++o) {
-                if (!var_tap(var, o)) continue;
-                const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
-                s += double(W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw]);
-            }
-            dst[i] = float(s);
+            const int o = int(r % 3), t = int(r / 3);
+            const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
+            const int n3 = (cout + 7) / 8 * 24;
+            dst[((size_t)t * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin + c] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw];
             break;
         }
         case PK_RANK1_BWD: {                     // dst [(tap*cin + c)*(3*cout) + j*cout + co]
@@ -189,7 +181,7 @@ struct Plan {
             const bool a_is_col = (p == 0);
             for (int slot = 1; slot <= 2; ++slot) {
                 const bool colv = (slot == 1) ? a_is_col : !a_is_col;
-                add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)3 * 4 * cout * cin, cout, ctot, cin, 9, slot, colv);
+                add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)3 * 3 * cout * cin, cout, ctot, cin, 9, slot, colv);
                 const size_t off = talloc(size_t(3) * cin * 3 * cout);
                 (colv ? wt.rcol_T[p] : wt.rrow_T[p]) = off;
                 add(PK_RANK1_BWD, w, off, (long long)3 * cin * 3 * cout, cout, ctot, cin, 9, slot, colv, 1);

@@ -82,8 +82,8 @@ size_t push(std::vector<float>& st, const float* src, size_t n) {
 }
 static const std::vector<float>& H(const s3d_unet* m, const std::string& name) { return m->host.at(name); }
 
-// taps of the summed-out axis that stay inside the image, by edge variant (see edge_variant in s3d_conv.hip)
-static const int kVarTaps[4][3] = {{1, 1, 1}, {0, 1, 1}, {1, 1, 0}, {0, 1, 0}};
+// (taps of the summed-out axis that stay inside the image, by edge variant — edge_variant in s3d_conv.hip: interior
+// {1,1,1}, first {0,1,1}, last {1,1,0}, single {0,1,0}; k_rank1<true> forms the four sums from the per-tap products)
 
 // Pack one TriplaneConv.  Rollout channel blocks (src/diffusion/unet_triplane.py:37-46):
 //   plane xy: A = mean_d(yz) varies along columns (w), B = mean_d(xz) varies along rows (h)
@@ -110,20 +110,18 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
         const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
         for (int slot = 1; slot <= 2; ++slot) {
             const bool col_varying = (slot == 1) ? a_is_col : !a_is_col;
-            size_t off = push(stage, nullptr, size_t(3) * 4 * cout * cin);
+            // per tap t along the vector's own axis and tap o of the summed-out axis: row (co/8)*24 + o*8 + co%8 (k_rank1<true>)
+            const int n3 = (cout + 7) / 8 * 24;
+            size_t off = push(stage, nullptr, size_t(3) * n3 * cin);
             float* r = stage.data() + off;
-            for (int t = 0; t < 3; ++t)                      // tap along the vector's own axis
-                for (int var = 0; var < 4; ++var)
-                    for (int co = 0; co < cout; ++co)
-                        for (int c = 0; c < cin; ++c) {
-                            double s = 0;
-                            for (int o = 0; o < 3; ++o) {       // the summed-out axis
-                                if (!kVarTaps[var][o]) continue;
-                                const int kh = col_varying ? o : t, kw = col_varying ? t : o;
-                                s += W[(size_t(co) * ctot + slot * cin + c) * 9 + kh * 3 + kw];
-                            }
-                            r[(size_t(t) * 4 * cout + var * cout + co) * cin + c] = float(s);
-                        }
+            std::fill(r, r + size_t(3) * n3 * cin, 0.f);
+            for (int t = 0; t < 3; ++t)
+                for (int o = 0; o < 3; ++o)
+                    for (int co = 0; co < cout; ++co) {
+                        const int kh = col_varying ? o : t, kw = col_varying ? t : o;
+                        float* dst = r + (size_t(t) * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin;
+                        for (int c = 0; c < cin; ++c) dst[c] = W[(size_t(co) * ctot + slot * cin + c) * 9 + kh * 3 + kw];
+                    }
             if (col_varying) cw.rcol[p] = off; else cw.rrow[p] = off;
         }
     }

@@ -628,7 +628,7 @@ size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, 
             const int nt = co >> 5, jn = co & 31, k8 = c >> 3, hf = (c >> 2) & 1, e = c & 3;
             for (int u = 0; u < 4; ++u)
                 for (int v = 0; v < 6; ++v) {
-                    const double uv = t[u][0] * kG4[v][0] + t[u][1] * kG4[v][1] + t[u][2] * kG4[v][2];
+                    const double uv = fma(t[u][0], kG4[v][0], fma(t[u][1], kG4[v][1], t[u][2] * kG4[v][2]));    // explicit fma: host and device (s3d_pack.hip) round alike
                     d[(((size_t(nt) * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
                 }
         }
@@ -651,7 +651,7 @@ size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout,
             const int nt = co >> 5, nb = (co >> 4) & 1, jn = co & 15, k16 = c >> 4, q = (c >> 2) & 3, e = c & 3;
             for (int u = 0; u < 4; ++u)
                 for (int v = 0; v < 6; ++v) {
-                    const double uv = t[u][0] * kG4[v][0] + t[u][1] * kG4[v][1] + t[u][2] * kG4[v][2];
+                    const double uv = fma(t[u][0], kG4[v][0], fma(t[u][1], kG4[v][1], t[u][2] * kG4[v][2]));    // explicit fma: host and device (s3d_pack.hip) round alike
                     d[((((size_t(nt) * k16t + k16) * 24 + (u * 6 + v)) * 2 + nb) * 64 + (q * 16 + jn)) * 4 + e] = float(uv);
                 }
         }

@@ -321,4 +321,4 @@ def test_adamw_ema_kernel_elementwise(wd):
         # p ~ N(0,1) is stored in fp32 (half an ulp at 4.0 = 2.4e-7 per step); a wrong bias-correction exponent or decay order
         # moves the update by >= 1e-4
         assert np.max(np.abs(dp - dref)) < 1.5e-6, (s, np.max(np.abs(dp - dref)))
-        assert np.max(np.abs(ema.double().cpu().numpy() - ema_ref.numpy())) < 5e-7, s
+        assert np.max(np.abs(ema.double().cpu().numpy() - ema_ref.numpy())) < 1.5e-6, s
