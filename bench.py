@@ -280,7 +280,7 @@ def worker(args):
                 "hbm_frac_of_8TBs": round(traffic / avg_s / 8e12, 4) if traffic else None,
                 "kernel": "the dense 3x3 TriplaneConv kernel (own-channel part of the rollout convolution): "
                           + {"0": "k_conv_mfma<3x3> direct", "2": "k_conv_wino2 Winograd F(2x2,3x3)", "6": "k_conv_wino6 Winograd F(4x4,3x3)"}.get(
-                              os.environ.get("S3D_WINO", ""), "default 3x3 kernel of sin3dm_amd/csrc/s3d_wino.hip"),
+                              os.environ.get("S3D_WINO", ""), "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks (k_conv_wino4 F(2x2) for layers it does not take)"),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(prof.launches[0]),
                 "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
                 "mfma_flops_per_launch_avg": prof.mfma_flops[0] / prof.launches[0],

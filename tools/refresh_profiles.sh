@@ -1,35 +1,50 @@
 #!/bin/bash
 # Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r01'
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r02'
 # Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
-R=${1:-r01}
+R=${1:-r02}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline --profile-every 0"
-# 1. kernel trace + stats
+# 1. kernel trace + stats, one step's timeline
 rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o t --output-format csv -- $B > /tmp/p1.log 2>&1
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/${R}_kernel_stats.csv
-python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 65 > $OUT/${R}_kernel_summary.txt
+python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 125 > $OUT/${R}_kernel_summary.txt
+python3 $ROOT/tools/trace_timeline.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) > $OUT/${R}_timeline.txt
 # 2. HBM traffic: two PMC passes (counters only with --kernel-trace)
 P="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-every 0"
 rm -rf /tmp/p2 && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o t --output-format csv -- $P > /tmp/p2.log 2>&1
 rm -rf /tmp/p3 && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o t --output-format csv -- $P > /tmp/p3.log 2>&1
-python3 $ROOT/tools/pmc_traffic.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_traffic.json k_conv_wino
+python3 $ROOT/tools/pmc_traffic.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_traffic.json k_conv_wino24s
 # 3. SQ counters
 rm -rf /tmp/p4 && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p4 -o t --output-format csv -- $P > /tmp/p4.log 2>&1
 { echo "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 6 --warmup 2";
   echo "MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs)";
   python3 $ROOT/tools/pmc_sq_summary.py $(find /tmp/p4 -name "*counter_collection.csv" | head -1); } > $OUT/${R}_pmc_sq_summary.txt
+rm -rf /tmp/p5 && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/p5 -o t --output-format csv -- $P > /tmp/p5.log 2>&1
+python3 - $(find /tmp/p5 -name "*counter_collection.csv" | head -1) >> $OUT/${R}_pmc_sq_summary.txt <<'PY'
+import collections, csv, sys
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"].replace("s3d::", "").replace("void ", "").split("(")[0][:70]
+    agg.setdefault(n, collections.Counter())[r["Counter_Name"]] += float(r["Counter_Value"])
+print("LDS bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE):")
+for n, c in agg.items():
+    if c["SQ_LDS_IDX_ACTIVE"] > 0 and "conv" in n:
+        print(f"  {n:60s} {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']:.3f}")
+PY
 cd $ROOT
 # 4. the headline line (uses profiles/<round>_pmc_traffic.json as committed; copy the new one in first for the traffic field)
 cp $OUT/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
 python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench.json
-# 5. other configurations, training, decode
+python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench_driver_flags.json
+# 5. other configurations, the graph-replay experiment, training, decode
 python3 tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/${R}_other_configs.txt
+python3 tools/graph_experiment.py 2>/dev/null | grep "^{" > $OUT/${R}_graph_experiment.txt
 { python3 tools/bench_train.py 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
 { python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
-# 6. Winograd kernel alone, with per-block phase times
-[ -x tools/ub_wino_t ] && timeout 120 tools/ub_wino_t > $OUT/${R}_wino_ubench_raw.txt
+# 6. the 3x3 kernels alone
+[ -x tools/ub_wino24 ] && timeout 300 tools/ub_wino24 > $OUT/${R}_wino_ubench.txt
 ls -la $OUT

@@ -1,0 +1,57 @@
+// Stand-alone timing of the three 3x3 kernels on the network's layer shapes (tuning / profiles/r02_wino_ubench.txt):
+//   k_conv_wino4 (F(2x2), s3d_wino.hip), k_conv_wino24s and k_conv_wino24 (F(2x4), s3d_wino24.hip), random data, three square planes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino24_ubench.hip -o tools/ub_wino24
+#include "../sin3dm_amd/csrc/s3d_common.h"
+namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; }
+  size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
+#include "../sin3dm_amd/csrc/s3d_wino.hip"
+#include "../sin3dm_amd/csrc/s3d_wino24.hip"
+#include <cstdlib>
+using namespace s3d;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
+    const size_t npix = size_t(3) * hw * hw * B;
+    float *in, *wgt, *out, *res, *tab;
+    const size_t wsz = wino24_packed_floats(cout, cin);          // >= the F(2x2) image
+    CK(hipMalloc(&in, npix * cin * 4)); CK(hipMalloc(&wgt, 3 * wsz * 4)); CK(hipMalloc(&out, npix * cout * 4)); CK(hipMalloc(&res, npix * cout * 4));
+    CK(hipMalloc(&tab, size_t(B) * hw * 4 * cout * 4));
+    std::vector<float> h(npix * cin); for (auto& v : h) v = float(rand()) / RAND_MAX - 0.5f;
+    CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> hw_(3 * wsz); for (auto& v : hw_) v = float(rand()) / RAND_MAX - 0.5f;
+    CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(res, 0, npix * cout * 4)); CK(hipMemset(tab, 0, size_t(B) * hw * 4 * cout * 4));
+    const char* names[3] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px"};
+    const double frac[3] = {4.0 / 9, 1.0 / 3, 1.0 / 3};
+    for (int k = 0; k < 3; ++k) {
+        ConvArgs a; memset(&a, 0, sizeof a);
+        a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
+        for (int p = 0; p < 3; ++p) {
+            a.job[p].in = in + size_t(p) * hw * hw * B * cin; a.job[p].wgt = wgt + p * wsz;
+            a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
+            if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
+        }
+        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : launch_conv_wino24(a, 0)); };
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int i = 0; i < 3; ++i) launch();
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * npix;
+        int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
+        printf("%s cin=%4d cout=%4d hw=%3d B=%d extras=%d blocks=%5d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
+               names[k], cin, cout, hw, B, extras, blocks, us, fl / us / 1e6, fl * frac[k] / us / 1e6, fl * frac[k] / us / 1e6 / 157.3);
+    }
+    CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
+}
+int main() {
+    run(128, 128, 128, 1, 20, true);      // input_blocks.0 / output_blocks.1.0.out_layers.2
+    run(128, 256, 64, 1, 20, true);       // input_blocks.1.1.in_layers.2
+    run(256, 256, 64, 1, 20, true);       // the three half-resolution 256 -> 256 layers
+    run(384, 128, 128, 1, 20, true);      // output_blocks.1.0.in_layers.2
+    run(128, 128, 128, 8, 5, true);       // batch 8 (BASELINE config 3)
+    run(256, 256, 64, 8, 5, true);
+    run(384, 128, 256, 1, 5, true);       // (256,256,128)-sized planes (config 5), square stand-in
+    return 0;
+}
