@@ -128,9 +128,13 @@ class _TriplaneUNetBase(nn.Module):
                 self._synced, self._flat_dirty = stamp, False
             return lib
         if stamp != self._synced:
-            params = dict(self.named_parameters())
-            for name in self._param_names:
-                host = params[name].detach().to("cpu", th.float32).contiguous()
+            # only the tensors whose version moved travel to the host and into the handle (a stock optimizer that updates
+            # every parameter still re-sends all of them each step: training belongs on the flat path, _ensure_flat)
+            old = self._synced if self._synced is not None and len(self._synced) == len(stamp) else None
+            for i, name in enumerate(self._param_names):
+                if old is not None and old[i] == stamp[i]:
+                    continue
+                host = self._plist[i].detach().to("cpu", th.float32).contiguous()
                 shape = (C.c_int64 * host.dim())(*host.shape)
                 _lib.check(lib.s3d_unet_set_param(self._handle, name.encode(), C.c_void_p(host.data_ptr()), shape,
                                                   host.dim()))
