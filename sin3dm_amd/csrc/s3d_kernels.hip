@@ -271,24 +271,31 @@ struct GnFinArgs {
     int maxparts, nparts[3], nsub, subs_per_group;
     double count[3];      // elements per group = (C/32)*h*w
 };
-__global__ void k_gn_finalize(GnFinArgs a) {                   // one block per (group, plane, sample): 96 blocks at batch 1, not 3
-    __shared__ double sm[128][2];
+// fixed-order reduction of one double per thread over a 256-thread block: butterfly inside each wave (the same pairing for
+// every launch), then the four wave sums in wave order: bit-repeatable
+__device__ __forceinline__ double block_sum256(double v, double* sm4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (sm4[0] + sm4[1]) + (sm4[2] + sm4[3]);
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void k_gn_finalize(GnFinArgs a) {                   // one block per (group, plane, sample): 96 blocks at batch 1, not 3
+    __shared__ double sm4[4];
     const int g = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const double* base = a.part + (size_t(b) * 3 + p) * a.maxparts * a.nsub * 2;
     double S = 0, SS = 0;
     for (int k = 0; k < a.subs_per_group; ++k) {               // [sub][part]: a group's parts are contiguous
-        const double* row = base + (size_t(g) * a.subs_per_group + k) * a.maxparts * 2;
-        for (int part = tid; part < a.nparts[p]; part += 128) { S += row[2 * part]; SS += row[2 * part + 1]; }
+        const double2* row = reinterpret_cast<const double2*>(base + (size_t(g) * a.subs_per_group + k) * a.maxparts * 2);
+        for (int part = tid; part < a.nparts[p]; part += 256) { const double2 v = row[part]; S += v.x; SS += v.y; }
     }
-    sm[tid][0] = S; sm[tid][1] = SS;
-    __syncthreads();
-    for (int s = 64; s >= 1; s >>= 1) {                        // fixed tree: bit-repeatable
-        if (tid < s) { sm[tid][0] += sm[tid + s][0]; sm[tid][1] += sm[tid + s][1]; }
-        __syncthreads();
-    }
+    S = block_sum256(S, sm4);
+    SS = block_sum256(SS, sm4);
     if (tid == 0) {
-        const double m = sm[0][0] / a.count[p];
-        double var = sm[0][1] / a.count[p] - m * m;
+        const double m = S / a.count[p];
+        double var = SS / a.count[p] - m * m;
         if (var < 0) var = 0;
         float* o = a.mr + ((size_t(b) * 3 + p) * 32 + g) * 2;
         o[0] = float(m);
@@ -302,7 +309,7 @@ int launch_gn_finalize(const GnPartials& part, const Geo& g, int C, int B, GnSta
     a.subs_per_group = part.nsub / 32;
     for (int p = 0; p < 3; ++p) { a.nparts[p] = part.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
     if (!B) return 0;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(32, 3, B), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_gn_finalize, dim3(32, 3, B), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -426,27 +433,24 @@ struct GnFinCatArgs {
     int maxparts_u, maxparts_s, nparts_u[3], nparts_s[3], nsub_u, nsub_s, subs_per_group;
     double count[3];
 };
-__global__ void k_gn_finalize_cat(GnFinCatArgs a) {
-    __shared__ double sm[128][2];
+__global__ __launch_bounds__(256) void k_gn_finalize_cat(GnFinCatArgs a) {
+    __shared__ double sm4[4];
     const int g = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     double S = 0, SS = 0;
     for (int k = 0; k < a.subs_per_group; ++k) {
         const int sub = g * a.subs_per_group + k;
         const bool up = sub < a.nsub_u;
-        const double* row = up ? a.pu + (((size_t(b) * 3 + p) * a.nsub_u + sub) * a.maxparts_u) * 2
-                               : a.ps + (((size_t(b) * 3 + p) * a.nsub_s + (sub - a.nsub_u)) * a.maxparts_s) * 2;
+        const double2* row = reinterpret_cast<const double2*>(
+            up ? a.pu + (((size_t(b) * 3 + p) * a.nsub_u + sub) * a.maxparts_u) * 2
+               : a.ps + (((size_t(b) * 3 + p) * a.nsub_s + (sub - a.nsub_u)) * a.maxparts_s) * 2);
         const int n = up ? a.nparts_u[p] : a.nparts_s[p];
-        for (int part = tid; part < n; part += 128) { S += row[2 * part]; SS += row[2 * part + 1]; }
+        for (int part = tid; part < n; part += 256) { const double2 v = row[part]; S += v.x; SS += v.y; }
     }
-    sm[tid][0] = S; sm[tid][1] = SS;
-    __syncthreads();
-    for (int s = 64; s >= 1; s >>= 1) {
-        if (tid < s) { sm[tid][0] += sm[tid + s][0]; sm[tid][1] += sm[tid + s][1]; }
-        __syncthreads();
-    }
+    S = block_sum256(S, sm4);
+    SS = block_sum256(SS, sm4);
     if (tid == 0) {
-        const double m = sm[0][0] / a.count[p];
-        double var = sm[0][1] / a.count[p] - m * m;
+        const double m = S / a.count[p];
+        double var = SS / a.count[p] - m * m;
         if (var < 0) var = 0;
         float* o = a.mr + ((size_t(b) * 3 + p) * 32 + g) * 2;
         o[0] = float(m);
@@ -460,7 +464,7 @@ int launch_gn_finalize_cat(const GnPartials& pu, const GnPartials& ps, const Geo
     a.subs_per_group = (pu.nsub + ps.nsub) / 32;
     for (int p = 0; p < 3; ++p) { a.nparts_u[p] = pu.nparts[p]; a.nparts_s[p] = ps.nparts[p]; a.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
     if (!B) return 0;
-    hipLaunchKernelGGL(k_gn_finalize_cat, dim3(32, 3, B), dim3(128), 0, st, a);
+    hipLaunchKernelGGL(k_gn_finalize_cat, dim3(32, 3, B), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -711,11 +715,15 @@ struct MeanFinArgs {
     int C, cq, B;
     long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
 };
-__global__ void k_means_finalize(MeanFinArgs a) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.begin[6] * a.B) return;
-    const int b = int(i / a.begin[6]);
-    long long r = i % a.begin[6];
+__global__ __launch_bounds__(256) void k_means_finalize(MeanFinArgs a) {
+    // item = (vector, position, channel quad); four adjacent lanes share an item: lane k takes partials k, k+4, ... and the
+    // four sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch)
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    const int part0 = threadIdx.x & 3;
+    const bool live = i < a.begin[6] * a.B;
+    const long long ii = live ? i : 0;
+    const int b = int(ii / a.begin[6]);
+    long long r = ii % a.begin[6];
     int v = 0;
     while (r >= a.begin[v + 1]) ++v;
     r -= a.begin[v];
@@ -723,25 +731,22 @@ __global__ void k_means_finalize(MeanFinArgs a) {
     const int pos = int(r / a.cq), q = int(r % a.cq);
     const int h = a.h[p], w = a.w[p];
     float4 s = make_float4(0, 0, 0, 0);
-    if (!is_col) {
-        const int ntc = (w + kActCols - 1) / kActCols;
-        for (int t = 0; t < ntc; ++t) {
-            const float4 u = reinterpret_cast<const float4*>(a.rowpart[p] + ((size_t(b) * ntc + t) * h + pos) * a.C)[q];
-            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
-        }
-        const float inv = 1.0f / float(w);
-        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-        reinterpret_cast<float4*>(a.rowmean[p] + (size_t(b) * h + pos) * a.C)[q] = s;
-    } else {
-        const int ntr = (h + kActRows - 1) / kActRows;
-        for (int t = 0; t < ntr; ++t) {
-            const float4 u = reinterpret_cast<const float4*>(a.colpart[p] + ((size_t(b) * ntr + t) * w + pos) * a.C)[q];
-            s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
-        }
-        const float inv = 1.0f / float(h);
-        s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-        reinterpret_cast<float4*>(a.colmean[p] + (size_t(b) * w + pos) * a.C)[q] = s;
+    const int nt = is_col ? (h + kActRows - 1) / kActRows : (w + kActCols - 1) / kActCols;
+    const int len = is_col ? w : h;
+    const float* src = is_col ? a.colpart[p] : a.rowpart[p];
+    for (int t = part0; t < nt; t += 4) {
+        const float4 u = reinterpret_cast<const float4*>(src + ((size_t(b) * nt + t) * len + pos) * a.C)[q];
+        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
     }
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {
+        s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64); s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
+    }
+    if (!live || part0 != 0) return;
+    const float inv = 1.0f / float(is_col ? h : w);
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    float* dst = is_col ? a.colmean[p] : a.rowmean[p];
+    reinterpret_cast<float4*>(dst + (size_t(b) * len + pos) * a.C)[q] = s;
 }
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st) {
     MeanFinArgs a;
@@ -755,7 +760,7 @@ int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, Me
     }
     long long n = a.begin[6] * B;
     if (!n) return 0;
-    hipLaunchKernelGGL(k_means_finalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_means_finalize, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
