@@ -332,6 +332,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino24(ConvArgs args) {
 // Weights: [n32][k16][24 freq][2 x 16 couts][64 lanes][4], a six-deep register ring of 1 KB fragments, each requested half a
 // step before its use.  The A operands of the next step overwrite the current ones frequency by frequency as soon as their
 // MFMAs have been issued.
+#ifdef W24_TIMING
+__device__ unsigned long long* g_w24time;     // tools/wino24_ubench.hip: per-block wall-clock stamps (entry, halo in LDS, first MFMA, last MFMA, images written, exit)
+#define W24_STAMP(k) if (threadIdx.x == 0) g_w24time[size_t(blockIdx.x) * 8 + (k)] = wall_clock64();
+#else
+#define W24_STAMP(k)
+#endif
 constexpr int C_KC = 32, C_LD = C_KC + 4;
 constexpr int C_TH = 8, C_TW = 16;
 constexpr int C_HH = C_TH + 2, C_HW = C_TW + 2;
@@ -343,6 +349,7 @@ constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image 
 __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
     __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];             // 51.8 KB: two halo buffers; four share images after the loop
     static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
+    W24_STAMP(0)
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     int bid = blockIdx.x;
     if (args.xcd_swizzle & 1) {
@@ -411,14 +418,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
     f32x4 V[6], ring[6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) { ring[s] = wfrag(0, s); __builtin_amdgcn_sched_barrier(0); }
+    // chunk 0 into buffer 0, then the barrier; the first half of chunk 1 is requested with it but lands in buffer 1 only
+    // after the first operands are built (the barrier of step (0,0) publishes it): it is off the prologue's critical path
+    f32x4 pre[3];
     {
         const int c1 = nchunks > 1 ? 1 : 0;
+        f32x4 h0[C_ITEMS_PT];
 #pragma unroll
-        for (int it = 0; it < C_ITEMS_PT; ++it) item_store(it, 0, item_load(it, 0));
+        for (int it = 0; it < C_ITEMS_PT; ++it) h0[it] = item_load(it, 0);
 #pragma unroll
-        for (int it = 0; it < 3; ++it) item_store(it, 1, item_load(it, c1));
+        for (int it = 0; it < 3; ++it) pre[it] = item_load(it, c1);
+#pragma unroll
+        for (int it = 0; it < C_ITEMS_PT; ++it) item_store(it, 0, h0[it]);
     }
     __syncthreads();
+    W24_STAMP(1)
 #define C_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
 #define C_PIN(v) asm volatile("" : "+v"(v))
     {
@@ -435,6 +449,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
         V[3] = s3 + 2.f * s4; V[4] = s3 - 2.f * s4;
         V[5] = 4.f * t[1] + (t[5] - 5.f * t[3]);
     }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) item_store(it, 1, pre[it]);
 
     // One k-step (16 channels) = 12 groups {four MFMAs on one A operand + a piece of the other work}, pinned.
 #define C_GROUP(F, NB, WORK)                                                                                          \
@@ -484,6 +500,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
 
     int cur = 0;                                  // byte offset of the buffer that holds the current chunk
     const int tog = C_ABUF * 4;
+    W24_STAMP(2)
     __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cn1 = chunk + 1 < nchunks ? chunk + 1 : nchunks - 1;
@@ -498,8 +515,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
 #undef C_LDS4
 #undef C_PIN
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
-    __syncthreads();                                     // all patch reads and halo stores of the last step are done
-
+    W24_STAMP(3)
     // ---- epilogue: as k_conv_wino24; lane (g, t16) holds output channel nb*16 + t16 of the tiles (tile row g, tile column r)
     const float* __restrict__ p_bias = J.bias;
     const float* __restrict__ p_bbias = J.bbias;
@@ -508,18 +524,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
     const float* __restrict__ p_res = J.res;
     float* __restrict__ p_out = J.out;
     double* p_gn = J.gn_part;
-    {
-        float* img = smem + u * C_IMG + t16;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r], m4 = acc[4][nb][r], m5 = acc[5][nb][r];
-                const float p = m1 + m2, q = m1 - m2, rr = m3 + m4, s = m3 - m4;
-                const int pp = (g * C_TW + 4 * r) * 32 + nb * 16;
-                img[pp] = (m0 + p) + rr; img[pp + 32] = fmaf(2.f, s, q); img[pp + 64] = fmaf(4.f, rr, p); img[pp + 96] = fmaf(8.f, s, q) + m5;
-            }
-    }
+    // the finishing threads' operands (bias, rank-1 tables, residual) are requested BEFORE the barrier and the share-image
+    // writes: their L2/HBM latency runs beside both (2.3 -> 1.6 us for this phase)
     const int quad = tid & 7, xl = (tid >> 3) & 15, rsel = tid >> 7;
     const int co4 = n32 * 32 + quad * 4;
     const bool c_ok = co4 < cout;
@@ -560,7 +566,22 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
             tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
         }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                     // all patch reads and halo stores of the last step are done
+    {
+        float* img = smem + u * C_IMG + t16;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r], m4 = acc[4][nb][r], m5 = acc[5][nb][r];
+                const float p = m1 + m2, q = m1 - m2, rr = m3 + m4, s = m3 - m4;
+                const int pp = (g * C_TW + 4 * r) * 32 + nb * 16;
+                img[pp] = (m0 + p) + rr; img[pp + 32] = fmaf(2.f, s, q); img[pp + 64] = fmaf(4.f, rr, p); img[pp + 96] = fmaf(8.f, s, q) + m5;
+            }
+    }
     __syncthreads();                                     // the share images are complete
+    W24_STAMP(4)
     f32x4 gs4 = zero4, gss4 = zero4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -598,6 +619,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
             }
         }
     }
+    W24_STAMP(5)
 }
 
 // ------------------------------------------------------------------ host side

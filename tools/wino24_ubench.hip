@@ -9,6 +9,9 @@ namespace s3d { void set_error(const char*, ...) {} const char* get_error() { re
 #include <cstdlib>
 using namespace s3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#ifdef W24_TIMING
+static unsigned long long* g_tb = nullptr;
+#endif
 static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     const size_t npix = size_t(3) * hw * hw * B;
     float *in, *wgt, *out, *res, *tab;
@@ -40,12 +43,36 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * npix;
         int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
+#ifdef W24_TIMING
+        if (k == 1) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
+            unsigned long long* tb = g_tb;
+            launch(); CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> t(size_t(blocks) * 8);
+            CK(hipMemcpy(t.data(), tb, t.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t5 = 0;
+            for (int i = 0; i < blocks; ++i) { t0 = std::min(t0, t[i * 8]); t5 = std::max(t5, t[i * 8 + 5]); }
+            double ph[2][5] = {{0}}; int n[2] = {0, 0};
+            for (int i = 0; i < blocks; ++i) {
+                const int late = (t[i * 8] - t0) > 300;
+                for (int q = 0; q < 5; ++q) ph[late][q] += (t[i * 8 + q + 1] - t[i * 8 + q]) * 0.01;
+                ++n[late];
+            }
+            printf("    wino24s phases, span %.1f us:", (t5 - t0) * 0.01);
+            for (int l = 0; l < 2; ++l)
+                if (n[l]) printf("  [%s %d blocks] halo->LDS %.1f | first operands %.1f | k-loop %.1f | barrier + share images + operand loads %.1f | finish + stores %.1f us",
+                                 l ? "later" : "first-wave", n[l], ph[l][0] / n[l], ph[l][1] / n[l], ph[l][2] / n[l], ph[l][3] / n[l], ph[l][4] / n[l]);
+            printf("\n");
+        }
+#endif
         printf("%s cin=%4d cout=%4d hw=%3d B=%d extras=%d blocks=%5d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
                names[k], cin, cout, hw, B, extras, blocks, us, fl / us / 1e6, fl * frac[k] / us / 1e6, fl * frac[k] / us / 1e6 / 157.3);
     }
     CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
 int main() {
+#ifdef W24_TIMING
+    CK(hipMalloc(&g_tb, size_t(1 << 16) * 64)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_w24time), &g_tb, sizeof g_tb));
+#endif
     run(128, 128, 128, 1, 20, true);      // input_blocks.0 / output_blocks.1.0.out_layers.2
     run(128, 256, 64, 1, 20, true);       // input_blocks.1.1.in_layers.2
     run(256, 256, 64, 1, 20, true);       // the three half-resolution 256 -> 256 layers
