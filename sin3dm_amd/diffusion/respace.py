@@ -115,18 +115,19 @@ class _WrappedModel:
         one batched launch — instead of a host-to-device copy and three small launches on the first visit of every index."""
         key = str(device)
         sched = ("schedule", key, batch)
-        if sched in self._maps:
-            return
-        vals = [self._mapped(i) for i in range(num_timesteps)]
-        col = th.tensor(vals, device=device, dtype=th.float32)
-        rows = col[:, None].expand(-1, batch).contiguous()
-        for i, v in enumerate(vals):
-            hv = (v,) * batch
-            self._maps[(key, hv)] = HostTimesteps(rows[i], hv)
-        self._maps[sched] = rows
+        entry = self._maps.get(sched)
+        if entry is None:
+            vals = [self._mapped(i) for i in range(num_timesteps)]
+            col = th.tensor(vals, device=device, dtype=th.float32)
+            rows = col[:, None].expand(-1, batch).contiguous()
+            for i, v in enumerate(vals):
+                hv = (v,) * batch
+                self._maps[(key, hv)] = HostTimesteps(rows[i], hv)
+            entry = self._maps[sched] = (vals, col, rows)
+        # the timestep tables themselves are recomputed for every loop (= every sample): batched, not carried over
         prep = getattr(self.model, "prepare_timesteps", None)
         if prep is not None:
-            prep(vals, col)
+            prep(entry[0], entry[1])
 
     def __getattr__(self, name):          # forward_train / backward_flat / flat_parameters of the wrapped denoiser
         return getattr(self.__dict__["model"], name)

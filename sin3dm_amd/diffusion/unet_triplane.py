@@ -289,13 +289,13 @@ class _TriplaneUNetBase(nn.Module):
         return out
 
     def prepare_timesteps(self, values, t_dev):
-        """The FiLM tables of a whole schedule (host values + the same values on the device) in one batched launch; the
-        sampling loops call this before their first step.  Remembered, so that a weight update refills the cache in one go."""
+        """The FiLM tables of a whole schedule (host values + the same values on the device) in one batched launch (three
+        linears over len(values) rows); the sampling loops call this at the start of EVERY loop, i.e. once per sample: the
+        per-step work is batched and hoisted, not carried over between samples.  Remembered, so that a weight update in the
+        middle of a loop refills the cache in one go."""
         self._film_sched = (tuple(values), t_dev)
         lib = self._ensure_handle()
         dkey = str(t_dev.device)
-        if all((dkey, v) in self._film_cache for v in values):
-            return
         width = lib.s3d_unet_film_width(self._handle)
         t = t_dev.to(th.float32).contiguous()
         film = th.empty((len(values), width), device=t.device, dtype=th.float32)
