@@ -536,3 +536,28 @@ def test_host_known_timesteps_change_nothing():
         after_h = diff.p_sample(model, x, HostTimesteps(t, (3, 3)), model_kwargs=kw)["sample"]
         after_p = diff.p_sample(model, x, t, model_kwargs=kw)["sample"]
     assert torch.equal(after_h, after_p) and not torch.equal(before, after_h)
+
+
+def test_config1_towerruins64_ddim10_whole_run(oracle):
+    """BASELINE configs[0] end to end on the diffusion side: the default 64-ch UNet on the towerruins triplane at
+    --fm_reso 64, (H,W,D) = (46,64,46), a whole DDIM-10 run (respacing "10": timesteps 0, 111, ..., 999) through
+    ddim_sample_loop against the CPU port of the reference stepping the same chain; eta = 0, so the only random input
+    is x_T.  The corner must end at exactly 0."""
+    sys_path_oracle()
+    import torch_port as tp
+    mc, (H, W, D) = 64, (46, 64, 46)
+    kw = dict(H=H, W=W, D=D)
+    sd = T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0)
+    model = make_model(mc)
+    diff = make_diffusion("10")
+    tab, tmap = oracle.schedule_tables(sorted(diff.use_timesteps))
+    assert list(tmap) == [0, 111, 222, 333, 444, 555, 666, 777, 888, 999]
+    xT = torch.from_numpy(T.synthetic_noise((1, 12, H + D, W + D), 91))
+    with torch.no_grad():
+        got = diff.ddim_sample_loop(model, tuple(xT.shape), noise=xT.to(dev()), model_kwargs=kw)
+        x = xT.clone()
+        for i in range(9, -1, -1):
+            out = tp.unet_forward(sd, x, torch.tensor([float(tmap[i])]), H, W, D, mc)
+            x, _ = tp_ddim(out, x, tab, i)
+    assert relerr(got.cpu().numpy(), x.numpy()) < TOL_FWD
+    assert float(got[..., H:, W:].abs().max()) == 0.0
