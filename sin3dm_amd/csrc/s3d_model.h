@@ -279,9 +279,9 @@ struct Fwd {
         hipStream_t st = on ? on : this->st;
         out = alloc_tri(cw.cout, y.g);
         if (!(cw.k == 3 && !conv_use_naive())) want_stats = 0;
-        // the mixed Winograd kernel serves the inference forward; the training tier (forward_train + dgrad) stays on the
-        // F(2x2) kernels, whose transposed operators the backward pass has
-        const int w24 = cw.k == 3 && !tape && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout) : 0;
+        // the mixed Winograd kernel serves every forward (the tape keeps activations, not conv internals); dgrad stays on
+        // the F(2x2) kernels, whose transposed operators the backward pass has
+        const int w24 = cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout) : 0;
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);
