@@ -58,11 +58,13 @@ struct Tape {
 struct ConvWT {
     size_t dense_T[3] = {0, 0, 0};    // [taps][cin][cout], taps flipped: dgrad as a forward convolution
     size_t wino_T[3] = {0, 0, 0};     // the same operator in Winograd fragment order (3x3 only)
+    size_t wino24s_T[3] = {0, 0, 0};  // ... and in the mixed F(2x4) order of k_conv_wino24s
+    bool has_wino24s_T = false;
     size_t rrow_T[3] = {0, 0, 0};     // [3 taps][cin][3*cout]: d(row-varying mean vector) from the row sums of dy
     size_t rcol_T[3] = {0, 0, 0};
 };
 struct ResBlockWT { ConvWT c1, c2, skip; };
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD };
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD, PK_WINO24S_T };
 struct PackDesc {                     // one device-side repacking job: flat reference-layout parameter -> packed image
     int kind, cout, ctot, cin, slot, taps, col_varying, to_tbuf;
     long long src, dst, n;

@@ -89,12 +89,17 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
                 }
             break;
         }
+        case PK_WINO24S_T:
         case PK_WINO24S:
-        case PK_WINO24: {                        // item = one (cout, cin) filter: G2 g G4^T, fragment order [n32][k8][24][64][4] / [n32][k16][24][2][64][4]
-            const int n = int(i / cin), k = int(i % cin);
+        case PK_WINO24: {                        // item = one (n, k) filter: G2 g G4^T, fragment order [n32][k8][24][64][4] / [n32][k16][24][2][64][4]
+            // operator dims as in PK_WINO: forward N = cout, K = cin; transposed (dgrad) N = cin, K = cout, taps flipped
+            const bool tr = d.kind == PK_WINO24S_T;
+            const int K = tr ? cout : cin;
+            const int n = int(i / K), k = int(i % K);
             double g[9];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) g[q] = double(W[((size_t)n * ctot + k) * 9 + q]);
+            for (int q = 0; q < 9; ++q)
+                g[q] = tr ? double(W[((size_t)k * ctot + n) * 9 + (8 - q)]) : double(W[((size_t)n * ctot + k) * 9 + q]);
             const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                      {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) t[u][q] = G2[u][0] * g[0 * 3 + q] + G2[u][1] * g[1 * 3 + q] + G2[u][2] * g[2 * 3 + q];
-            const int k8t = cin / 8;
+            const int k8t = K / 8;
             const int nt = n >> 5, jn = n & 31, k8 = k >> 3, hf = (k >> 2) & 1, e = k & 3;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
                 for (int v = 0; v < 6; ++v) {
                     const double uv = fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2]));       // as pack_wino24_weights
                     if (d.kind == PK_WINO24) dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
-                    else dst[(((((size_t)nt * (cin / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
+                    else dst[(((((size_t)nt * (K / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
                 }
             break;
         }
@@ -176,6 +181,11 @@ struct Plan {
                 // transposed operator: cin outputs (padded to 32) x cout inputs
                 wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
                 add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
+                if (cw.wino24s[p] && cout % 32 == 0) {          // dgrad through k_conv_wino24s: K = cout in 32-channel chunks
+                    wt.wino24s_T[p] = talloc(wino24_packed_floats(cin, cout));
+                    wt.has_wino24s_T = true;
+                    add(PK_WINO24S_T, w, wt.wino24s_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
+                }
             }
             if (!cw.rollout) continue;
             const bool a_is_col = (p == 0);

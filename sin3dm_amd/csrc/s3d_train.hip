@@ -52,6 +52,7 @@ struct Bwd {
                 for (int p = 0; p < 3; ++p) {
                     ConvJob& J = ca.job[p];
                     J.in = dy.p[p]; J.wgt = m->tdev(wt.dense_T[p]); J.wgt_wino = cw.k == 3 ? m->tdev(wt.wino_T[p]) : nullptr;
+                    J.wgt_wino24s = cw.k == 3 && wt.has_wino24s_T ? m->tdev(wt.wino24s_T[p]) : nullptr;
                     J.res = res ? res->p[p] : nullptr; J.out = d_a->p[p]; J.h = g.h[p]; J.w = g.w[p];
                 }
                 S3D_TRY(launch_conv(cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
