@@ -84,6 +84,7 @@ __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
     // All (sample, plane) partial sums are accumulated first (independent loads in flight), then reduced over the lanes
     // through LDS in lane order, four samples at a time.
     __shared__ float sm[12][kBiasLanes][kBiasCh];
+    __shared__ float sm2[12][kBiasCh];
     const int cl = threadIdx.x % kBiasCh, lane = threadIdx.x / kBiasCh, co = blockIdx.x * kBiasCh + cl;
     float tot_p[3] = {0.f, 0.f, 0.f};
     for (int b0 = 0; b0 < a.B; b0 += 4) {
@@ -106,12 +107,20 @@ __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) sm[bb * 3 + p][lane][cl] = s[bb][p];
         __syncthreads();
+        // one thread per (sample, plane, channel) adds the row lanes in lane order; then one per channel combines the planes
+        if (threadIdx.x < 12 * kBiasCh) {
+            const int bp = threadIdx.x / kBiasCh, c2 = threadIdx.x % kBiasCh;
+            float t = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < kBiasLanes; ++k) t += sm[bp][k][c2];
+            sm2[bp][c2] = t;
+        }
+        __syncthreads();
         if (lane == 0 && co < a.C)
             for (int bb = 0; bb < nb; ++bb) {
                 float tot = 0.f;
                 for (int p = 0; p < 3; ++p) {
-                    float t = 0.f;
-                    for (int k = 0; k < kBiasLanes; ++k) t += sm[bb * 3 + p][k][cl];
+                    const float t = sm2[bb * 3 + p][cl];
                     tot += t; tot_p[p] += t;
                 }
                 if (a.per_sample) a.per_sample[size_t(b0 + bb) * a.per_sample_stride + co] = tot;
@@ -518,13 +527,20 @@ static bool wgrad_use_wino() {
 }
 
 struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
-__global__ void k_wgrad_reduce(WgRedArgs a) {
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgRedArgs a) {
+    // block = 64 items x 4 slice lanes (lane j adds slices j, j+4, ...; the four sums meet through LDS in lane order)
+    __shared__ float red[4][64];
     const long long n = (long long)a.cout * a.cin * a.taps;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const int p = blockIdx.y;
+    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int p = blockIdx.y, kl = threadIdx.x >> 6, l = threadIdx.x & 63;
     float s = 0.f;
-    for (int k = 0; k < a.ksplit; ++k) s += a.part[p][size_t(k) * n + idx];
+    if (idx < n)
+#pragma unroll 4
+        for (int k = kl; k < a.ksplit; k += 4) s += a.part[p][size_t(k) * n + idx];
+    red[kl][l] = s;
+    __syncthreads();
+    if (kl != 0 || idx >= n) return;
+    s = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
     const int t = int(idx % a.taps);
     const long long r = idx / a.taps;
     const int ci = int(r % a.cin), co = int(r / a.cin);
@@ -610,7 +626,7 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.taps = w.taps;
     r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin;
     const long long n = (long long)w.cout * w.cin * w.taps;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 255) / 256), w.nplanes), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((n + 63) / 64), w.nplanes), dim3(256), 0, st, r);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -725,6 +741,7 @@ __global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
     }
     a.A[size_t(idx) * 2] = float(s1); a.A[size_t(idx) * 2 + 1] = float(s2);
 }
+// (measured: folding k_gn_bwd_sum into this single block costs 16.5 us against 5.0 + 6.3 for the two launches)
 __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
     const int C = a.C, G = a.ngroups, cg = C / G;
     // (1) group coefficients
@@ -893,8 +910,8 @@ __global__ __launch_bounds__(256) void k_small_outer(SmallArgs a) {
     const int S = a.S;
     const int chunk = blockIdx.x, p = blockIdx.y;
     const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
-    const long long npix = (long long)a.B * h * w;
-    const long long p0 = npix * chunk / kSmallChunks, p1 = npix * (chunk + 1) / kSmallChunks;
+    const int hw = h * w, npix = a.B * hw;               // (checked below 2^31 by the launcher)
+    const int p0 = int((long long)npix * chunk / kSmallChunks), p1 = int((long long)npix * (chunk + 1) / kSmallChunks);
     const int C = a.C, q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
     float acc[SM][4], vs[4] = {0, 0, 0, 0}, wt[SM][4], ssum[SM];
 #pragma unroll
@@ -907,15 +924,23 @@ __global__ __launch_bounds__(256) void k_small_outer(SmallArgs a) {
         }
     }
     const size_t ostride = size_t(a.H + a.D) * (a.W + a.D);
-    for (long long i = p0 + l; i < p1; i += a.pl) {
-        const int b = int(i / ((long long)h * w));
-        const long long pq = i % ((long long)h * w);
-        const int r = int(pq / w), c = int(pq % w);
-        float sv[SM];
+    // one-deep software pipeline: the thirteen loads of the next pixel are in flight during this pixel's FMAs
+    auto fetch = [&](int i, float (&sv)[SM], float4& v) {
+        i = min(i, p1 - 1);
+        const int b = i / hw, pq = i - b * hw;
+        const int r = pq / w, c = pq - r * w;
         const size_t base = composed_index(p, a.H, a.W, a.D, S, b, 0, r, c);
 #pragma unroll
         for (int o = 0; o < SM; ++o) sv[o] = o < S ? a.s[base + o * ostride] : 0.f;
-        const float4 v = reinterpret_cast<const float4*>(a.v[p])[size_t(i) * a.cq + q];
+        v = reinterpret_cast<const float4*>(a.v[p])[size_t(i) * a.cq + q];
+    };
+    float sv[SM];
+    float4 v = make_float4(0, 0, 0, 0);
+    if (p0 + l < p1) fetch(p0 + l, sv, v);
+    for (int i = p0 + l; i < p1; i += a.pl) {
+        float svn[SM];
+        float4 vn;
+        fetch(i + a.pl, svn, vn);
         const float vv[4] = {v.x, v.y, v.z, v.w};
         float dv[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -927,28 +952,46 @@ __global__ __launch_bounds__(256) void k_small_outer(SmallArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) vs[k] += vv[k];
         if (a.dv[p]) reinterpret_cast<float4*>(a.dv[p])[size_t(i) * a.cq + q] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+#pragma unroll
+        for (int o = 0; o < SM; ++o) sv[o] = svn[o];
+        v = vn;
     }
-    float* sms = sm_so + size_t(a.pl) * (S + 1) * C;
+    // pixel lanes that share a wave meet by xor-shuffles first (a wave holds 64/cq of them), so LDS carries one partial per
+    // wave (13 KB instead of 54 KB at 64 channels: the block count per CU was LDS-bound)
+    const int lw = (a.cq < 64 && 64 % a.cq == 0) ? 64 / a.cq : 1, ng = a.pl / lw, grp = l / lw;
+    for (int off = a.cq; lw > 1 && off < 64; off <<= 1) {
 #pragma unroll
-    for (int o = 0; o < SM; ++o)
-        if (o < S) {
+        for (int o = 0; o < SM; ++o) {
+            ssum[o] += __shfl_xor(ssum[o], off, 64);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) sm_so[(size_t(l) * (S + 1) + o) * C + 4 * q + k] = acc[o][k];
-            if (q == 0) sms[l * S + o] = ssum[o];
+            for (int k = 0; k < 4; ++k) acc[o][k] += __shfl_xor(acc[o][k], off, 64);
         }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sm_so[(size_t(l) * (S + 1) + S) * C + 4 * q + k] = vs[k];
+        for (int k = 0; k < 4; ++k) vs[k] += __shfl_xor(vs[k], off, 64);
+    }
+    float* sms = sm_so + size_t(ng) * (S + 1) * C;
+    if (l % lw == 0) {
+#pragma unroll
+        for (int o = 0; o < SM; ++o)
+            if (o < S) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sm_so[(size_t(grp) * (S + 1) + o) * C + 4 * q + k] = acc[o][k];
+                if (q == 0) sms[grp * S + o] = ssum[o];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm_so[(size_t(grp) * (S + 1) + S) * C + 4 * q + k] = vs[k];
+    }
     __syncthreads();
     float* part = a.part + (size_t(p) * kSmallChunks + chunk) * (S + 1) * C;
     for (int i = threadIdx.x; i < (S + 1) * C; i += blockDim.x) {
         float s = 0.f;
-        for (int ll = 0; ll < a.pl; ++ll) s += sm_so[size_t(ll) * (S + 1) * C + i];
+        for (int g = 0; g < ng; ++g) s += sm_so[size_t(g) * (S + 1) * C + i];
         part[i] = s;
     }
     float* sp = a.part + size_t(3) * kSmallChunks * (S + 1) * C + (size_t(p) * kSmallChunks + chunk) * S;
     if (int(threadIdx.x) < S) {
         float s = 0.f;
-        for (int ll = 0; ll < a.pl; ++ll) s += sms[ll * S + threadIdx.x];
+        for (int g = 0; g < ng; ++g) s += sms[g * S + threadIdx.x];
         sp[threadIdx.x] = s;
     }
 }
@@ -957,22 +1000,33 @@ struct SmallRedArgs {
     float* outer[3]; int outer_transposed;   // 0: outer[p][o*C + c] ; 1: outer[p][c*S + o]
     float* ssum[3]; float* vsum[3];          // optional
 };
-__global__ void k_small_reduce(SmallRedArgs a) {
+__global__ __launch_bounds__(256) void k_small_reduce(SmallRedArgs a) {
+    // block = 64 items x 4 chunk lanes: lane j adds chunks j, j+4, ... (double), the four sums meet through LDS in lane order
+    __shared__ double red[4][64];
     const int p = blockIdx.y, S = a.S, C = a.C;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (S + 1) * C) {
+    const int idx = blockIdx.x * 64 + (threadIdx.x & 63), kl = threadIdx.x >> 6;
+    const int n_outer = (S + 1) * C, n_all = n_outer + S;
+    double s = 0;
+    if (idx < n_outer) {
         const int o = idx / C, c = idx % C;
-        double s = 0;
-        for (int k = 0; k < kSmallChunks; ++k) s += a.part[((size_t(p) * kSmallChunks + k) * (S + 1) + o) * C + c];
+#pragma unroll 8
+        for (int k = kl; k < kSmallChunks; k += 4) s += a.part[((size_t(p) * kSmallChunks + k) * (S + 1) + o) * C + c];
+    } else if (idx < n_all) {
+        const int o = idx - n_outer;
+#pragma unroll 8
+        for (int k = kl; k < kSmallChunks; k += 4)
+            s += a.part[size_t(3) * kSmallChunks * n_outer + (size_t(p) * kSmallChunks + k) * S + o];
+    }
+    red[kl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (kl != 0 || idx >= n_all) return;
+    const int l = threadIdx.x & 63;
+    s = ((red[0][l] + red[1][l]) + red[2][l]) + red[3][l];
+    if (idx < n_outer) {
+        const int o = idx / C, c = idx % C;
         if (o < S) a.outer[p][a.outer_transposed ? size_t(c) * S + o : size_t(o) * C + c] = float(s);
         else if (a.vsum[p]) a.vsum[p][c] = float(s);
-    } else if (idx < (S + 1) * C + S && a.ssum[p]) {
-        const int o = idx - (S + 1) * C;
-        double s = 0;
-        for (int k = 0; k < kSmallChunks; ++k)
-            s += a.part[size_t(3) * kSmallChunks * (S + 1) * C + (size_t(p) * kSmallChunks + k) * S + o];
-        a.ssum[p][o] = float(s);
-    }
+    } else if (a.ssum[p]) a.ssum[p][idx - n_outer] = float(s);
 }
 size_t small_outer_ws_floats(int S, int C) { return size_t(3) * kSmallChunks * ((S + 1) * C + S); }
 int launch_small_outer(const SmallOuter& s, hipStream_t st) {
@@ -982,13 +1036,14 @@ int launch_small_outer(const SmallOuter& s, hipStream_t st) {
     a.s = s.s; a.Wt = s.Wt; a.part = s.ws; a.H = s.H; a.W = s.W; a.D = s.D; a.S = s.S; a.C = s.C; a.B = s.B;
     a.cq = s.C / 4; a.pl = a.cq >= 256 ? 1 : 256 / a.cq;
     for (int p = 0; p < 3; ++p) { a.v[p] = s.v.p[p]; a.dv[p] = s.dv ? s.dv->p[p] : nullptr; }
-    const size_t shm = size_t(a.pl) * ((s.S + 1) * s.C + s.S) * sizeof(float);
+    S3D_CHECK((long long)s.B * std::max(s.H, s.W) * std::max(s.W, s.D) < (1LL << 31), S3D_ERR_INVALID, "small_outer: batch x plane exceeds 2^31 pixels");
+    const size_t shm = size_t((a.cq < 64 && 64 % a.cq == 0) ? a.pl / (64 / a.cq) : a.pl) * ((s.S + 1) * s.C + s.S) * sizeof(float);
     hipLaunchKernelGGL(k_small_outer, dim3(kSmallChunks, 3), dim3(a.cq * a.pl), shm, st, a);
     S3D_HIP(hipGetLastError());
     SmallRedArgs r;
     r.part = s.ws; r.S = s.S; r.C = s.C; r.outer_transposed = s.outer_transposed;
     for (int p = 0; p < 3; ++p) { r.outer[p] = s.outer[p]; r.ssum[p] = s.ssum ? s.ssum[p] : nullptr; r.vsum[p] = s.vsum ? s.vsum[p] : nullptr; }
-    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv((s.S + 1) * s.C + s.S, 256), 3), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(k_small_reduce, dim3(cdiv((s.S + 1) * s.C + s.S, 64), 3), dim3(256), 0, st, r);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -1116,22 +1171,25 @@ __global__ void k_linear_bwd_w(const float* __restrict__ dy, int dy_stride, cons
     dW[idx] = s;
     if (i == 0) db[o] = sb;
 }
-// dx[b][i] = (sum_o dy[b][o] * W[o][i]) * (in_mode == 1 ? silu'(in[b][i]) : 1); block = (b, 32 inputs) x 8 output lanes
-__global__ __launch_bounds__(256) void k_linear_bwd_x(const float* __restrict__ dy, int dy_stride, const float* __restrict__ W,
-                                                      const float* __restrict__ in, int B, int I, int O, int in_mode,
-                                                      float* __restrict__ dx) {
-    __shared__ float sm[8][32];
+// dx[b][i] = (sum_o dy[b][o] * W[o][i]) * (in_mode == 1 ? silu'(in[b][i]) : 1); block = (b, 32 inputs) x 32 output lanes
+// (the FiLM projection has O = a few thousand outputs for 32 (b, input tile) blocks: the lanes split that loop, added in
+// lane order through LDS)
+constexpr int kLinBwdLanes = 32;
+__global__ __launch_bounds__(32 * kLinBwdLanes) void k_linear_bwd_x(const float* __restrict__ dy, int dy_stride, const float* __restrict__ W,
+                                                                    const float* __restrict__ in, int B, int I, int O, int in_mode,
+                                                                    float* __restrict__ dx) {
+    __shared__ float sm[kLinBwdLanes][32];
     const int il = threadIdx.x & 31, ol = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + il, b = blockIdx.y;
     float s = 0.f;
     if (i < I)
-        for (int o = ol; o < O; o += 8) s = fmaf(dy[size_t(b) * dy_stride + o], W[size_t(o) * I + i], s);
+        for (int o = ol; o < O; o += kLinBwdLanes) s = fmaf(dy[size_t(b) * dy_stride + o], W[size_t(o) * I + i], s);
     sm[ol][il] = s;
     __syncthreads();
     if (ol == 0 && i < I) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][il];
+        for (int k = 0; k < kLinBwdLanes; ++k) t += sm[k][il];
         if (in_mode == 1) {
             const float v = in[size_t(b) * I + i], sg = 1.0f / (1.0f + expf(-v));
             t *= sg * (1.0f + v * (1.0f - sg));
@@ -1147,7 +1205,7 @@ int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, in
         S3D_HIP(hipGetLastError());
     }
     if (dx) {
-        hipLaunchKernelGGL(k_linear_bwd_x, dim3(cdiv(I, 32), B), dim3(256), 0, st, dy, dy_stride, W, in, B, I, O, in_mode, dx);
+        hipLaunchKernelGGL(k_linear_bwd_x, dim3(cdiv(I, 32), B), dim3(32 * kLinBwdLanes), 0, st, dy, dy_stride, W, in, B, I, O, in_mode, dx);
         S3D_HIP(hipGetLastError());
     }
     return 0;

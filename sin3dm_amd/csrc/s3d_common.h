@@ -198,6 +198,8 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st);
 double wino_exec_fraction();
 // mixed Winograd F(2x4,3x3) (s3d_wino24.hip): the default 3x3 kernel of the inference forward (S3D_WINO=4 / 2 / 0 select the others)
 bool conv_use_wino24();
+bool conv_wino24_big_enabled();                     // S3D_WINO24_BIG_MIN_BLOCKS set: the 16x16-pixel variant may be chosen
+bool conv_wino24_channels(int cin, int cout);       // the mixed kernel takes every 3x3 launch of these widths
 // which mixed kernel these planes / channels (not the batch size) take: 0 none (F(2x2)), 1 the 8x16-pixel form, 2 the 16x16-pixel form
 int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout);
 void wino24_gn_parts(const Geo& g, int nparts[3]);

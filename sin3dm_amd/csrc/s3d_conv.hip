@@ -595,9 +595,15 @@ static long long count_tiles(const ConvArgs& a) {
 // the 16x16-pixel kernel (two blocks per CU, half the halo and weight traffic per flop) takes over from
 // S3D_WINO24_BIG_MIN_BLOCKS per-sample blocks of its own size.  The choice must not depend on the batch size: a sample's
 // result may not depend on what it is batched with.
+static long long wino24_big_min() {
+    static const long long v = getenv("S3D_WINO24_BIG_MIN_BLOCKS") ? atoll(getenv("S3D_WINO24_BIG_MIN_BLOCKS")) : (1LL << 60);
+    return v;
+}
+bool conv_wino24_big_enabled() { return conv_use_wino24() && wino24_big_min() < (1LL << 60); }
+bool conv_wino24_channels(int cin, int cout) { return conv_use_wino24() && cout % 4 == 0 && cin % 32 == 0; }
 int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout) {
-    if (!(conv_use_wino24() && cout % 4 == 0 && cin % 32 == 0)) return 0;
-    static const long long big_min = getenv("S3D_WINO24_BIG_MIN_BLOCKS") ? atoll(getenv("S3D_WINO24_BIG_MIN_BLOCKS")) : (1LL << 60);
+    if (!conv_wino24_channels(cin, cout)) return 0;
+    const long long big_min = wino24_big_min();
     long long blocks = 0;
     for (int j = 0; j < nplanes; ++j) blocks += (long long)((w[j] + 15) / 16) * ((h[j] + 15) / 16) * ((cout + 31) / 32);
     return blocks >= big_min ? 2 : 1;

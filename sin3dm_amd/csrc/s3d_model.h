@@ -59,7 +59,7 @@ struct ConvWT {
     size_t dense_T[3] = {0, 0, 0};    // [taps][cin][cout], taps flipped: dgrad as a forward convolution
     size_t wino_T[3] = {0, 0, 0};     // the same operator in Winograd fragment order (3x3 only)
     size_t wino24s_T[3] = {0, 0, 0};  // ... and in the mixed F(2x4) order of k_conv_wino24s
-    bool has_wino24s_T = false;
+    bool has_wino24s_T = false, has_wino_T = false;
     size_t rrow_T[3] = {0, 0, 0};     // [3 taps][cin][3*cout]: d(row-varying mean vector) from the row sums of dy
     size_t rcol_T[3] = {0, 0, 0};
 };
@@ -300,7 +300,7 @@ struct Fwd {
         for (int p = 0; p < 3; ++p) {
             ConvJob& J = ca.job[p];
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = no_bias ? nullptr : m->dev(cw.bias[p]);
-            J.wgt_wino = cw.k == 3 ? m->dev(cw.wino[p]) : nullptr;
+            J.wgt_wino = cw.k == 3 && !w24 ? m->dev(cw.wino[p]) : nullptr;     // (the repack plan keeps only the image in use current)
             J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
             J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = fstride();

@@ -175,13 +175,18 @@ struct Plan {
             wt.dense_T[p] = talloc(size_t(taps) * cout * cin);
             add(PK_DENSE_T, w, wt.dense_T[p], (long long)taps * cout * cin, cout, ctot, cin, taps, 0, 0, 1);
             if (k == 3) {
-                add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
-                if (cw.wino24[p]) add(PK_WINO24, w, cw.wino24[p], (long long)cout * cin, cout, ctot, cin, 9);
+                // the per-step repack writes only the images this process's kernels read (S3D_WINO is fixed per process): with
+                // the mixed kernel active the F(2x2) images and the 16x16-pixel variant's would be rewritten for nobody
+                const bool fwd24 = cw.wino24s[p] && conv_wino24_channels(cin, cout);
+                const bool bwd24 = cw.wino24s[p] && cout % 32 == 0 && conv_wino24_channels(cout, cin);
+                if (!fwd24) add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
+                if (cw.wino24[p] && (conv_wino24_big_enabled() || !fwd24)) add(PK_WINO24, w, cw.wino24[p], (long long)cout * cin, cout, ctot, cin, 9);
                 if (cw.wino24s[p]) add(PK_WINO24S, w, cw.wino24s[p], (long long)cout * cin, cout, ctot, cin, 9);
-                // transposed operator: cin outputs (padded to 32) x cout inputs
-                wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
-                add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
-                if (cw.wino24s[p] && cout % 32 == 0) {          // dgrad through k_conv_wino24s: K = cout in 32-channel chunks
+                if (!bwd24) {      // transposed operator: cin outputs (padded to 32) x cout inputs
+                    wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
+                    wt.has_wino_T = true;
+                    add(PK_WINO_T, w, wt.wino_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
+                } else {           // dgrad through k_conv_wino24s: K = cout in 32-channel chunks
                     wt.wino24s_T[p] = talloc(wino24_packed_floats(cin, cout));
                     wt.has_wino24s_T = true;
                     add(PK_WINO24S_T, w, wt.wino24s_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);

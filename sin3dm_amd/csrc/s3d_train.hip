@@ -51,7 +51,7 @@ struct Bwd {
                 ca.B = B; ca.cin = cout; ca.cout = cin; ca.njobs = 3;
                 for (int p = 0; p < 3; ++p) {
                     ConvJob& J = ca.job[p];
-                    J.in = dy.p[p]; J.wgt = m->tdev(wt.dense_T[p]); J.wgt_wino = cw.k == 3 ? m->tdev(wt.wino_T[p]) : nullptr;
+                    J.in = dy.p[p]; J.wgt = m->tdev(wt.dense_T[p]); J.wgt_wino = cw.k == 3 && wt.has_wino_T ? m->tdev(wt.wino_T[p]) : nullptr;
                     J.wgt_wino24s = cw.k == 3 && wt.has_wino24s_T ? m->tdev(wt.wino24s_T[p]) : nullptr;
                     J.res = res ? res->p[p] : nullptr; J.out = d_a->p[p]; J.h = g.h[p]; J.w = g.w[p];
                 }
