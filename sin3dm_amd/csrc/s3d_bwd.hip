@@ -458,6 +458,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
 #pragma unroll
         for (int x = 0; x < 2; ++x) { o.d0[x] = pd[x * WW_LD]; o.d1[x] = pd[(WW_TW + x) * WW_LD]; }
     };
+    // (measured and dropped: starting the CU's three blocks a third of a region period apart with s_sleep — 60 us against 57)
     for (long long rr = r_begin; rr < r_end; ++rr) {
         // no register prefetch of the next region (40 VGPRs that made the allocator spill): with three blocks per CU the
         // other waves of the SIMD keep the matrix pipe busy while this one waits for its loads
@@ -495,17 +496,29 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
 }
 // dg = G^T (sum of the slices' dU) G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
-__global__ void k_wgrad_wino_reduce(WgwRedArgs a) {
+__global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) {
+    // block = 64 (co, ci) pairs x 4 slice lanes: lane j adds slices j, j+4, ..., the four sums meet through LDS in lane order
+    // (one thread per pair over all slices left 48 blocks walking 64 x 16 dependent loads each: 24 us at 64 channels)
+    __shared__ float red[3][16][64];
     const long long n = (long long)a.cout * a.cin;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
+    const int l = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + l;
     const int p = blockIdx.y;
     float S[16];
 #pragma unroll
     for (int f = 0; f < 16; ++f) S[f] = 0.f;
-    for (int k = 0; k < a.ksplit; ++k)
+    if (idx < n)
+        for (int k = kl; k < a.ksplit; k += 4)
 #pragma unroll
-        for (int f = 0; f < 16; ++f) S[f] += a.part[p][(size_t(k) * 16 + f) * n + idx];
+            for (int f = 0; f < 16; ++f) S[f] += a.part[p][(size_t(k) * 16 + f) * n + idx];
+    if (kl > 0) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f) red[kl - 1][f][l] = S[f];
+    }
+    __syncthreads();
+    if (kl != 0 || idx >= n) return;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) S[f] = ((S[f] + red[0][f][l]) + red[1][f][l]) + red[2][f][l];
     float T[4][3];
 #pragma unroll
     for (int uu = 0; uu < 4; ++uu) {
@@ -547,6 +560,12 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgRedArgs a) {
     if (ci < a.cin_store) a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
 }
 
+// 1x1: the 128 x 128 channel tile halves the staging traffic per flop, but a 64 -> 128 or 192 -> 64 skip convolution would
+// fill 37-50 % of it (95 us for the 192 -> 64 one at towerruins size); take it only when the padding costs under a quarter
+static bool wgrad_1x1_wide(int cin, int cout) {
+    const long long wide = (long long)cdiv(cout, 128) * 128 * cdiv(cin, 128) * 128, narrow = (long long)cdiv(cout, 64) * 64 * cdiv(cin, 64) * 64;
+    return 4 * wide <= 5 * narrow;
+}
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
     long long tiles = 0;
@@ -560,12 +579,12 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
         return int(std::max<long long>(1, std::min(std::min(ks, per_plane), (long long)96)));
     }
     for (int p = 0; p < 3; ++p) { tiles += (long long)cdiv(g.h[p], WG_TR) * cdiv(g.w[p], WG_TC); planes += g.h[p] > 0; }
-    const int bt = taps == 1 ? 128 : 64;
+    const int bt = taps == 1 && wgrad_1x1_wide(cin, cout) ? 128 : 64;
     const int rows = taps == 9 ? 3 : (taps == 25 ? 5 : 1);           // blocks per (tile, slice): one kernel row each
     const long long base = (long long)cdiv(cout, bt) * cdiv(cin, bt) * std::max(planes, 1) * rows;
     // one balanced round of equal blocks: as many as are resident at once, never more - 516 blocks on 512 slots cost a
     // whole extra round (measured at 64 channels, batch 4: 2 per CU 4.90 ms/step, 3 per CU 4.79)
-    const int slots = (taps == 9 ? 3 : 2) * cus;                     // blocks the kernel variant holds per CU (registers / LDS)
+    const int slots = (taps == 9 || (taps == 1 && bt == 64) ? 3 : 2) * cus;   // blocks the kernel variant holds per CU (registers / LDS)
     long long ks = std::max<long long>(1, slots / base);
     const long long per_plane = std::max<long long>(1, tiles * B / std::max(planes, 1));
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
@@ -596,13 +615,14 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
         for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
         r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin;
         const long long n = (long long)w.cout * w.cin;
-        hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3((unsigned)((n + 255) / 256), w.nplanes), dim3(256), 0, st, r);
+        hipLaunchKernelGGL(k_wgrad_wino_reduce, dim3((unsigned)((n + 63) / 64), w.nplanes), dim3(256), 0, st, r);
         S3D_HIP(hipGetLastError());
         return 0;
     }
     WgArgs a;
     a.B = w.B; a.cin = w.cin; a.cout = w.cout; a.a_cstride = w.a.C; a.ksplit = w.ksplit;
-    const int bt = w.taps == 1 ? 128 : 64;                           // block tile (see WT)
+    const bool wide = w.taps == 1 && wgrad_1x1_wide(w.cin, w.cout);
+    const int bt = wide ? 128 : 64;                                  // block tile (see WT)
     a.n_co = cdiv(w.cout, bt); a.n_ci = cdiv(w.cin, bt);
     // one kernel row per block (3x / 5x the blocks, a third of the accumulators -> three waves per SIMD)
     const bool split_rows = w.taps != 1;
@@ -619,7 +639,8 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     if (!blocks || !w.B) return 0;
     if (w.taps == 25) hipLaunchKernelGGL((k_wgrad_mfma<25, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
     else if (w.taps == 9) hipLaunchKernelGGL((k_wgrad_mfma<9, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else if (wide) hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     WgRedArgs r;
     for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
