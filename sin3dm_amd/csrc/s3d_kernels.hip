@@ -909,20 +909,25 @@ __global__ void k_upcat(UpCatArgs a) {
     }
     reinterpret_cast<float4*>(a.out[p])[((size_t(b) * ho + yo) * wo + xo) * oq + q] = o;
 }
-// The same pass with 4 pixels x all channel quads per block, which also leaves the block's GroupNorm partial of the
-// concatenated tensor (per-channel sums of the 4 pixels through LDS, then 32 threads add their group's channels).
-constexpr int kUpcatPx = 4;
+// The same pass with 32 pixels x all channel quads per block (four pixel lanes, eight trips), which also leaves the
+// block's GroupNorm partial of the concatenated tensor: a thread adds its eight pixels per channel in double, the lanes
+// meet through LDS and 32 threads add their group's channels.  (Four pixels per block — 35 328 blocks and as many partial
+// records at towerruins size, batch 4 — took 51 us.)
+constexpr int kUpcatPx = 32, kUpcatLanes = 4;
 __global__ void k_upcat_gn(UpCatArgs a, double* part, int maxparts) {
-    extern __shared__ __attribute__((aligned(16))) float up_sm[];     // [2][kUpcatPx][C]
+    extern __shared__ __attribute__((aligned(16))) double up_smd[];     // [2][kUpcatLanes][C]
     const int p = blockIdx.y, b = blockIdx.z;
     const int hi = a.hi[p], wi = a.wi[p], ho = 2 * hi, wo = 2 * wi, npix = ho * wo;
     const int oq = a.cuq + a.csq, C = oq * 4;
     const int q = threadIdx.x % oq, lp = threadIdx.x / oq;
-    const int pix = blockIdx.x * kUpcatPx + lp;
     if (int(blockIdx.x) * kUpcatPx >= npix) return;
-    float4 o = make_float4(0, 0, 0, 0);
-    if (pix < npix) {
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int it = 0; it < kUpcatPx / kUpcatLanes; ++it) {
+        const int pix = blockIdx.x * kUpcatPx + it * kUpcatLanes + lp;
+        if (pix >= npix) break;
         const int xo = pix % wo, yo = pix / wo;
+        float4 o;
         if (q >= a.cuq) {
             o = reinterpret_cast<const float4*>(a.sk[p])[((size_t(b) * ho + yo) * wo + xo) * a.csq + (q - a.cuq)];
         } else {
@@ -941,22 +946,25 @@ __global__ void k_upcat_gn(UpCatArgs a, double* part, int maxparts) {
             o.w = ly0 * (lx0 * v00.w + lx1 * v01.w) + ly1 * (lx0 * v10.w + lx1 * v11.w);
         }
         reinterpret_cast<float4*>(a.out[p])[((size_t(b) * ho + yo) * wo + xo) * oq + q] = o;
+        const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k] += double(ov[k]); ss[k] += double(ov[k]) * double(ov[k]); }
     }
-    float* ss = up_sm + kUpcatPx * C;
-    *reinterpret_cast<float4*>(up_sm + lp * C + 4 * q) = o;                                   // pixels past the end contribute zeros
-    *reinterpret_cast<float4*>(ss + lp * C + 4 * q) = make_float4(o.x * o.x, o.y * o.y, o.z * o.z, o.w * o.w);
+    double* sq = up_smd + kUpcatLanes * C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { up_smd[lp * C + 4 * q + k] = s[k]; sq[lp * C + 4 * q + k] = ss[k]; }
     __syncthreads();
     if (threadIdx.x < 32) {
         const int g = threadIdx.x, cg = C / 32;
         double S = 0, SS = 0;
-        for (int l = 0; l < kUpcatPx; ++l)
-            for (int c = g * cg; c < (g + 1) * cg; ++c) { S += up_sm[l * C + c]; SS += ss[l * C + c]; }
+        for (int l = 0; l < kUpcatLanes; ++l)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) { S += up_smd[l * C + c]; SS += sq[l * C + c]; }
         double* op = part + (((size_t(b) * 3 + p) * 32 + g) * maxparts + blockIdx.x) * 2;
         op[0] = S; op[1] = SS;
     }
 }
 bool upcat_gn_parts(const Geo& out_g, int C, int nparts[3]) {
-    if (C % 32 != 0 || C / 4 * kUpcatPx > 1024) return false;
+    if (C % 32 != 0 || C / 4 * kUpcatLanes > 1024) return false;
     for (int p = 0; p < 3; ++p) nparts[p] = (out_g.h[p] * out_g.w[p] + kUpcatPx - 1) / kUpcatPx;
     return true;
 }
@@ -974,7 +982,7 @@ int launch_upcat(const Tri& u, const Tri& sk, int B, Tri& out, hipStream_t st, c
         S3D_CHECK(upcat_gn_parts(out.g, out.C, np) && part->nsub == 32 && part->nparts[0] == np[0] && part->nparts[1] == np[1] && part->nparts[2] == np[2],
                   S3D_ERR_INVALID, "upcat: GroupNorm partial layout");
         const int mx = std::max(np[0], std::max(np[1], np[2]));
-        hipLaunchKernelGGL(k_upcat_gn, dim3(mx, 3, B), dim3(out.C / 4 * kUpcatPx), size_t(2) * kUpcatPx * out.C * sizeof(float), st, a, part->p, part->maxparts);
+        hipLaunchKernelGGL(k_upcat_gn, dim3(mx, 3, B), dim3(out.C / 4 * kUpcatLanes), size_t(2) * kUpcatLanes * out.C * sizeof(double), st, a, part->p, part->maxparts);
         S3D_HIP(hipGetLastError());
         return 0;
     }
