@@ -200,8 +200,8 @@ double wino_exec_fraction();
 bool conv_use_wino24();
 bool conv_wino24_big_enabled();                     // S3D_WINO24_BIG_MIN_BLOCKS set: the 16x16-pixel variant may be chosen
 bool conv_wino24_channels(int cin, int cout);       // the mixed kernel takes every 3x3 launch of these widths
-// which mixed kernel these planes / channels (not the batch size) take: 0 none (F(2x2)), 1 the 8x16-pixel form, 2 the 16x16-pixel form
-int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout);
+// which mixed kernel a launch over these planes / channels / samples takes: 0 none (F(2x2)), 1 the 8x16-pixel form, 2 the 16x16-pixel form
+int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B);
 void wino24_gn_parts(const Geo& g, int nparts[3]);
 size_t wino24_packed_floats(int cout, int cin);
 size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
@@ -216,7 +216,8 @@ struct ActArgs {
     const float* film;       // [B][film_stride]: scale at [0,C), shift at [C,2C); or null
     int film_stride;
 };
-constexpr int kActRows = 8, kActCols = 8;     // tile of the act kernel (measured: 8x16 +1 %, 4x16 +3 %, 16x8 +15 % per step)
+constexpr int kActRows = 8, kActCols = 8;     // tile of the act kernel (measured: 8x16 +1 %, 4x16 +3 %, 16x8 +15 % per step; 4x8 on the
+                                              // half-resolution planes only, 384 blocks instead of 192: -0.7 us per call, not kept)
 struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a tile's columns), colpart [B][ntr][w][C]
     float* rowpart[3];
     float* colpart[3];

@@ -344,11 +344,8 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
 
 // ------------------------------------------------------------------ rank-1 rollout tables (skinny GEMMs)
 // out[b][pos][n] = sum_{tap, c} W[tap][n][c] * v[b][pos + tap - 1][c]   (zero outside [0, L)), n = variant*cout + co.
-// M = L is only ~128 rows, so the work is split along K instead: a block owns 128 positions x 32 columns and its four
-// waves each contract a quarter of K = 3*C, operands fetched straight from L2 into MFMA registers (no staging, no
-// barriers in the loop; one weight fragment feeds four row tiles).  The four partial accumulators are then added
-// through LDS in wave order.
-// One block = 32 positions x 32 columns.  K = 3 taps x C is walked in stages of (tap, <=128-channel chunk): whole
+// M = L is only ~128 rows, so the work is split along K instead.  One block = 32 positions x 32 columns.  K = 3 taps x C
+// is walked in stages of (tap, <=128-channel chunk): whole
 // 512-byte rows of the vector (with its +-1 halo, loaded once per chunk) and of the weights are staged in LDS with
 // coalesced loads, register-prefetched one stage ahead; inside a stage the four waves each contract a quarter of the
 // chunk, and their partial accumulators are added through LDS in wave order at the end.
@@ -601,17 +598,17 @@ static long long wino24_big_min() {
 }
 bool conv_wino24_big_enabled() { return conv_use_wino24() && wino24_big_min() < (1LL << 60); }
 bool conv_wino24_channels(int cin, int cout) { return conv_use_wino24() && cout % 4 == 0 && cin % 32 == 0; }
-int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout) {
+int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B) {
     if (!conv_wino24_channels(cin, cout)) return 0;
     const long long big_min = wino24_big_min();
     long long blocks = 0;
-    for (int j = 0; j < nplanes; ++j) blocks += (long long)((w[j] + 15) / 16) * ((h[j] + 15) / 16) * ((cout + 31) / 32);
+    for (int j = 0; j < nplanes; ++j) blocks += (long long)B * ((w[j] + 15) / 16) * ((h[j] + 15) / 16) * ((cout + 31) / 32);
     return blocks >= big_min ? 2 : 1;
 }
 static int takes_wino24(const ConvArgs& a) {
     int h[kMaxConvJobs], w[kMaxConvJobs];
     for (int j = 0; j < a.njobs; ++j) { h[j] = a.job[j].h; w[j] = a.job[j].w; }
-    const int k = conv_wino24_geo(h, w, a.njobs, a.cin, a.cout);
+    const int k = conv_wino24_geo(h, w, a.njobs, a.cin, a.cout, a.B);
     if (k == 2 && a.job[0].wgt_wino24) return 2;
     if (k >= 1 && a.job[0].wgt_wino24s) return 1;
     return 0;

@@ -218,8 +218,6 @@ struct Fwd {
         return launch_gn_finalize(part, x.g, x.C, B, out, st);
     }
 
-    // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and
-    // the rank-1 tables its epilogue needs.  Returns activated tensor; fills rrow/rcol table pointers.
     // workspace of a rollout convolution's rank-1 terms for the activated tensor y: axis-sum partials, mean vectors, tables
     int roll_buffers(const Tri& y, const ConvW& cw, bool roll, MeanPartials& mp, MeanVecs& mv, const float* rrow[3], const float* rcol[3]) {
         for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
@@ -252,6 +250,8 @@ struct Fwd {
         }
         return m->timed_conv(2, CONV_1x3_ROLL, ca, st);
     }
+    // GN (+FiLM) + SiLU of x into a new tensor; when `cw` is a rollout conv also the six mean vectors and the rank-1
+    // tables its epilogue needs (rrow / rcol)
     int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
                  const float* rcol[3], NormTape* nt = nullptr) {
         const bool measuring = ar().measuring;
@@ -273,17 +273,16 @@ struct Fwd {
         return rank1_tables(y, *cw, mp, mv, rrow, rcol);
     }
 
-    // want_stats: also reduce the GroupNorm statistics of the output in the epilogue (3x3 MFMA path only)
-    // want_stats: 1 = reduce the GroupNorm statistics of the output (partials in the epilogue + finalize), 2 = leave only
-    // the partials with the tensor (it is normalised later as the skip half of a concat)
+    // want_stats (3x3 MFMA paths only): 1 = reduce the GroupNorm statistics of the output (partials in the epilogue +
+    // finalize), 2 = leave only the partials with the tensor (it is normalised later as the skip half of a concat)
     int conv(const Tri& y, const ConvW& cw, const float* bbias, const float* const rrow[3], const float* const rcol[3],
              const Tri* res, Tri& out, int want_stats = 0, hipStream_t on = nullptr, bool no_bias = false, bool res_up = false) {
         hipStream_t st = on ? on : this->st;
         out = alloc_tri(cw.cout, y.g);
         if (!(cw.k == 3 && !conv_use_naive())) want_stats = 0;
-        // the mixed Winograd kernel serves every forward (the tape keeps activations, not conv internals); dgrad stays on
-        // the F(2x2) kernels, whose transposed operators the backward pass has
-        const int w24 = cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout) : 0;
+        // the mixed Winograd kernel serves every forward (the tape keeps activations, not conv internals) and, on the transposed
+        // image, the backward's dgrad (s3d_train.hip:conv_bwd)
+        const int w24 = cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) : 0;
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);
