@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
 // ------------------------------------------------------------------ Winograd weight gradient of the 3x3 convolutions
 // Forward: Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile (s3d_wino.hip).  Hence
 //   dU[u][v][co][ci] = sum over tiles of (A dY A^T)[u][v][co] * (B^T d B)[u][v][ci]      (16 GEMMs, K = tiles)
-//   dg = G^T dU G                                                                          (k_wgrad_wino_reduce)
+//   dg = G^T dU G                                                                          (per slice, in the block's epilogue)
 // 16 multiplies per tile and channel pair instead of 36: 2.25x fewer MFMA flops than the direct weight gradient.
 // A block owns one 32(co) x 32(ci) pair and a slice of the pixel regions (8x16 pixels = 32 Winograd tiles, the
 // forward kernel's tile); its four waves own one row u of the frequency grid each (four accumulators).  A region's
@@ -486,53 +486,63 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
             cur = nxt;
         }
     }
-    // partial [ks][16 freq][cout][cin]
+    // dg = G^T dU G of THIS slice before it leaves the block (9 values per channel pair instead of 16: the partials are what
+    // this launch writes and the reduce kernel reads — 50 MB each way at 768 blocks, a fifth of the two kernels' time).
+    // Column pass in registers (v: 4 -> 3, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]); row pass across the four waves
+    // through LDS, one column j at a time: wave w finishes accumulator registers 4w .. 4w+3.
+    float* red = sx;                                       // [4 waves][16 regs][64 lanes] = 16 KB of the 26 KB halo buffer
+    static_assert(WW_HH * WW_HW * WW_LD >= 4 * 16 * 64, "row-pass scratch");
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        float* dst = J.part + ((size_t(ks) * 16 + u * 4 + v) * args.cout + co0) * args.cin + ci0 + i;
+    for (int j = 0; j < 3; ++j) {
+        __syncthreads();                                   // the k-loop's last reads / the previous column's reads are done
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[size_t((r & 3) + 8 * (r >> 2) + 4 * half) * args.cin] = acc[v][r];
+        for (int r = 0; r < 16; ++r) {
+            const float h1 = 0.5f * acc[1][r], h2 = 0.5f * acc[2][r];
+            const float t = j == 0 ? acc[0][r] + (h1 + h2) : (j == 1 ? h1 - h2 : (h1 + h2) + acc[3][r]);
+            red[(u * 16 + r) * 64 + lane] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = u * 4 + rr;
+            const float t0 = red[(0 * 16 + r) * 64 + lane], t1 = red[(1 * 16 + r) * 64 + lane];
+            const float t2 = red[(2 * 16 + r) * 64 + lane], t3 = red[(3 * 16 + r) * 64 + lane];
+            const float h1 = 0.5f * t1, h2 = 0.5f * t2;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = J.part + ((size_t(ks) * 9 + j) * args.cout + co) * args.cin + ci0 + i;     // [ks][tap = 3*row + j][cout][cin]
+            const size_t tap_stride = size_t(3) * args.cout * args.cin;
+            dst[0] = t0 + (h1 + h2); dst[tap_stride] = h1 - h2; dst[2 * tap_stride] = (h1 + h2) + t3;
+        }
     }
 }
-// dg = G^T (sum of the slices' dU) G, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+// adds the slices' dg in slice order and scatters to OIHW
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
 __global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) {
     // block = 64 (co, ci) pairs x 4 slice lanes: lane j adds slices j, j+4, ..., the four sums meet through LDS in lane order
     // (one thread per pair over all slices left 48 blocks walking 64 x 16 dependent loads each: 24 us at 64 channels)
-    __shared__ float red[3][16][64];
+    __shared__ float red[3][9][64];
     const long long n = (long long)a.cout * a.cin;
     const int l = threadIdx.x & 63, kl = threadIdx.x >> 6;
     const long long idx = (long long)blockIdx.x * 64 + l;
     const int p = blockIdx.y;
-    float S[16];
+    float S[9];
 #pragma unroll
-    for (int f = 0; f < 16; ++f) S[f] = 0.f;
+    for (int f = 0; f < 9; ++f) S[f] = 0.f;
     if (idx < n)
         for (int k = kl; k < a.ksplit; k += 4)
 #pragma unroll
-            for (int f = 0; f < 16; ++f) S[f] += a.part[p][(size_t(k) * 16 + f) * n + idx];
+            for (int f = 0; f < 9; ++f) S[f] += a.part[p][(size_t(k) * 9 + f) * n + idx];
     if (kl > 0) {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) red[kl - 1][f][l] = S[f];
+        for (int f = 0; f < 9; ++f) red[kl - 1][f][l] = S[f];
     }
     __syncthreads();
     if (kl != 0 || idx >= n) return;
-#pragma unroll
-    for (int f = 0; f < 16; ++f) S[f] = ((S[f] + red[0][f][l]) + red[1][f][l]) + red[2][f][l];
-    float T[4][3];
-#pragma unroll
-    for (int uu = 0; uu < 4; ++uu) {
-        const float h1 = 0.5f * S[uu * 4 + 1], h2 = 0.5f * S[uu * 4 + 2];
-        T[uu][0] = S[uu * 4 + 0] + (h1 + h2); T[uu][1] = h1 - h2; T[uu][2] = (h1 + h2) + S[uu * 4 + 3];
-    }
     const int ci = int(idx % a.cin), co = int(idx / a.cin);
     if (ci >= a.cin_store) return;
     float* d = a.dW[p] + (size_t(co) * a.ctot + ci) * 9;
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-        const float h1 = 0.5f * T[1][jj], h2 = 0.5f * T[2][jj];
-        d[0 * 3 + jj] = T[0][jj] + (h1 + h2); d[1 * 3 + jj] = h1 - h2; d[2 * 3 + jj] = (h1 + h2) + T[3][jj];
-    }
+    for (int f = 0; f < 9; ++f) d[f] = ((S[f] + red[0][f][l]) + red[1][f][l]) + red[2][f][l];
 }
 static bool wgrad_use_wino() {
     static const bool on = !(getenv("S3D_WGRAD_WINO") && atoi(getenv("S3D_WGRAD_WINO")) == 0);
@@ -590,7 +600,7 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
     ks = std::max<long long>(1, std::min(ks, per_plane));            // at least one pixel tile per slice (roughly)
     return int(std::min<long long>(ks, 128));                        // ... and bound the partial-sum traffic
 }
-size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * (taps == 9 && wgrad_use_wino() ? 16 : taps); }
+size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
 int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     S3D_CHECK(w.taps == 9 || w.taps == 1 || w.taps == 25, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
