@@ -575,6 +575,7 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y,
     }
     a.mr = stats.mr; a.film = aa.film; a.film_stride = aa.film_stride;
     a.C = x.C; thread_shape(x.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
+    a.pl = std::min(a.pl, kActCols);          // a pixel lane per tile column at most (64 channels: 16 lanes left half the block idle)
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
