@@ -446,10 +446,12 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
 #pragma unroll
         for (int k = 0; k < NDY; ++k) *reinterpret_cast<float4*>(sdy + (k * 32 + prow) * WW_LD + q * 4) = rdy[k];
     };
-    // operands of MFMA step st (tiles 2*st and 2*st + 1, one per lane half): 8 patch values, 4 dy values
+    // operands of MFMA step st (two tiles, one per lane half): 8 patch values, 4 dy values
     struct Ops { float x[4], y[4], d0[2], d1[2]; };
     auto lds_step = [&](int st, Ops& o) {
-        const int t = 2 * st + half, tr = t >> 3, tc = t & 7;
+        // the two lane halves take tiles FOUR columns apart: 8 pixels x 36 floats = 32 banks, so the 64 lanes of a ds_read_b32
+        // cover all 64 banks once (adjacent tiles, 8 banks apart, made 24 of the 32 lanes of each half collide)
+        const int tr = st >> 2, tc = (st & 3) + 4 * half;
         const float* px = sx + ((2 * tr + xrow) * WW_HW + 2 * tc) * WW_LD + i;
         const float* py = sx + ((2 * tr + yrow) * WW_HW + 2 * tc) * WW_LD + i;
         const float* pd = sdy + ((2 * tr) * WW_TW + 2 * tc) * WW_LD + i;
