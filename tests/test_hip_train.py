@@ -102,6 +102,22 @@ def test_grads_with_the_direct_weight_gradient_kernel():
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_training_on_the_f2x2_winograd_kernels():
+    """S3D_WINO=4: forward and dgrad on k_conv_wino4 and a repack plan that keeps the F(2x2) images (and their transposes)
+    current instead of the mixed kernel's — the branch the default process never takes.  Gradients against the golden
+    digests, then optimizer steps (each one repacks) against the golden parameter norms."""
+    import os, subprocess, sys
+    code = ("import sys; sys.path.insert(0, 'tests')\n"
+            "import test_hip_train as tt\n"
+            "tt.test_training_losses_and_grads(*tt.TRAIN_CASES[0]); tt.test_training_losses_and_grads(*tt.TRAIN_CASES[4])\n"
+            "tt.test_device_repack_reproduces_host_packing(); tt.test_optimizer_steps('wd01')\n"
+            "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_WINO="4"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_fast_path_equals_autograd_and_is_repeatable():
     """training_losses_and_grads (no autograd graph) gives the same flat gradient as loss.backward(), bit for bit,
     and twice the same bits (all reductions have a fixed order)."""
