@@ -224,8 +224,10 @@ struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a ti
 };
 // stats.p == nullptr: identity (no norm, no SiLU) — used by the leaf-operator entry point to get the rollout
 // means of a raw input.
+// stats_part != null (with stats.mr == null): the kernel adds the producer's partial sums itself (gn_act_can_add_parts)
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
-                  hipStream_t st);
+                  hipStream_t st, const GnPartials* stats_part = nullptr);
+bool gn_act_can_add_parts(const GnPartials& part, int C);
 // the same on the virtual concat [bilinear2x(u) | sk] (y.C = u.C + sk.C, y.g = sk.g = 2 * u.g)
 int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                       hipStream_t st);

@@ -529,7 +529,11 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
 void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
-    if (wino24 == 2 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }      // (the 8x16-pixel form tiles like the F(2x2) kernels)
+    if (wino24 == 2 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }
+    if (wino24 == 1 && conv_use_wino24()) {                       // k_conv_wino24s: one part per 8x16-pixel block
+        for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + 15) / 16) * ((g.h[p] + 7) / 8);
+        return;
+    }
     if (conv_use_wino()) { wino_gn_parts(g, nparts); return; }
     using CFG = ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>;
     for (int p = 0; p < 3; ++p)

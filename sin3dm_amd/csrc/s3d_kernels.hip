@@ -482,6 +482,9 @@ struct GnActArgs {
     const float* film; int film_stride;
     int h[3], w[3];
     int C, cq, pl, with_means;
+    // mr == null && part != null: the statistics come from the producer's partial sums, added here (every block adds the
+    // parts of its plane's 32 groups itself: 64 KB from L2 at 128^2 x 128 channels, instead of a k_gn_finalize launch)
+    const double* part; int nparts[3], maxparts, nsub, spg; double count[3];
 };
 __global__ void k_gn_act(GnActArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -491,10 +494,48 @@ __global__ void k_gn_act(GnActArgs a) {
     const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
     if (int(blockIdx.x) >= ntc * ntr) return;
     const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
-    const bool ident = a.mr == nullptr;
-    if (threadIdx.x < 32 && !ident) {
-        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
-        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
+    const bool ident = a.mr == nullptr && a.part == nullptr;
+    if (a.mr) {
+        if (threadIdx.x < 32) {
+            const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
+            sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
+        }
+    } else if (a.part) {
+        // L = blockDim/32 lanes per group: lane j adds entries j, j+L, ... of the group's [sub][part] list, the lanes meet in
+        // lane order (double) — the formula of k_gn_finalize
+        double* sd = reinterpret_cast<double*>(smem_raw);
+        const int L = int(blockDim.x) >> 5, tid = threadIdx.x;
+        if (tid < 32 * L) {
+            const int g = tid / L, j = tid - g * L;
+            const int n = a.nparts[p], tot = a.spg * n;
+            const double2* base = reinterpret_cast<const double2*>(a.part) + ((size_t(b) * 3 + p) * a.nsub + size_t(g) * a.spg) * a.maxparts;
+            double S = 0, SS = 0;
+            constexpr int NB = 16;                          // loads in flight per trip (added in index order afterwards)
+            for (int k0 = j; k0 < tot; k0 += NB * L) {
+                double2 v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int k = k0 + u * L, kc = k < tot ? k : j;
+                    const int sub = kc / n, part = kc - sub * n;
+                    v[u] = base[size_t(sub) * a.maxparts + part];
+                    if (k >= tot) v[u] = make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) { S += v[u].x; SS += v[u].y; }
+            }
+            sd[tid * 2] = S; sd[tid * 2 + 1] = SS;
+        }
+        __syncthreads();
+        if (tid < 32) {
+            double S = 0, SS = 0;
+            for (int j = 0; j < L; ++j) { S += sd[(tid * L + j) * 2]; SS += sd[(tid * L + j) * 2 + 1]; }
+            const double m = S / a.count[p];
+            double var = SS / a.count[p] - m * m;
+            if (var < 0) var = 0;
+            float* stf = reinterpret_cast<float*>(sd + 2 * blockDim.x);     // behind the lanes' sums: no second barrier
+            stf[tid] = float(m); stf[32 + tid] = float(1.0 / sqrt(var + 1e-5));
+        }
+        sm = reinterpret_cast<float*>(sd + 2 * blockDim.x);
     }
     __syncthreads();
     const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
@@ -545,7 +586,7 @@ __global__ void k_gn_act(GnActArgs a) {
             reinterpret_cast<float4*>(a.colpart[p] + ((size_t(b) * ntr + tr) * w + j) * a.C)[q] = colacc;
     }
     if (!a.with_means) return;
-    float4* smr = reinterpret_cast<float4*>(sm);               // [pl][kActRows][cq]
+    float4* smr = reinterpret_cast<float4*>(smem_raw);         // [pl][kActRows][cq] (from the start of the block's LDS)
 #pragma unroll
     for (int r = 0; r < kActRows; ++r) smr[(size_t(l) * kActRows + r) * a.cq + q] = rowacc[r];
     __syncthreads();
@@ -562,9 +603,20 @@ __global__ void k_gn_act(GnActArgs a) {
         reinterpret_cast<float4*>(a.rowpart[p] + ((size_t(b) * ntc + tc) * h + i) * a.C)[qq] = s;
     }
 }
+bool gn_act_can_add_parts(const GnPartials& part, int C) {
+    if (!part.p || part.nsub % 32 != 0 || C % 32 != 0) return false;
+    static const bool on = !(getenv("S3D_GN_FUSED") && atoi(getenv("S3D_GN_FUSED")) == 0);
+    return on && (part.nsub / 32) * part.maxparts <= 160;      // entries per group a block adds (x 32 groups x 16 bytes)
+}
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
-                  hipStream_t st) {
+                  hipStream_t st, const GnPartials* stats_part) {
     GnActArgs a;
+    a.part = nullptr;
+    if (stats_part) {
+        S3D_CHECK(!stats.mr && gn_act_can_add_parts(*stats_part, x.C), S3D_ERR_INVALID, "gn_act: partial-sum statistics layout");
+        a.part = stats_part->p; a.maxparts = stats_part->maxparts; a.nsub = stats_part->nsub; a.spg = stats_part->nsub / 32;
+        for (int p = 0; p < 3; ++p) { a.nparts[p] = stats_part->nparts[p]; a.count[p] = double(x.C / 32) * x.g.h[p] * x.g.w[p]; }
+    }
     int maxtiles = 0;
     for (int p = 0; p < 3; ++p) {
         a.x[p] = x.p[p]; a.y[p] = y.p[p]; a.h[p] = x.g.h[p]; a.w[p] = x.g.w[p];
@@ -579,6 +631,7 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y,
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
+    if (a.part) shm = std::max(shm, size_t(a.cq) * a.pl * 2 * sizeof(double) + 64 * sizeof(float));
     hipLaunchKernelGGL(k_gn_act, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

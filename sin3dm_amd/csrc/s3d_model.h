@@ -208,6 +208,11 @@ struct Fwd {
     // GroupNorm {mean, rstd} of x: taken from its producer's epilogue when available, otherwise one read pass.
     int stats_of(const Tri& x, GnStats& out) {
         if (x.gn) { out.mr = x.gn; return 0; }
+        if (x.part.p) {                                   // only the producer's partials travel with it: add them now
+            out.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+            if (ar().measuring) return 0;
+            return launch_gn_finalize(x.part, x.g, x.C, B, out, st);
+        }
         GnPartials part;
         part.p = ar().alloc<double>(size_t(B) * 3 * kGnChunks * 64);
         part.maxparts = kGnChunks; part.nsub = 32;
@@ -255,8 +260,10 @@ struct Fwd {
     int norm_act(const Tri& x, const NormW& nw, const float* film_ptr, const ConvW* cw, Tri& y, const float* rrow[3],
                  const float* rcol[3], NormTape* nt = nullptr) {
         const bool measuring = ar().measuring;
-        GnStats stats;
-        S3D_TRY(stats_of(x, stats));
+        GnStats stats{nullptr};
+        // inference: when x carries its producer's partial sums and they are few, the act kernel adds them itself
+        const bool add_parts = !nt && !x.gn && gn_act_can_add_parts(x.part, x.C);
+        if (!add_parts) S3D_TRY(stats_of(x, stats));
         if (nt) { nt->stats = stats; nt->roll = cw && cw->rollout; }
         y = alloc_tri(x.C, x.g);
         ActArgs aa;
@@ -268,7 +275,7 @@ struct Fwd {
         else for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
         if (nt && roll) nt->mv = mv;
         if (measuring) return 0;
-        S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st));
+        S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st, add_parts ? &x.part : nullptr));
         if (!roll) return 0;
         return rank1_tables(y, *cw, mp, mv, rrow, rcol);
     }
@@ -351,7 +358,7 @@ struct Fwd {
                 if (roll) S3D_TRY(rank1_tables(y1, rb.c1, mp, mv, rr, rc));
             }
         }
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 1));
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, tape ? 1 : 2));   // inference: partials only (norm_act adds them)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, nullptr));
         S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, &skip, out, out_stats));
         return 0;
@@ -377,7 +384,7 @@ struct Fwd {
         RBTape rt;
         RBTape* T = tape ? &rt : nullptr;
         S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc, T ? &T->n1 : nullptr));
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 1));      // (!ssn: h = h + emb_out, :298-303)
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, tape ? 1 : 2));   // inference: partials only (norm_act adds them)      // (!ssn: h = h + emb_out, :298-303)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, T ? &T->n2 : nullptr));
         if (fork) S3D_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
         S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_stats_override >= 0 ? out_stats_override : (out_feeds_norm ? 1 : 0)));

@@ -270,7 +270,8 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         Tri o;
         // the deepest output goes straight into a norm; the others become the skip half of a concat later: in the
         // inference forward their producing convolution leaves the GroupNorm partials with them (Fwd::resblock_cat)
-        S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1, level == c.n_levels - 1 ? -1 : (tape ? 0 : 2)));
+        // (... and the deepest one's too: the GN-act kernel of the first output block adds them itself)
+        S3D_TRY(f.resblock(m->in_blocks[level], h, o, level == c.n_levels - 1, tape ? (level == c.n_levels - 1 ? -1 : 0) : 2));
         if (tape) { f.last_rb.index = level; f.last_rb.is_out = false; tape->in_rb.push_back(f.last_rb); }
         h = o;
         hs.push_back(o);

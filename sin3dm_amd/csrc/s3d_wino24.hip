@@ -597,25 +597,42 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
         }
     }
     if (p_gn) {
+        // one partial per BLOCK: the four waves' sums meet through LDS (wave order, double) — a quarter of the records for
+        // the statistics' readers (the GN-act kernel adds them itself, s3d_kernels.hip:k_gn_act)
+        __shared__ float gred[4][8][8];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
-        const int sg = args.gn_sg;
-        const int part = tile_idx * 4 + u;
-        auto put = [&](int sub, float s, float ss) {
-            double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
-            dst[0] = double(s); dst[1] = double(ss);
-        };
-        if (sg >= 4) {
-            float s = (gs4[0] + gs4[1]) + (gs4[2] + gs4[3]), ss = (gss4[0] + gss4[1]) + (gss4[2] + gss4[3]);
-            for (int off = 1; off < (sg >> 2); off <<= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
-            if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, s, ss);
-        } else if (lane < 8 && c_ok) {
+        if (lane < 8) {
 #pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                if (sg == 2) put((co4 + e) / 2, gs4[e] + gs4[e + 1], gss4[e] + gss4[e + 1]);
-                else { put(co4 + e, gs4[e], gss4[e]); put(co4 + e + 1, gs4[e + 1], gss4[e + 1]); }
+            for (int e = 0; e < 4; ++e) { gred[u][lane][e] = gs4[e]; gred[u][lane][4 + e] = gss4[e]; }
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // lanes 0..7 of wave 0: channel quad `quad` = lane
+            double ds[4], dss[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int l8 = lane & 7;
+                ds[e] = ((double(gred[0][l8][e]) + double(gred[1][l8][e])) + double(gred[2][l8][e])) + double(gred[3][l8][e]);
+                dss[e] = ((double(gred[0][l8][4 + e]) + double(gred[1][l8][4 + e])) + double(gred[2][l8][4 + e])) + double(gred[3][l8][4 + e]);
+            }
+            const int sg = args.gn_sg;
+            const int part = tile_idx;
+            auto put = [&](int sub, double sv, double ssv) {
+                double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+                dst[0] = sv; dst[1] = ssv;
+            };
+            if (sg >= 4) {
+                double sv = (ds[0] + ds[1]) + (ds[2] + ds[3]), ssv = (dss[0] + dss[1]) + (dss[2] + dss[3]);
+                for (int off = 1; off < (sg >> 2); off <<= 1) { sv += __shfl_xor(sv, off, 64); ssv += __shfl_xor(ssv, off, 64); }
+                if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, sv, ssv);
+            } else if (lane < 8 && c_ok) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    if (sg == 2) put((co4 + e) / 2, ds[e] + ds[e + 1], dss[e] + dss[e + 1]);
+                    else { put(co4 + e, ds[e], dss[e]); put(co4 + e + 1, ds[e + 1], dss[e + 1]); }
+                }
             }
         }
     }
