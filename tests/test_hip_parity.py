@@ -99,14 +99,15 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["24", "24big", "4", "2", "0", "novcat", "oldhead"])
+@pytest.mark.parametrize("variant", ["24", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
 def test_unet_forward_golden_other_conv_kernels(variant):
     """Every 3x3 kernel on the golden planes (S3D_WINO=24: mixed Winograd F(2x4,3x3), 8x16-pixel blocks — the default;
     24big: its 16x16-pixel form forced onto every layer with S3D_WINO24_BIG_MIN_BLOCKS=0; 4 / 2: F(2x2) with one / two
     frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors, leaf convolutions and ragged
     shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual concat of
-    Fwd::resblock_cat; oldhead: S3D_OUT_HEAD=0, the thread-per-quad output head.  The choices are read once per process,
-    hence the subprocess."""
+    Fwd::resblock_cat; oldhead: S3D_OUT_HEAD=0, the thread-per-quad output head; gnsplit: S3D_GN_FUSED=0, every GroupNorm
+    statistic through k_gn_finalize instead of being added inside k_gn_act.  The choices are read once per process, hence
+    the subprocess."""
     import os, subprocess, sys
     code = (
         "import numpy as np, torch, sys\n"
@@ -125,7 +126,7 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
     env = {"24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
-           "oldhead": dict(S3D_OUT_HEAD="0")}.get(variant, dict(S3D_WINO=variant))
+           "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0")}.get(variant, dict(S3D_WINO=variant))
     env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
