@@ -485,6 +485,7 @@ struct GnActArgs {
     // mr == null && part != null: the statistics come from the producer's partial sums, added here (every block adds the
     // parts of its plane's 32 groups itself: 64 KB from L2 at 128^2 x 128 channels, instead of a k_gn_finalize launch)
     const double* part; int nparts[3], maxparts, nsub, spg; double count[3];
+    float* mr_out;            // ... and block 0 of each (plane, sample) also leaves {mean, rstd} [B][3][32][2] (the training tape)
 };
 __global__ void k_gn_act(GnActArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -534,6 +535,10 @@ __global__ void k_gn_act(GnActArgs a) {
             if (var < 0) var = 0;
             float* stf = reinterpret_cast<float*>(sd + 2 * blockDim.x);     // behind the lanes' sums: no second barrier
             stf[tid] = float(m); stf[32 + tid] = float(1.0 / sqrt(var + 1e-5));
+            if (a.mr_out && blockIdx.x == 0) {
+                float* o = a.mr_out + ((size_t(b) * 3 + p) * 32 + tid) * 2;
+                o[0] = stf[tid]; o[1] = stf[32 + tid];
+            }
         }
         sm = reinterpret_cast<float*>(sd + 2 * blockDim.x);
     }
@@ -611,9 +616,10 @@ bool gn_act_can_add_parts(const GnPartials& part, int C) {
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
                   hipStream_t st, const GnPartials* stats_part) {
     GnActArgs a;
-    a.part = nullptr;
-    if (stats_part) {
-        S3D_CHECK(!stats.mr && gn_act_can_add_parts(*stats_part, x.C), S3D_ERR_INVALID, "gn_act: partial-sum statistics layout");
+    a.part = nullptr; a.mr_out = nullptr;
+    if (stats_part) {                                     // stats.mr (optional) then receives the statistics instead of providing them
+        S3D_CHECK(gn_act_can_add_parts(*stats_part, x.C), S3D_ERR_INVALID, "gn_act: partial-sum statistics layout");
+        a.mr_out = stats.mr; stats.mr = nullptr;
         a.part = stats_part->p; a.maxparts = stats_part->maxparts; a.nsub = stats_part->nsub; a.spg = stats_part->nsub / 32;
         for (int p = 0; p < 3; ++p) { a.nparts[p] = stats_part->nparts[p]; a.count[p] = double(x.C / 32) * x.g.h[p] * x.g.w[p]; }
     }

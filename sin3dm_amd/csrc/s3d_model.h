@@ -261,9 +261,11 @@ struct Fwd {
                  const float* rcol[3], NormTape* nt = nullptr) {
         const bool measuring = ar().measuring;
         GnStats stats{nullptr};
-        // inference: when x carries its producer's partial sums and they are few, the act kernel adds them itself
-        const bool add_parts = !nt && !x.gn && gn_act_can_add_parts(x.part, x.C);
+        // when x carries its producer's partial sums and they are few, the act kernel adds them itself
+        // (with a tape, block 0 of each plane also writes them out for the backward pass)
+        const bool add_parts = !x.gn && gn_act_can_add_parts(x.part, x.C);
         if (!add_parts) S3D_TRY(stats_of(x, stats));
+        else if (nt) stats.mr = ar().alloc<float>(size_t(B) * 3 * 64);
         if (nt) { nt->stats = stats; nt->roll = cw && cw->rollout; }
         y = alloc_tri(x.C, x.g);
         ActArgs aa;
@@ -358,7 +360,7 @@ struct Fwd {
                 if (roll) S3D_TRY(rank1_tables(y1, rb.c1, mp, mv, rr, rc));
             }
         }
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, tape ? 1 : 2));   // inference: partials only (norm_act adds them)
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 2));   // partials only (norm_act adds them)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, nullptr));
         S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, &skip, out, out_stats));
         return 0;
@@ -384,7 +386,7 @@ struct Fwd {
         RBTape rt;
         RBTape* T = tape ? &rt : nullptr;
         S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc, T ? &T->n1 : nullptr));
-        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, tape ? 1 : 2));   // inference: partials only (norm_act adds them)      // (!ssn: h = h + emb_out, :298-303)
+        S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 2));   // partials only (norm_act adds them)      // (!ssn: h = h + emb_out, :298-303)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, T ? &T->n2 : nullptr));
         if (fork) S3D_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
         S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_stats_override >= 0 ? out_stats_override : (out_feeds_norm ? 1 : 0)));
