@@ -20,8 +20,6 @@ handful of steps to reach steady clocks and warm caches (round 1: 1.145 ms/step 
 import argparse
 import json
 import os
-import socket
-import subprocess
 import sys
 import time
 
@@ -33,7 +31,7 @@ HWD = (128, 128, 128)
 T_STEPS = 1000
 PREWARM = 60
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
-TRAFFIC_PROFILE = "profiles/r02_pmc_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
 
 
 def f_dense_per_step(mc, H, W, D, mult=(1, 2)):
@@ -145,33 +143,22 @@ def s3d_switches():
 
 # ------------------------------------------------------------------------------------------------ launcher
 def spawn_workers(args, argv):
-    """`python bench.py --gpus N` without a torchrun environment: N fresh processes, one per GPU.  The parent never
-    initialises the GPU (no HIP call, no torch.cuda.*), never exec()s, and forwards rank 0's JSON line."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    line = next((l for l in reversed((out0 or "").splitlines()) if l.startswith("{")), None)
-    bad = [i for i, rc in enumerate(rcs) if rc != 0]
-    if bad or line is None:
-        sys.stderr.write(f"bench.py: worker rank(s) {bad} failed (exit codes {rcs}); rank 0 stdout tail: {(out0 or '')[-400:]!r}\n")
-        return 1
-    print(line, flush=True)
-    return 0
+    """`python bench.py --gpus N` without a torchrun environment: N fresh processes, one per GPU (sin3dm_amd/launcher.py).
+    The parent never initialises the GPU (no HIP call, no torch.cuda.*), never exec()s, watches ALL children — the first
+    non-zero exit stops the others within seconds — and forwards rank 0's JSON line."""
+    from sin3dm_amd.launcher import spawn_ranks
+    return spawn_ranks(os.path.abspath(__file__), argv, args.gpus)
+
+
+def csrc_sha256():
+    """sha256 over the kernel sources the committed PMC traffic figure was measured with (tools/pmc_traffic.py stores it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "sin3dm_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "sin3dm_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 # ------------------------------------------------------------------------------------------------ worker
@@ -186,9 +173,12 @@ def worker(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     H, W, D = HWD
 
+    ident = {"device_index": None, "pci_bus_id": None, "uuid": None, "name": "cpu (dry run)"}
     if args.dry_run:
         # plumbing check without a GPU (tests/test_bench_launch.py): same rendezvous / barrier / max-over-ranks / JSON
         # path over gloo, the step replaced by a sleep.  Never a measurement: the line says so.
+        if args.dry_run_fail_rank == rank and args.dry_run_fail_early:
+            raise SystemExit(4)                                    # a rank that dies BEFORE the rendezvous
         if world > 1:
             dist.init_process_group("gloo")
         if args.dry_run_fail_rank == rank:
@@ -201,9 +191,15 @@ def worker(args):
         from sin3dm_amd import _lib, testing as T
         from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
         from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
+        from sin3dm_amd.launcher import device_identity
+        ndev = torch.cuda.device_count()                             # (counting devices does not initialise the GPU)
+        if local >= ndev or world > ndev:                             # (--nnodes=1 by contract)
+            raise SystemExit(f"bench.py: --gpus {args.gpus} (rank {rank}, LOCAL_RANK {local}) but this node shows {ndev} GPU(s): "
+                             f"one process per GPU needs N <= {ndev}")
         _lib.require_gpu()
         torch.cuda.set_device(local)
         dev = torch.device(f"cuda:{local}")
+        ident = device_identity(local)
         if world > 1:
             dist.init_process_group("nccl", device_id=dev)
         model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
@@ -246,14 +242,24 @@ def worker(args):
         model.profile(0)
         assert torch.isfinite(state["x"]).all()
 
+    # every rank reports who it was and what it measured: the line shows N distinct devices, not just a world size
+    mine = dict(ident, rank=rank, ms_per_step=round(dt / args.steps * 1e3, 4))
+    ranks, backend_world = [mine], 1
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        backend_world = dist.get_world_size()
+        backend = dist.get_backend()
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return 0
+    distinct = {(r["pci_bus_id"], r["uuid"], r["device_index"]) for r in ranks}
+    if not args.dry_run and len(distinct) != world:
+        raise SystemExit(f"bench.py: {world} ranks but only {len(distinct)} distinct devices: {ranks}")
 
     ms_step = dt / args.steps * 1e3
     value = world * args.steps / T_STEPS / dt
@@ -266,11 +272,17 @@ def worker(args):
         executed = prof.mfma_flops[0] / sec / 1e12                 # what the matrix cores multiply: the hardware rate
         algorithmic = prof.flops[0] / sec / 1e12
         traffic, traffic_src = None, None
-        if not switches:     # the committed PMC passes were taken with the default kernels
+        if not switches:     # the committed PMC passes were taken with the default kernels ...
             try:
-                traffic = json.load(open(os.path.join(REPO, TRAFFIC_PROFILE)))["dominant_traffic_bytes_per_launch"]
-                traffic_src = (f"from_committed_profile {TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command "
-                               "(separate passes, gfx950 2x read correction); not re-measured in this run")
+                tp = json.load(open(os.path.join(REPO, TRAFFIC_PROFILE)))
+                if tp.get("csrc_sha256") == csrc_sha256():            # ... of exactly this tree's kernel sources
+                    traffic = tp["dominant_traffic_bytes_per_launch"]
+                    traffic_src = (f"from_committed_profile {TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command "
+                                   "(separate passes, gfx950 2x read correction), kernel sources unchanged since (sha256 match); "
+                                   "not re-measured in this run")
+                else:
+                    traffic_src = (f"dropped: {TRAFFIC_PROFILE} was measured on other kernel sources "
+                                   f"(csrc sha256 {str(tp.get('csrc_sha256'))[:12]} != {csrc_sha256()[:12]}); re-run tools/refresh_profiles.sh")
             except (OSError, KeyError, ValueError):
                 pass
         roof = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -278,9 +290,8 @@ def worker(args):
                 "algorithmic_tflops": round(algorithmic, 2),
                 "hbm_gbs": round(traffic / avg_s / 1e9, 1) if traffic else None,
                 "hbm_frac_of_8TBs": round(traffic / avg_s / 8e12, 4) if traffic else None,
-                "kernel": "the dense 3x3 TriplaneConv kernel (own-channel part of the rollout convolution): "
-                          + {"0": "k_conv_mfma<3x3> direct", "2": "k_conv_wino2 Winograd F(2x2,3x3)", "6": "k_conv_wino6 Winograd F(4x4,3x3)"}.get(
-                              os.environ.get("S3D_WINO", ""), "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks (k_conv_wino4 F(2x2) for layers it does not take)"),
+                "kernel": "the dense 3x3 TriplaneConv kernel (own-channel part of the rollout convolution), as reported by the "
+                          "library for the timed launches: " + model.profile_kernel(0),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(prof.launches[0]),
                 "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
                 "mfma_flops_per_launch_avg": prof.mfma_flops[0] / prof.launches[0],
@@ -303,7 +314,9 @@ def worker(args):
                        "prewarm_steps": PREWARM},
             "f_dense_gflop_per_step": round(fd / 1e9, 2),
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
-            "roofline": roof, "s3d_switches": switches}
+            "roofline": roof, "s3d_switches": switches,
+            "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks],
+            "rccl_world_size": backend_world if world > 1 else None, "dist_backend": backend if world > 1 else None}
     if args.dry_run:
         line["data"] = "DRY RUN (no GPU work: launcher / rendezvous plumbing check only)"
         line["value"] = 0.0
@@ -327,6 +340,7 @@ def main():
     ap.add_argument("--profile-every", type=int, default=8, help="instrument every n-th step with HIP events (0=off)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-fail-early", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args, sys.argv[1:])

@@ -89,4 +89,8 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
+    from .launcher import maybe_spawn_module
+    rc = maybe_spawn_module("sin3dm_amd.sample")      # S3D_GPUS=N: N fresh ranks, one per GPU (this process touches none)
+    if rc is not None:
+        raise SystemExit(rc)
     main()

@@ -3,6 +3,7 @@
     python -m sin3dm_amd.train --tag EXP --data_path shape.npz [--only_enc] [--enc_n_iters 25000 --diff_n_iters 25000 ...]
     python -m sin3dm_amd.train --tag EXP --enc_log PATH/TO/encoding            # reuse an existing encoding
     python -m torch.distributed.run --nproc-per-node 8 -m sin3dm_amd.train --tag EXP --data_path ... --diff_batch_size 4
+    S3D_GPUS=8 python -m sin3dm_amd.train --tag EXP --data_path ... --diff_batch_size 4     # the same, self-launched (sin3dm_amd/launcher.py)
 
 Stage 1 (src/train.py:8-29): ShapeAutoEncoder.train on the preprocessed shape, then EXP/encoding/{args.json, feat.npz,
 ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it, the others wait.
@@ -79,4 +80,8 @@ def main(argv=None, confirm=input):
 
 
 if __name__ == "__main__":
+    from .launcher import maybe_spawn_module
+    rc = maybe_spawn_module("sin3dm_amd.train")       # S3D_GPUS=N: N fresh ranks, one per GPU (this process touches none)
+    if rc is not None:
+        raise SystemExit(rc)
     main()

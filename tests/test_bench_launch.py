@@ -47,3 +47,36 @@ def test_switches_are_recorded():
     r = _run("--gpus", "1", env={"S3D_WINO": "2", "S3D_XCD": "0"})
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["s3d_switches"] == {"S3D_WINO": "2", "S3D_XCD": "0"}
+
+
+def test_peer_that_dies_before_rendezvous_ends_the_launch_within_seconds():
+    """Rank 1 exits before init_process_group: rank 0 would sit in the store rendezvous for minutes.  The launcher polls
+    all children, stops the survivor and fails fast."""
+    import time
+    t0 = time.time()
+    r = _run("--gpus", "2", "--dry-run-fail-rank", "1", "--dry-run-fail-early")
+    dt = time.time() - t0
+    assert r.returncode != 0
+    assert dt < 60, f"launcher took {dt:.0f} s to notice a dead peer"
+    assert "rank(s) [1]" in r.stderr and "stopped" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_line_reports_every_rank():
+    r = _run("--gpus", "2")
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert [x["rank"] for x in line["ranks"]] == [0, 1] and len(line["per_rank_ms"]) == 2
+    assert line["rccl_world_size"] == 2 and line["dist_backend"] == "gloo"     # (nccl = RCCL on the GPU box)
+
+
+def test_launch_deadline(tmp_path):
+    """A hung rank (sleeps forever) is bounded by S3D_LAUNCH_TIMEOUT."""
+    import time
+    from sin3dm_amd.launcher import spawn_ranks
+    script = tmp_path / "hang.py"
+    script.write_text("import time\ntime.sleep(600)\n")
+    import io
+    err = io.StringIO()
+    t0 = time.time()
+    rc = spawn_ranks(str(script), [], 2, timeout=2.0, err=err)
+    assert rc == 1 and time.time() - t0 < 30 and "no result after" in err.getvalue()

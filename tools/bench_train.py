@@ -3,7 +3,8 @@
 batch 4 per GPU) — not the scored bench line (bench.py measures sampling).
 
     python tools/bench_train.py [--mc 64] [--hwd 92 128 92] [--batch 4] [--steps 20] [--cpu-baseline]
-    python -m torch.distributed.run --nproc-per-node N tools/bench_train.py ...      # data parallel, one all-reduce/step
+    python tools/bench_train.py --gpus N ...                                         # data parallel: N fresh ranks (sin3dm_amd/launcher.py)
+    python -m torch.distributed.run --nproc-per-node N tools/bench_train.py --gpus N ...   # the same under torchrun
 
 A step = timestep draw + q_sample + UNet forward + per-plane MSE + UNet backward (+ gradient all-reduce) + fused
 AdamW/EMA + device-side weight repack.  Prints one JSON line on rank 0."""
@@ -15,6 +16,16 @@ import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ:
+    # --gpus N without a torchrun environment: this process touches no GPU, starts N fresh ranks and relays rank 0's line
+    _pre = argparse.ArgumentParser(add_help=False)
+    _pre.add_argument("--gpus", type=int, default=1)
+    _n = _pre.parse_known_args()[0].gpus
+    if _n > 1:
+        from sin3dm_amd.launcher import spawn_ranks
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], _n))
+
 import torch
 import torch.distributed as dist
 
@@ -31,9 +42,15 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--cpu-baseline", action="store_true")
+ap.add_argument("--gpus", type=int, default=1)
+ap.add_argument("--overlap", type=int, default=-1, help="gradient all-reduce chunks overlapped with backward (-1: TrainLoop default)")
 args = ap.parse_args()
 
 rank, local, world = parallel.env_rank_world()
+if world != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+if local >= torch.cuda.device_count():
+    raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but this node shows {torch.cuda.device_count()} GPU(s)")
 torch.cuda.set_device(local)
 dev = torch.device(f"cuda:{local}")
 parallel.init(device=dev)

@@ -8,7 +8,11 @@ FETCH_SIZE is reported in KB and, on gfx950, counts 64 B per 128-B request for w
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_sha256
 
 
 def per_kernel(path, counter):
@@ -36,6 +40,7 @@ for k in fetch:
                          "hbm_read_bytes": int(2 * f / n * 1024), "hbm_write_bytes": int(w[0] / max(w[1], 1) * 1024)}
 d = [v for k, v in out["kernels"].items() if dom in k][0]
 out["dominant_kernel"] = dom
+out["csrc_sha256"] = csrc_sha256()      # bench.py drops the traffic field when the kernel sources have changed since
 out["dominant_traffic_bytes_per_launch"] = d["hbm_read_bytes"] + d["hbm_write_bytes"]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(dom, d, out["dominant_traffic_bytes_per_launch"])
