@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define S3D_ABI_VERSION 2
+#define S3D_ABI_VERSION 3
 #define S3D_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -80,7 +80,10 @@ S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B,
  * weights): a sampling loop that knows them on the host (GaussianDiffusion._loop) computes each table once and reuses it
  * for every sample.  s3d_unet_film: timestep_embedding -> time_embed -> all emb_layers (nn.py:103-121,
  * unet_triplane.py:371-375, 232-238, 477, 281) for n timestep values t (device fp32) -> film [n][s3d_unet_film_width()].
- * s3d_unet_forward_film: forward() with that table; film_stride = width (one row per sample) or 0 (all samples share row 0). */
+ * s3d_unet_forward_film: forward() with that table; film_stride = width (one row per sample) or 0 (all samples share row 0).
+ * Streams: every call on one handle uses handle-owned scratch (the workspace arena, s3d_unet_film's hidden vectors) without
+ * internal events — issue the calls of a handle from ONE stream at a time, and make a stream that consumes a film table
+ * produced on another stream wait for it (the Python mirror records an event with each cached table and does so). */
 S3D_API int s3d_unet_film_width(const s3d_unet* m);
 S3D_API int s3d_unet_film(s3d_unet* m, const float* t, int n, float* film, void* stream);
 S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film, int film_stride, int B, int H, int W, int D,
@@ -90,7 +93,9 @@ S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film
  * MFMA convolution launch of each `every`-th forward (0 = off).  s3d_unet_profile_read waits for the
  * recorded events, ADDS their durations to `out` (caller zero-initialises) and recycles them.
  * flops = algorithmic flops of the launches, 2*taps*cin*cout*pixels; mfma_flops = what the
- * matrix cores really multiply for them (Winograd F(2x2,3x3): 4/9 of the direct count, F(4x4,3x3): 1/4). */
+ * matrix cores really multiply for them (Winograd F(2x2,3x3): 4/9 of the direct count, F(2x4,3x3): 1/3, F(4x4,3x3): 1/4).
+ * s3d_unet_profile_kernel: name of the kernel the most recent timed launch of class cls actually dispatched ("" if none):
+ * bench.py labels its roofline line with it instead of deriving a name from environment switches. */
 typedef struct {
     double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */
     double flops[3];
@@ -100,6 +105,7 @@ typedef struct {
 } s3d_profile;
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
+S3D_API const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls);
 
 /* ------------------------------------------------------------------------------------------
  * Sampler update: GaussianDiffusion.p_mean_variance + p_sample / ddim_sample

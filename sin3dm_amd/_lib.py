@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsin3dm_hip.so")
 c_fp = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 TAB_ROWS = ("sqrt_recip", "sqrt_recipm1", "coef1", "coef2", "logvar", "acp", "acp_prev")
 STEP_DDPM, STEP_DDIM, STEP_MEAN_ONLY = 0, 1, 2
 MEAN_START_X, MEAN_EPSILON = 0, 1
@@ -68,6 +68,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     "s3d_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "s3d_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
+    "s3d_unet_profile_kernel": (C.c_char_p, [C.c_void_p, C.c_int]),
     "s3d_sampler_step": (C.c_int, [C.POINTER(SamplerArgs), C.c_void_p]),
     "s3d_op_triplane_conv": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),

@@ -134,6 +134,9 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
 // Selected with S3D_CONV_IMPL=naive; never the default.
 int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st);
 bool conv_use_naive();
+// every launcher notes the kernel it dispatched (thread-local; read back by s3d_unet::timed_conv for s3d_unet_profile_kernel)
+void conv_note_kernel(const char* name);
+const char* conv_last_kernel();
 // MFMA flops a launch really issues / its direct-convolution flop count (1 for the direct kernels, 4/9 for Winograd F(2x2,3x3))
 double conv_exec_fraction(ConvKind kind, const ConvArgs& a);
 

@@ -520,6 +520,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     // (measured in round 2 and dropped: whole-chunk stages with two chunks of loads in flight, and eight waves per block —
     // 9.4 / 14.7 / 18.7 us at 128 / 256 / 384 channels either way: the launch is bound by the ~21 MB per 128-channel chunk that
     // 384 blocks pull through L2 at once, not by its stage latency or its MFMA chains)
+    conv_note_kernel(roll3 ? "k_rank1<true> (three-tap rollout tables)" : "k_rank1<false>");
     if (roll3) hipLaunchKernelGGL(k_rank1<true>, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_rank1<false>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
@@ -539,6 +540,10 @@ void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24) {
     for (int p = 0; p < 3; ++p)
         nparts[p] = ((g.w[p] + CFG::TW - 1) / CFG::TW) * ((g.h[p] + CFG::TH - 1) / CFG::TH) * CFG::WM;
 }
+
+static thread_local const char* t_last_kernel = "";
+void conv_note_kernel(const char* name) { t_last_kernel = name; }
+const char* conv_last_kernel() { return t_last_kernel; }
 
 bool conv_use_naive() {
     static int v = -1;
@@ -561,6 +566,7 @@ static void kind_taps(ConvKind kind, int& KH, int& KW) {
 int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st) {
     int KH, KW;
     kind_taps(kind, KH, KW);
+    conv_note_kernel("k_conv_naive (one thread per output, S3D_CONV_IMPL=naive)");
     hipLaunchKernelGGL(k_conv_naive, dim3(2048), dim3(256), 0, st, a, KH, KW);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -580,6 +586,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
     if (!blocks) return 0;
     static const int xcd = getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1;
     a.xcd_swizzle = xcd;
+    conv_note_kernel(CFG::KH == 3 ? "k_conv_mfma<3x3> direct MFMA convolution" : (CFG::KH == 1 ? "k_conv_mfma<1x1> direct MFMA convolution" : "k_conv_mfma<5x5> direct MFMA convolution"));
     hipLaunchKernelGGL(k_conv_mfma<CFG>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

@@ -118,6 +118,7 @@ struct s3d_unet {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int64_t prof_forwards = 0;
+    const char* prof_kernel[3] = {"", "", ""};
     hipEvent_t prof_event() {
         hipEvent_t e = nullptr;
         if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
@@ -134,6 +135,7 @@ struct s3d_unet {
         r.mfma_flops = r.flops * conv_exec_fraction(kind, ca);
         if (r.e0) (void)hipEventRecord(r.e0, st);
         int rc = launch_conv(kind, ca, st);
+        if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
         if (r.e1) (void)hipEventRecord(r.e1, st);
         prof_recs.push_back(r);
         return rc;

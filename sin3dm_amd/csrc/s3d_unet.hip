@@ -486,4 +486,8 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
     return 0;
 }
 
+const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls) {
+    return m && cls >= 0 && cls < 3 ? m->prof_kernel[cls] : "";
+}
+
 }  // extern "C"

@@ -677,6 +677,7 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st) {
     if (!blocks) return 0;
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
+    conv_note_kernel(four ? "k_conv_wino4 Winograd F(2x2,3x3), one frequency row per wave" : "k_conv_wino2 Winograd F(2x2,3x3), two waves per SIMD");
     if (four) hipLaunchKernelGGL(k_conv_wino4, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());

@@ -712,6 +712,7 @@ int launch_conv_wino24s(ConvArgs& a, hipStream_t st) {
     if (!blocks) return 0;
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
+    conv_note_kernel("k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks");
     hipLaunchKernelGGL(k_conv_wino24s, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -732,6 +733,7 @@ int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
     if (!blocks) return 0;
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
+    conv_note_kernel("k_conv_wino24 mixed Winograd F(2x4,3x3), 16x16-pixel blocks");
     hipLaunchKernelGGL(k_conv_wino24, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

@@ -106,14 +106,16 @@ class _WrappedModel:
         return self.model.parameters()
 
     def _mapped(self, v):
-        m = float(self.timestep_map[v])
-        return m * (1000.0 / self.original_num_steps) if self.rescale_timesteps else m
+        # the reference multiplies an fp32 tensor by the python scalar (respace.py:124-128): fp32 x fp32(scalar), rounded
+        # once — done the same way here so that the host-known path feeds the denoiser the identical float
+        m = np.float32(self.timestep_map[v])
+        return float(m * np.float32(1000.0 / self.original_num_steps)) if self.rescale_timesteps else float(m)
 
     def prepare_loop(self, num_timesteps, batch, device):
         """Called by the sampling loops before their first step: the mapped timesteps of the whole schedule as ONE device
         tensor (row i = the batch's timesteps of loop index i) and, if the denoiser offers it, its per-timestep tables in
         one batched launch — instead of a host-to-device copy and three small launches on the first visit of every index."""
-        key = str(device)
+        key = str(th.empty(0, device=device).device)      # 'cuda' -> 'cuda:0': the key __call__ derives from ts.device
         sched = ("schedule", key, batch)
         entry = self._maps.get(sched)
         if entry is None:

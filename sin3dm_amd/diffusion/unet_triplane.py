@@ -252,6 +252,10 @@ class _TriplaneUNetBase(nn.Module):
         _lib.check(_lib.load().s3d_unet_profile_read(self._handle, C.byref(prof)))
         return prof
 
+    def profile_kernel(self, cls=0):
+        """Name of the kernel the most recent timed launch of class cls (0: 3x3, 1: 1x1, 2: rank-1) dispatched."""
+        return (_lib.load().s3d_unet_profile_kernel(self._handle, int(cls)) or b"").decode()
+
     def convert_to_fp16(self):
         raise NotImplementedError("fp16 is not runnable in the reference (see __init__)")
 
@@ -301,18 +305,38 @@ class _TriplaneUNetBase(nn.Module):
         film = th.empty((len(values), width), device=t.device, dtype=th.float32)
         with th.cuda.device(t.device):
             _lib.check(lib.s3d_unet_film(self._handle, _lib.ptr(t), len(values), _lib.ptr(film), _lib.stream_ptr()))
+        # tables are produced on the stream that is current NOW; a later forward on another stream waits for this event
+        # (s3d_unet_film's scratch is shared per handle: calls on one handle are expected to be issued from one stream at a time)
+        mark = self._film_mark(t.device)
         for k, v in enumerate(values):
-            self._film_cache[(dkey, v)] = film[k:k + 1]
+            self._film_cache[(dkey, v)] = (film[k:k + 1], mark)
+
+    @staticmethod
+    def _film_mark(device):
+        st = th.cuda.current_stream(device)
+        ev = th.cuda.Event()
+        ev.record(st)
+        return (st.cuda_stream, ev)
+
+    @staticmethod
+    def _film_wait(mark, device):
+        st = th.cuda.current_stream(device)
+        if st.cuda_stream != mark[0]:
+            st.wait_event(mark[1])
 
     def _film_for(self, lib, hv, t):
         """(device FiLM table, row stride) for host-known timestep values: one row when the batch shares a value."""
         same = all(v == hv[0] for v in hv)
         key = (str(t.device), hv[0] if same else hv)
-        film = self._film_cache.get(key)
-        if film is None and same and self._film_sched is not None and hv[0] in self._film_sched[0] \
+        hit = self._film_cache.get(key)
+        if hit is None and same and self._film_sched is not None and hv[0] in self._film_sched[0] \
                 and str(self._film_sched[1].device) == str(t.device):
             self.prepare_timesteps(*self._film_sched)          # (the weights changed: refill the schedule's tables at once)
-            film = self._film_cache.get(key)
+            hit = self._film_cache.get(key)
+        film = None
+        if hit is not None:
+            film = hit[0]
+            self._film_wait(hit[1], t.device)
         if film is None:
             if len(self._film_cache) > 4096:
                 self._film_cache.clear()
@@ -320,7 +344,7 @@ class _TriplaneUNetBase(nn.Module):
             width = lib.s3d_unet_film_width(self._handle)
             film = th.empty((n, width), device=t.device, dtype=th.float32)
             _lib.check(lib.s3d_unet_film(self._handle, _lib.ptr(t[:n].contiguous()), n, _lib.ptr(film), _lib.stream_ptr()))
-            self._film_cache[key] = film
+            self._film_cache[key] = (film, self._film_mark(t.device))
         return film, (0 if same else film.shape[1])
 
     def _prep(self, x, timesteps, H, W, D):

@@ -100,3 +100,27 @@ def test_sample_args_roundtrip(tmp_path):
     assert saved["model_channels"] == 128 and saved["channel_mult"] == "1,2" and saved["use_scale_shift_norm"] is True
     s = pu.sample_args(["--tag", str(tag), "--timestep_respacing", "100", "--use_ddim", "True"])
     assert s.model_channels == 128 and s.timestep_respacing == "100" and s.use_ddim is True and s.fdim_geo == 4
+
+
+@pytest.mark.parametrize("orig,respacing", [(1000, "100"), (200, ""), (300, "50"), (4000, "ddim25"), (777, "")])
+def test_host_mapped_timesteps_equal_the_tensor_path(orig, respacing):
+    """_WrappedModel maps host-known timesteps on the host; the value must be the float the tensor path (and the reference,
+    respace.py:123-128: fp32 tensor x python scalar) produces, also when 1000/original_num_steps is not exact."""
+    from sin3dm_amd.diffusion.gaussian_diffusion import HostTimesteps
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    d = create_gaussian_diffusion(steps=orig, timestep_respacing=respacing, rescale_timesteps=True)
+    seen = {}
+
+    class Probe:
+        def __call__(self, x, ts, **kw):
+            seen["ts"] = ts
+            return x
+    wrapped = d._wrap_model(Probe())
+    n = d.num_timesteps
+    idx = torch.arange(n)
+    wrapped(torch.zeros(n), idx)                                   # tensor path
+    via_tensor = seen["ts"].clone()
+    for i in (0, 1, n // 3, n - 1):
+        wrapped(torch.zeros(2), HostTimesteps(torch.tensor([i, i]), (i, i)))
+        assert torch.equal(torch.as_tensor(seen["ts"]).float(), via_tensor[i].expand(2)), (i, seen["ts"], via_tensor[i])
+        assert seen["ts"].host_values == (float(via_tensor[i]),) * 2
