@@ -106,6 +106,11 @@ typedef struct {
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
 S3D_API const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls);
+/* The 3x3 convolution launches run the rollout's means + rank-1 tables (unet_triplane.py:37-58) as producer blocks of the same
+ * launch; consumers poll with a bound.  *err = 0 if no block ever gave up waiting since the handle was created (1: a table
+ * producer timed out on the means, 2: a convolution block timed out on the tables — results are then invalid).
+ * Synchronises the device. */
+S3D_API int s3d_unet_sync_errors(s3d_unet* m, int* err);
 
 /* ------------------------------------------------------------------------------------------
  * Sampler update: GaussianDiffusion.p_mean_variance + p_sample / ddim_sample

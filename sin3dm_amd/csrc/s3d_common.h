@@ -129,7 +129,10 @@ struct ConvArgs {
 // CONV_1x3_ROLL: the forward rollout tables — args.cout = the convolution's cout, out [B][pos][4 variants][cout] (k_rank1<true>)
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3, CONV_1x3_ROLL = 4 };
 // Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.
-int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
+struct R1Inline;
+// r1 (3x3 only, and only when conv_wino24_geo() == 1, i.e. the launch goes to k_conv_wino24s): the rollout's means + tables run
+// as producer blocks of this launch; sync_expect = the host mirror of the handle's hand-off counters
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1 = nullptr, unsigned* sync_expect = nullptr);
 // Debug/triangulation path: a plain one-thread-per-output direct convolution (no MFMA, no LDS).
 // Selected with S3D_CONV_IMPL=naive; never the default.
 int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st);
@@ -235,8 +238,35 @@ bool gn_act_can_add_parts(const GnPartials& part, int C);
 int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                       hipStream_t st);
 // finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
-struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
+// base / bytes: when the six vectors are ONE allocation (Fwd::roll_buffers) — the in-launch form stores them through one buffer descriptor
+struct MeanVecs { float* rowmean[3]; float* colmean[3]; float* base = nullptr; size_t bytes = 0; };
+struct MeanFinArgs {
+    const float* rowpart[3]; const float* colpart[3];
+    float* rowmean[3]; float* colmean[3];
+    int h[3], w[3];
+    int C, cq, B;
+    long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
+    float* mean_base; unsigned mean_bytes;
+};
+MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv);
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);
+
+// The rollout's small dependent stages run INSIDE the 3x3 convolution launch (s3d_rank1.h): blocks [0, na) finalize the six
+// mean vectors, blocks [na, na + nb) build the rank-1 tables, blocks [nprod, ...) are the convolution's tiles (nprod = na + nb
+// rounded up to a multiple of 8 so that block id % 8 — the XCD — means the same for the tiles as without producers).
+struct R1Job { const float* vin; const float* wgt; float* out; int L, tiles, block_begin; };
+struct R1Inline {
+    int nprod;                // 0: plain convolution launch
+    int na, nb, a_iters;      // an A block handles a_iters x 256 threads' worth of means_finalize items
+    int cin, n_tiles_n;       // mean-vector channels; cout / 8 column tiles of a table
+    unsigned* sync;           // kSyncWords counters of the handle (never reset: targets are cumulative)
+    unsigned a_target[8], b_target[3];
+    R1Job job[6];             // job 2p: the row-indexed table of plane p, 2p + 1: the column-indexed one
+    MeanFinArgs mf;
+};
+int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect /*host mirror of the counters*/, hipStream_t st);
+bool conv_rank1_inline_enabled();         // S3D_RANK1_INLINE=1 (default off: measured slower, profiles/r03_rank1_inline.txt)
+constexpr size_t kSyncWordsBytes = 12 * 32 * 4;   // = kSyncWords * 4 (s3d_rank1.h)
 
 // part != null: pixel-chunk form that also emits the GroupNorm partials of y (kGnChunks parts per plane, 32 groups)
 int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials* part = nullptr);

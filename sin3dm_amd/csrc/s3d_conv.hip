@@ -18,6 +18,7 @@
 //   * global->LDS staging is register-prefetched one stage ahead and double-buffered: one barrier per stage.
 //   * epilogue: + bias (+ per-sample bias) + rank-1 row/column terms + residual, 128-byte runs per pixel.
 #include "s3d_common.h"
+#include "s3d_rank1.h"
 
 namespace s3d {
 
@@ -354,127 +355,20 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
 // products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
 // 8 output channels = 24 weight rows (a quarter fewer weight bytes than four pre-summed variants: the kernel is bound by
 // streaming them once) — and the variants are formed while the four waves' partials are added.
-constexpr int kR1Chunk = 128, kR1Ld = kR1Chunk + 4;
 template <bool ROLL3>
 __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
-    __shared__ __attribute__((aligned(16))) float sA[34 * kR1Ld];
-    __shared__ __attribute__((aligned(16))) float sB[2][32 * kR1Ld];
+    __shared__ __attribute__((aligned(16))) float lds[kR1LdsFloats];
     const int bid = blockIdx.x;
     int j = 0;                                             // independent kernarg loads (a while loop chains up to five of them)
 #pragma unroll
     for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
-    const int ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
-    const int b = local / J.tiles_per_img, mtile = local % J.tiles_per_img;
-    const int L = J.w, cin = args.cin, cout4 = args.cout;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, half = lane >> 5;
-    const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
-    constexpr int q4 = kR1Chunk / 4;                        // float4 slots per staged row
-    const float* vb = J.in + size_t(b) * L * cin;
-    const size_t tapStride = ROLL3 ? size_t(J.n_tiles_n) * 24 * cin : size_t(cout4) * cin;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-    // staging items: A has 34 rows (positions mtile*32-1 .. +32), B 32 rows (columns ntile*32 ..); <= 5 + 4 float4 each
-    constexpr int NA = (34 * (kR1Chunk / 4) + 255) / 256, NB = (32 * (kR1Chunk / 4) + 255) / 256;
-    f32x4 ra[NA], rb[NB];
-    auto loadA = [&](int chunk) {
-        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
-#pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            const int pos = mtile * 32 - 1 + row;
-            const bool ok = row < 34 && pos >= 0 && pos < L && q < wq;
-            ra[it] = to_global4(vb + size_t(ok ? pos : 0) * cin + c0 + (ok ? q : 0) * 4)[0];
-            if (!ok) ra[it] = zero4;
-        }
-    };
-    auto loadB = [&](int tap, int chunk) {
-        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            const int n = ROLL3 ? ntile * 24 + row : ntile * 32 + row;
-            const bool ok = (ROLL3 ? row < 24 && ntile * 8 + (row & 7) < cout4 : row < 32 && n < cout4) && q < wq;
-            rb[it] = to_global4(J.wgt + tap * tapStride + size_t(ok ? n : 0) * cin + c0 + (ok ? q : 0) * 4)[0];
-            if (!ok) rb[it] = zero4;
-        }
-    };
-    auto storeA = [&]() {
-#pragma unroll
-        for (int it = 0; it < NA; ++it) {
-            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            if (row < 34) *reinterpret_cast<f32x4*>(sA + row * kR1Ld + q * 4) = ra[it];
-        }
-    };
-    auto storeB = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < NB; ++it) {
-            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            if (row < 32) *reinterpret_cast<f32x4*>(sB[buf] + row * kR1Ld + q * 4) = rb[it];
-        }
-    };
-
-    const int nstages = nchunks * 3;                       // stage s -> chunk = s / 3, tap = s % 3
-    loadA(0); loadB(0, 0);
-    storeA(); storeB(0);
-    __syncthreads();
-    for (int s = 0; s < nstages; ++s) {
-        const int chunk = s / 3, tap = s - chunk * 3;
-        const int ns = s + 1 < nstages ? s + 1 : s;
-        const int nchunk = ns / 3, ntap = ns - nchunk * 3;
-        loadB(ntap, nchunk);
-        const bool newA = nchunk != chunk;
-        if (newA) loadA(nchunk);
-        __builtin_amdgcn_sched_barrier(0);
-        // this wave's quarter of the chunk: k8 steps [wid*cw/32, (wid+1)*cw/32)
-        const float* Ar = sA + (i + tap) * kR1Ld + half * 4;
-        const float* Br = sB[s & 1] + i * kR1Ld + half * 4;
-        const int k8n = min(cin - chunk * kR1Chunk, kR1Chunk) / 32;
-        for (int k8 = 0; k8 < k8n; ++k8) {
-            const int c = (wid * k8n + k8) * 8;
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ar + c);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(Br + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (newA) __syncthreads();                          // everyone is done reading the old A tile
-        storeB((s + 1) & 1);
-        if (newA) storeA();
-        __syncthreads();
-    }
-    // add the four waves' partials (reuse sB as [4][16][64] floats = 16 KB)
-    float* red = &sB[0][0];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
-    __syncthreads();
-    if (ROLL3) {
-        // thread = (position, channel of the block's eight): MFMA row p sits in register (p&3) + 4*(p>>3) of lane half (p>>2)&1
-        const int p = tid >> 3, c8 = tid & 7;
-        const int r = (p & 3) + 4 * (p >> 3), lh = ((p >> 2) & 1) * 32;
-        float u[3];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const int l = lh + o * 8 + c8;
-            u[o] = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-        }
-        const int row = mtile * 32 + p, co = ntile * 8 + c8;
-        if (row < L && co < cout4) {
-            float* o4 = J.out + (size_t(b) * L + row) * 4 * cout4 + co;      // [pos][variant][cout]
-            o4[0] = (u[0] + u[1]) + u[2]; o4[cout4] = u[1] + u[2]; o4[2 * cout4] = u[0] + u[1]; o4[3 * cout4] = u[1];
-        }
-        return;
-    }
-    for (int it = tid; it < 1024; it += 256) {
-        const int r = it >> 6, l = it & 63;
-        const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
-        if (row < L && col < cout4) J.out[(size_t(b) * L + row) * cout4 + col] = v;
-    }
+    R1Block blk;
+    blk.ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
+    blk.b = local / J.tiles_per_img; blk.mtile = local % J.tiles_per_img;
+    blk.vin = J.in; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.w; blk.cin = args.cin; blk.cout4 = args.cout; blk.n_tiles_n = J.n_tiles_n;
+    rank1_block<ROLL3, false>(blk, lds, []() {});
 }
 
 // S3D_CONV_IMPL=naive counterpart of the ROLL3 form: one thread per table entry, plain loops over the same weight image
@@ -630,8 +524,9 @@ double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
     return 1.0;
 }
 
-int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsigned* sync_expect) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
+    S3D_CHECK(!r1 || (kind == CONV_3x3 && !conv_use_naive() && takes_wino24(a) == 1), S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
     if (conv_use_naive()) return launch_conv_naive(kind, a, st);
     // Tile choice (measured, tools/conv_ubench.hip and in the step; for 1x1 again after the Winograd rework): the 64-pixel x 64-cout tile wins at every
@@ -641,6 +536,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
         case CONV_3x3:
             if (const int k24 = takes_wino24(a)) {
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = k24 == 2 ? a.job[j].wgt_wino24 : a.job[j].wgt_wino24s;
+                if (r1) return launch_conv_wino24s_r1(a, *r1, sync_expect, st);
                 return k24 == 2 ? launch_conv_wino24(a, st) : launch_conv_wino24s(a, st);
             }
             if (conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) {   // (its epilogue moves channel quads; GroupNorm'd layers always qualify)

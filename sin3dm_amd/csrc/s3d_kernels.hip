@@ -7,6 +7,7 @@
 // All reductions are two-stage with a fixed summation order (no float atomics): results are
 // bit-repeatable run to run.
 #include "s3d_common.h"
+#include "s3d_rank1.h"
 
 namespace s3d {
 
@@ -768,49 +769,13 @@ int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const A
 
 // th.mean over one axis of the activated planes (src/diffusion/unet_triplane.py:38-46): add the tile partials
 // in index order and divide by the axis length.
-struct MeanFinArgs {
-    const float* rowpart[3]; const float* colpart[3];
-    float* rowmean[3]; float* colmean[3];
-    int h[3], w[3];
-    int C, cq, B;
-    long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
-};
 __global__ __launch_bounds__(256) void k_means_finalize(MeanFinArgs a) {
-    // item = (vector, position, channel quad); four adjacent lanes share an item: lane k takes partials k, k+4, ... and the
-    // four sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch)
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    const int part0 = threadIdx.x & 3;
-    const bool live = i < a.begin[6] * a.B;
-    const long long ii = live ? i : 0;
-    const int b = int(ii / a.begin[6]);
-    long long r = ii % a.begin[6];
-    int v = 0;
-    while (r >= a.begin[v + 1]) ++v;
-    r -= a.begin[v];
-    const int p = v >> 1, is_col = v & 1;
-    const int pos = int(r / a.cq), q = int(r % a.cq);
-    const int h = a.h[p], w = a.w[p];
-    float4 s = make_float4(0, 0, 0, 0);
-    const int nt = is_col ? (h + kActRows - 1) / kActRows : (w + kActCols - 1) / kActCols;
-    const int len = is_col ? w : h;
-    const float* src = is_col ? a.colpart[p] : a.rowpart[p];
-    for (int t = part0; t < nt; t += 4) {
-        const float4 u = reinterpret_cast<const float4*>(src + ((size_t(b) * nt + t) * len + pos) * a.C)[q];
-        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
-    }
-#pragma unroll
-    for (int off = 1; off <= 2; off <<= 1) {
-        s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64); s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
-    }
-    if (!live || part0 != 0) return;
-    const float inv = 1.0f / float(is_col ? h : w);
-    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-    float* dst = is_col ? a.colmean[p] : a.rowmean[p];
-    reinterpret_cast<float4*>(dst + (size_t(b) * len + pos) * a.C)[q] = s;
+    means_finalize_thread<false>(a, (long long)blockIdx.x * blockDim.x + threadIdx.x);
 }
-int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st) {
+MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv) {
     MeanFinArgs a;
     a.C = C; a.cq = C / 4; a.B = B; a.begin[0] = 0;
+    a.mean_base = mv.base; a.mean_bytes = (unsigned)mv.bytes;
     for (int p = 0; p < 3; ++p) {
         a.rowpart[p] = mp.rowpart[p]; a.colpart[p] = mp.colpart[p];
         a.rowmean[p] = mv.rowmean[p]; a.colmean[p] = mv.colmean[p];
@@ -818,6 +783,10 @@ int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, Me
         a.begin[2 * p + 1] = a.begin[2 * p] + (long long)g.h[p] * a.cq;
         a.begin[2 * p + 2] = a.begin[2 * p + 1] + (long long)g.w[p] * a.cq;
     }
+    return a;
+}
+int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st) {
+    MeanFinArgs a = means_finalize_args(g, C, B, mp, mv);
     long long n = a.begin[6] * B;
     if (!n) return 0;
     hipLaunchKernelGGL(k_means_finalize, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, a);

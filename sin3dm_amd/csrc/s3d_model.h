@@ -110,6 +110,19 @@ struct s3d_unet {
     Tape tape;
     const float* tdev(size_t off) const { return static_cast<const float*>(tbuf.p) + off; }
 
+    // counters of the in-launch producer hand-off (s3d_rank1.h): zeroed once, targets are cumulative (host mirror: sync_expect)
+    DevBuf sync_ws;
+    unsigned sync_expect[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int sync_counters(hipStream_t st, unsigned** out) {
+        if (!sync_ws.p) {
+            S3D_TRY(sync_ws.reserve(kSyncWordsBytes));
+            S3D_HIP(hipMemsetAsync(sync_ws.p, 0, kSyncWordsBytes, st));
+            memset(sync_expect, 0, sizeof sync_expect);
+        }
+        *out = static_cast<unsigned*>(sync_ws.p);
+        return 0;
+    }
+
     // optional live timing of the convolution launches (s3d_unet_profile)
     struct ProfRec { int cls; hipEvent_t e0, e1; double flops, mfma_flops; };
     int prof_every = 0;
@@ -125,8 +138,8 @@ struct s3d_unet {
         else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         return e;
     }
-    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
-        if (!prof_now) return launch_conv(kind, ca, st);
+    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st, R1Inline* r1 = nullptr) {
+        if (!prof_now) return launch_conv(kind, ca, st, r1, sync_expect);
         // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
         int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : (kind == CONV_1x3_ROLL ? 9 : 25)));
         double pix = 0;
@@ -134,7 +147,7 @@ struct s3d_unet {
         ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B, 0.0};
         r.mfma_flops = r.flops * conv_exec_fraction(kind, ca);
         if (r.e0) (void)hipEventRecord(r.e0, st);
-        int rc = launch_conv(kind, ca, st);
+        int rc = launch_conv(kind, ca, st, r1, sync_expect);
         if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
         if (r.e1) (void)hipEventRecord(r.e1, st);
         prof_recs.push_back(r);
@@ -229,17 +242,42 @@ struct Fwd {
     int roll_buffers(const Tri& y, const ConvW& cw, bool roll, MeanPartials& mp, MeanVecs& mv, const float* rrow[3], const float* rcol[3]) {
         for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
         if (!roll) return 0;
+        // the six mean vectors are ONE allocation: the in-launch producers store them through one buffer descriptor
+        size_t mtot = 0;
+        for (int p = 0; p < 3; ++p) mtot += size_t(B) * (y.g.h[p] + y.g.w[p]) * y.C;
+        S3D_CHECK(mtot * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "rollout mean vectors exceed 2 GiB");
+        float* means = ar().alloc<float>(mtot);
+        mv.base = means; mv.bytes = mtot * 4;
         for (int p = 0; p < 3; ++p) {
             const int h = y.g.h[p], w = y.g.w[p];
             const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
             mp.rowpart[p] = ar().alloc<float>(size_t(B) * ntc * h * y.C);
             mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * y.C);
-            mv.rowmean[p] = ar().alloc<float>(size_t(B) * h * y.C);
-            mv.colmean[p] = ar().alloc<float>(size_t(B) * w * y.C);
+            mv.rowmean[p] = means; means += size_t(B) * h * y.C;
+            mv.colmean[p] = means; means += size_t(B) * w * y.C;
             rrow[p] = ar().alloc<float>(size_t(B) * h * 4 * cw.cout);
             rcol[p] = ar().alloc<float>(size_t(B) * w * 4 * cw.cout);
         }
         return 0;
+    }
+    // The rollout's means + tables of an activated tensor, not yet enqueued: the 3x3 convolution that consumes the tables
+    // takes them into its own launch as producer blocks (s3d_rank1.h); anything else flushes them as two stand-alone launches.
+    struct PendingR1 {
+        bool active = false;
+        Tri y; const ConvW* cw = nullptr; MeanPartials mp; MeanVecs mv;
+        const float* rrow[3]; const float* rcol[3];
+    } pend;
+    int defer_rank1(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
+        S3D_TRY(flush_rank1());
+        if (!conv_rank1_inline_enabled() || conv_use_naive()) return rank1_tables(y, cw, mp, mv, rrow, rcol);
+        pend.active = true; pend.y = y; pend.cw = &cw; pend.mp = mp; pend.mv = mv;
+        for (int p = 0; p < 3; ++p) { pend.rrow[p] = rrow[p]; pend.rcol[p] = rcol[p]; }
+        return 0;
+    }
+    int flush_rank1() {
+        if (!pend.active) return 0;
+        pend.active = false;
+        return rank1_tables(pend.y, *pend.cw, pend.mp, pend.mv, pend.rrow, pend.rcol);
     }
     // th.mean over the axes + the six 1-D convolutions of the mean vectors (one launch each)
     int rank1_tables(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
@@ -281,7 +319,7 @@ struct Fwd {
         if (measuring) return 0;
         S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st, add_parts ? &x.part : nullptr));
         if (!roll) return 0;
-        return rank1_tables(y, *cw, mp, mv, rrow, rcol);
+        return defer_rank1(y, *cw, mp, mv, rrow, rcol);
     }
 
     // want_stats (3x3 MFMA paths only): 1 = reduce the GroupNorm statistics of the output (partials in the epilogue +
@@ -304,6 +342,27 @@ struct Fwd {
             else out.part = part;
         }
         if (ar().measuring) return 0;
+        // this convolution's own rollout tables still pending: its launch produces them itself when it is the mixed Winograd
+        // kernel on this stream; every other case gets the two stand-alone launches first
+        R1Inline r1; r1.nprod = 0;
+        if (pend.active) {
+            const bool mine = rrow && rcol && rrow[0] == pend.rrow[0] && w24 == 1 && !on && cw.cout % 8 == 0 && pend.cw == &cw;
+            if (!mine) S3D_TRY(flush_rank1());
+            else {
+                pend.active = false;
+                memset(&r1, 0, sizeof r1);
+                r1.nprod = 1;                                   // (the launcher fills in the layout)
+                r1.cin = pend.y.C;
+                S3D_TRY(m->sync_counters(st, &r1.sync));
+                r1.mf = means_finalize_args(pend.y.g, pend.y.C, B, pend.mp, pend.mv);
+                const float* rowvec[3] = {pend.mv.rowmean[1], pend.mv.rowmean[0], pend.mv.colmean[0]};   // as in rank1_tables
+                const float* colvec[3] = {pend.mv.rowmean[2], pend.mv.colmean[2], pend.mv.colmean[1]};
+                for (int p = 0; p < 3; ++p) {
+                    r1.job[2 * p] = R1Job{rowvec[p], m->dev(cw.rrow[p]), const_cast<float*>(rrow[p]), y.g.h[p], 0, 0};
+                    r1.job[2 * p + 1] = R1Job{colvec[p], m->dev(cw.rcol[p]), const_cast<float*>(rcol[p]), y.g.w[p], 0, 0};
+                }
+            }
+        }
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
         if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
@@ -318,7 +377,7 @@ struct Fwd {
             J.res = res ? res->p[p] : nullptr; J.res_up = res && res_up ? 1 : 0; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
             J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
         }
-        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
+        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st, r1.nprod ? &r1 : nullptr));
         if (want_stats == 1) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
         return 0;
     }
@@ -359,7 +418,7 @@ struct Fwd {
             S3D_TRY(roll_buffers(y1, rb.c1, roll, mp, mv, rr, rc));
             if (!measuring) {
                 S3D_TRY(launch_gn_act_cat(u, sk, B, stats, aa, y1, roll ? &mp : nullptr, st));
-                if (roll) S3D_TRY(rank1_tables(y1, rb.c1, mp, mv, rr, rc));
+                if (roll) S3D_TRY(defer_rank1(y1, rb.c1, mp, mv, rr, rc));
             }
         }
         S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 2));   // partials only (norm_act adds them)

@@ -1,0 +1,249 @@
+// s3d_rank1.h — device bodies of the rollout's small dependent stages, shared by their stand-alone kernels
+// (k_means_finalize in s3d_kernels.hip, k_rank1 in s3d_conv.hip) and by the 3x3 convolution launch that runs them as
+// producer blocks ahead of its own tiles (k_conv_wino24s, s3d_wino24.hip):
+//
+//   gn_act --(tile partial sums)--> means  --(six mean vectors)--> rank-1 tables --> convolution EPILOGUE
+//
+// The convolution's k-loop needs none of this, so with S3D_RANK1_INLINE=1 the three stages are ONE launch (built in round 3
+// on VERDICT r2's item 1, bit-identical, measured SLOWER and therefore off by default — profiles/r03_rank1_inline.txt):
+// blocks [0, na) finalize the means ("A"), blocks [na, na+nb) build the tables ("B"), the rest are convolution tiles ("C").
+// Hand-off inside the launch (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
+//   * payloads are written with 16-byte write-through (sc1) stores and read with sc1 loads — no agent-scope fence anywhere
+//     (a release would write back the XCD's dirty lines, i.e. the activation the C blocks are producing);
+//   * every writing wave drains its stores (s_waitcnt vmcnt(0)), the block meets at a barrier, ONE lane bumps a counter
+//     with a relaxed agent-scope atomic; A counters are sharded by block id & 7, B counters by plane;
+//   * consumers poll with relaxed agent-scope loads (one lane per counter), bounded: after ~20 ms a block raises the error
+//     word and goes on, so a scheduling surprise fails a test instead of hanging the GPU;
+//   * counters are never reset: the host hands every launch the cumulative value each counter must reach (launches on a
+//     handle are stream-ordered), compared wrap-safe.
+// Dead-lock freedom rests on block ids being dispatched in order (A before B before C; A waits for nothing).
+// Same arithmetic in the same order as the stand-alone kernels: results are bit-identical with the switch on or off.
+#pragma once
+#include "s3d_common.h"
+
+namespace s3d {
+
+typedef float r1_f32x16 __attribute__((ext_vector_type(16)));
+typedef float r1_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned r1_u32x4 __attribute__((ext_vector_type(4)));
+typedef const r1_f32x4 __attribute__((address_space(1)))* r1_gf4ptr;
+constexpr int kAuxSc1 = 16;                               // buffer-instruction aux bit 4 = sc1 (write-through / L1-bypass)
+
+constexpr int kR1Chunk = 128, kR1Ld = kR1Chunk + 4;
+constexpr int kR1LdsFloats = (34 + 2 * 32) * kR1Ld;       // A tile (34 rows) + two B tiles: 51 744 bytes
+constexpr int kSyncStride = 32;                           // counters 128 bytes apart
+constexpr int kSyncA = 0, kSyncB = 8, kSyncErr = 11, kSyncWords = 12 * kSyncStride;
+constexpr int kSpinLimit = 1 << 14;
+static_assert(size_t(kSyncWords) * 4 == kSyncWordsBytes, "s3d_common.h sizes the handle's counter buffer");
+
+__device__ __forceinline__ unsigned sync_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_arrive(unsigned* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the block has issued its payload stores: drain them, meet, one lane publishes
+__device__ __forceinline__ void sync_publish(unsigned* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) sync_arrive(counter);
+}
+// spin until *p has reached target (wrap-safe); returns false after kSpinLimit polls
+__device__ __forceinline__ bool sync_wait(const unsigned* p, unsigned target, unsigned first) {
+    unsigned v = first;
+    for (int spin = 0; int(v - target) < 0; ++spin) {
+        if (spin >= kSpinLimit) return false;
+        __builtin_amdgcn_s_sleep(8);
+        v = sync_load(p);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ stage A: th.mean over one axis of the activated planes
+// (src/diffusion/unet_triplane.py:38-46): add the tile partials in index order and divide by the axis length.
+// item = (vector, position, channel quad); four adjacent lanes share an item: lane k takes partials k, k+4, ... and the four
+// sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch).  gthread = global thread index.
+template <bool SC1>
+__device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long long gthread) {
+    const long long i = gthread >> 2;
+    const int part0 = int(gthread & 3);
+    const bool live = i < a.begin[6] * a.B;
+    const long long ii = live ? i : 0;
+    const int b = int(ii / a.begin[6]);
+    long long r = ii % a.begin[6];
+    int v = 0;
+    while (r >= a.begin[v + 1]) ++v;
+    r -= a.begin[v];
+    const int p = v >> 1, is_col = v & 1;
+    const int pos = int(r / a.cq), q = int(r % a.cq);
+    const int h = a.h[p], w = a.w[p];
+    float4 s = make_float4(0, 0, 0, 0);
+    const int nt = is_col ? (h + kActRows - 1) / kActRows : (w + kActCols - 1) / kActCols;
+    const int len = is_col ? w : h;
+    const float* src = is_col ? a.colpart[p] : a.rowpart[p];
+    for (int t = part0; t < nt; t += 4) {
+        const float4 u = reinterpret_cast<const float4*>(src + ((size_t(b) * nt + t) * len + pos) * a.C)[q];
+        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+    }
+#pragma unroll
+    for (int off = 1; off <= 2; off <<= 1) {
+        s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64); s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
+    }
+    if (!live || part0 != 0) return;
+    const float inv = 1.0f / float(is_col ? h : w);
+    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+    float* dst = (is_col ? a.colmean[p] : a.rowmean[p]) + (size_t(b) * len + pos) * a.C + q * 4;
+    if (SC1) {       // one descriptor for the launch: the six vectors are one allocation (Fwd::roll_buffers)
+        const r1_f32x4 v4 = {s.x, s.y, s.z, s.w};
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.mean_base, 0, int(a.mean_bytes), 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v4), rs, unsigned(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(a.mean_base)), 0, kAuxSc1);
+    } else {
+        *reinterpret_cast<float4*>(dst) = s;
+    }
+}
+
+// ------------------------------------------------------------------ stage B: rank-1 rollout tables (skinny GEMMs)
+// out[b][pos][n] = sum_{tap, c} W[tap][n][c] * v[b][pos + tap - 1][c]   (zero outside [0, L)), n = variant*cout + co.
+// M = L is only ~128 rows, so the work is split along K instead.  One block = 32 positions x 32 columns.  K = 3 taps x C
+// is walked in stages of (tap, <=128-channel chunk): whole 512-byte rows of the vector (with its +-1 halo, loaded once per
+// chunk) and of the weights are staged in LDS with coalesced loads, register-prefetched one stage ahead; inside a stage the
+// four waves each contract a quarter of the chunk, and their partial accumulators are added through LDS in wave order.
+// ROLL3 (CONV_1x3_ROLL, the forward rollout tables): the four edge variants of a table entry are sums over subsets of the
+// three taps o of the SUMMED-OUT axis (interior o0+o1+o2, first o1+o2, last o0+o1, single o1), so only the three per-tap
+// products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
+// 8 output channels = 24 weight rows — and the variants are formed while the four waves' partials are added.
+// SC1: the vector `vin` was written earlier in THIS launch (stage A): it is read with sc1 loads after `wait()` returns, and
+// the table leaves with 16-byte sc1 stores (requires cout % 4 == 0).  lds: kR1LdsFloats floats.
+struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; };
+
+template <bool ROLL3, bool SC1, class Wait>
+__device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait wait) {
+    float* sA = lds;
+    float* sB0 = lds + 34 * kR1Ld;
+    const int L = J.L, cin = J.cin, cout4 = J.cout4, mtile = J.mtile, ntile = J.ntile, b = J.b;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, half = lane >> 5;
+    const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
+    constexpr int q4 = kR1Chunk / 4;                        // float4 slots per staged row
+    const float* vb = J.vin + size_t(b) * L * cin;
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, L * cin * 4, 0x00020000);
+    const size_t tapStride = ROLL3 ? size_t(J.n_tiles_n) * 24 * cin : size_t(cout4) * cin;
+    const r1_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    r1_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // staging items: A has 34 rows (positions mtile*32-1 .. +32), B 32 rows (columns ntile*32 ..); <= 5 + 4 float4 each
+    constexpr int NA = (34 * (kR1Chunk / 4) + 255) / 256, NB = (32 * (kR1Chunk / 4) + 255) / 256;
+    r1_f32x4 ra[NA], rb[NB];
+    auto loadA = [&](int chunk) {
+        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            const int pos = mtile * 32 - 1 + row;
+            const bool ok = row < 34 && pos >= 0 && pos < L && q < wq;
+            if (SC1) {                                      // out-of-range offset: the hardware returns zeros
+                ra[it] = __builtin_bit_cast(r1_f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, ok ? unsigned((pos * cin + c0 + q * 4) * 4) : 0x80000000u, 0, kAuxSc1));
+            } else {
+                ra[it] = ((r1_gf4ptr)(uintptr_t)(vb + size_t(ok ? pos : 0) * cin + c0 + (ok ? q : 0) * 4))[0];
+                if (!ok) ra[it] = zero4;
+            }
+        }
+    };
+    auto loadB = [&](int tap, int chunk) {
+        const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            const int n = ROLL3 ? ntile * 24 + row : ntile * 32 + row;
+            const bool ok = (ROLL3 ? row < 24 && ntile * 8 + (row & 7) < cout4 : row < 32 && n < cout4) && q < wq;
+            rb[it] = ((r1_gf4ptr)(uintptr_t)(J.wgt + tap * tapStride + size_t(ok ? n : 0) * cin + c0 + (ok ? q : 0) * 4))[0];
+            if (!ok) rb[it] = zero4;
+        }
+    };
+    auto storeA = [&]() {
+#pragma unroll
+        for (int it = 0; it < NA; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            if (row < 34) *reinterpret_cast<r1_f32x4*>(sA + row * kR1Ld + q * 4) = ra[it];
+        }
+    };
+    auto storeB = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NB; ++it) {
+            const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
+            if (row < 32) *reinterpret_cast<r1_f32x4*>(sB0 + buf * (32 * kR1Ld) + row * kR1Ld + q * 4) = rb[it];
+        }
+    };
+
+    const int nstages = nchunks * 3;                       // stage s -> chunk = s / 3, tap = s % 3
+    loadB(0, 0);                                           // the weights do not depend on stage A: requested before the wait
+    wait();
+    loadA(0);
+    storeA(); storeB(0);
+    __syncthreads();
+    for (int s = 0; s < nstages; ++s) {
+        const int chunk = s / 3, tap = s - chunk * 3;
+        const int ns = s + 1 < nstages ? s + 1 : s;
+        const int nchunk = ns / 3, ntap = ns - nchunk * 3;
+        loadB(ntap, nchunk);
+        const bool newA = nchunk != chunk;
+        if (newA) loadA(nchunk);
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's quarter of the chunk: k8 steps [wid*cw/32, (wid+1)*cw/32)
+        const float* Ar = sA + (i + tap) * kR1Ld + half * 4;
+        const float* Br = sB0 + (s & 1) * (32 * kR1Ld) + i * kR1Ld + half * 4;
+        const int k8n = min(cin - chunk * kR1Chunk, kR1Chunk) / 32;
+        for (int k8 = 0; k8 < k8n; ++k8) {
+            const int c = (wid * k8n + k8) * 8;
+            const r1_f32x4 a4 = *reinterpret_cast<const r1_f32x4*>(Ar + c);
+            const r1_f32x4 b4 = *reinterpret_cast<const r1_f32x4*>(Br + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (newA) __syncthreads();                          // everyone is done reading the old A tile
+        storeB((s + 1) & 1);
+        if (newA) storeA();
+        __syncthreads();
+    }
+    // add the four waves' partials (reuse the B tiles as [4][16][64] floats = 16 KB)
+    float* red = sB0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (ROLL3) {
+        // MFMA row p sits in register (p&3) + 4*(p>>3) of lane half (p>>2)&1
+        auto usum = [&](int p, int c8, int o) {
+            const int r = (p & 3) + 4 * (p >> 3), l = ((p >> 2) & 1) * 32 + o * 8 + c8;
+            return red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+        };
+        if (SC1) {
+            // thread = (position, variant, channel quad of the block's eight): one 16-byte write-through store each
+            const int p = tid >> 3, var = (tid >> 1) & 3, c4 = (tid & 1) * 4;
+            const int row = mtile * 32 + p, co = ntile * 8 + c4;
+            r1_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u0 = usum(p, c4 + e, 0), u1 = usum(p, c4 + e, 1), u2 = usum(p, c4 + e, 2);
+                v[e] = var == 0 ? (u0 + u1) + u2 : (var == 1 ? u1 + u2 : (var == 2 ? u0 + u1 : u1));
+            }
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J.out + size_t(b) * L * 4 * cout4, 0, L * 4 * cout4 * 4, 0x00020000);
+            if (row < L && co < cout4)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v), rs, unsigned(((row * 4 + var) * cout4 + co) * 4), 0, kAuxSc1);
+            return;
+        }
+        const int p = tid >> 3, c8 = tid & 7;
+        const float u0 = usum(p, c8, 0), u1 = usum(p, c8, 1), u2 = usum(p, c8, 2);
+        const int row = mtile * 32 + p, co = ntile * 8 + c8;
+        if (row < L && co < cout4) {
+            float* o4 = J.out + (size_t(b) * L + row) * 4 * cout4 + co;      // [pos][variant][cout]
+            o4[0] = (u0 + u1) + u2; o4[cout4] = u1 + u2; o4[2 * cout4] = u0 + u1; o4[3 * cout4] = u1;
+        }
+        return;
+    }
+    for (int it = tid; it < 1024; it += 256) {
+        const int r = it >> 6, l = it & 63;
+        const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
+        if (row < L && col < cout4) J.out[(size_t(b) * L + row) * cout4 + col] = v;
+    }
+}
+
+}  // namespace s3d

@@ -329,6 +329,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         h = o;
         (void)level;
     }
+    S3D_TRY(f.flush_rank1());                       // (every rollout convolution takes its tables into its own launch: nothing is left)
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
     GnStats stats;
     S3D_TRY(f.stats_of(h, stats));
@@ -483,6 +484,17 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
     m->prof_recs.clear();
     out->forwards += m->prof_forwards;
     m->prof_forwards = 0;
+    return 0;
+}
+
+int s3d_unet_sync_errors(s3d_unet* m, int* err) {
+    S3D_CHECK(m && err, S3D_ERR_INVALID, "unet_sync_errors: null argument");
+    *err = 0;
+    if (!m->sync_ws.p) return 0;
+    S3D_HIP(hipDeviceSynchronize());
+    unsigned v = 0;
+    S3D_HIP(hipMemcpy(&v, static_cast<const unsigned*>(m->sync_ws.p) + 11 * 32, sizeof v, hipMemcpyDeviceToHost));
+    *err = int(v);
     return 0;
 }
 

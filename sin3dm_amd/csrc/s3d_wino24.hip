@@ -25,6 +25,7 @@
 //     [8 tile rows][16 columns][32 channels]; pixel-quad threads combine three images (row pass), add bias / rank-1
 //     rollout terms / residual, store 16 bytes and reduce the GroupNorm partial sums.
 #include "s3d_common.h"
+#include "s3d_rank1.h"
 
 namespace s3d {
 
@@ -346,14 +347,49 @@ constexpr int C_ITEMS_PT = (C_ITEMS + 255) / 256;            // 6 (the sixth rou
 constexpr int C_ABUF = C_HH * C_HW * C_LD;                   // floats per halo buffer (6480)
 constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image [4 tile rows][16 columns][32 channels]
 
-__global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
+// The rollout's producer roles of a launch with r1.nprod > 0 (s3d_rank1.h): block ids [0, na) finalize the mean vectors,
+// [na, na + nb) build the rank-1 tables from them, [na + nb, nprod) are padding.
+__device__ __forceinline__ void wino24s_producer(const R1Inline& r1, int bid, float* smem) {
+    const int tid = threadIdx.x;
+    if (bid < r1.na) {
+        for (int it = 0; it < r1.a_iters; ++it) means_finalize_thread<true>(r1.mf, ((long long)bid * r1.a_iters + it) * 256 + tid);
+        sync_publish(r1.sync + (kSyncA + (bid & 7)) * kSyncStride);
+        return;
+    }
+    const int lb = bid - r1.na;
+    if (lb >= r1.nb) return;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) j += lb >= r1.job[k].block_begin ? 1 : 0;
+    const R1Job& J = r1.job[j];
+    int local = lb - J.block_begin;
+    R1Block blk;
+    blk.ntile = local % r1.n_tiles_n; local /= r1.n_tiles_n;
+    blk.b = local / J.tiles; blk.mtile = local % J.tiles;
+    blk.vin = J.vin; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.L; blk.cin = r1.cin; blk.cout4 = r1.n_tiles_n * 8; blk.n_tiles_n = r1.n_tiles_n;
+    rank1_block<true, true>(blk, smem, [&]() {
+        if (tid < 8) {                                       // one lane per A counter
+            const unsigned* c = r1.sync + (kSyncA + tid) * kSyncStride;
+            if (!sync_wait(c, r1.a_target[tid], sync_load(c))) __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    });
+    sync_publish(r1.sync + (kSyncB + (j >> 1)) * kSyncStride);
+}
+
+__global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline r1) {
     __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];             // 51.8 KB: two halo buffers; four share images after the loop
     static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
+    static_assert(kR1LdsFloats <= 2 * C_ABUF, "the rank-1 producer role fits the convolution's LDS");
     W24_STAMP(0)
-    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     int bid = blockIdx.x;
+    if (r1.nprod) {
+        if (bid < r1.nprod) { wino24s_producer(r1, bid, smem); return; }
+        bid -= r1.nprod;
+    }
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     if (args.xcd_swizzle & 1) {
-        const int chunk = int(gridDim.x) >> 3;
+        const int chunk = (int(gridDim.x) - r1.nprod) >> 3;
         if (bid < (chunk << 3)) bid = (bid & 7) * chunk + (bid >> 3);
     }
     int j = 0;
@@ -500,11 +536,17 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
 
     int cur = 0;                                  // byte offset of the buffer that holds the current chunk
     const int tog = C_ABUF * 4;
+    // in-launch producers (s3d_rank1.h): this plane's tables are complete when its counter has reached the target; the first
+    // poll is issued a chunk before the epilogue needs the answer (normally the only one: the producers finish well before)
+    const unsigned* poll_ptr = r1.nprod ? r1.sync + (kSyncB + j) * kSyncStride : nullptr;
+    const unsigned poll_target = r1.nprod ? r1.b_target[j] : 0u;
+    unsigned poll_seen = poll_target;
     W24_STAMP(2)
     __builtin_amdgcn_s_setprio(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const int cn1 = chunk + 1 < nchunks ? chunk + 1 : nchunks - 1;
         const int cn2 = chunk + 2 < nchunks ? chunk + 2 : nchunks - 1;
+        if (poll_ptr && chunk == nchunks - 1) poll_seen = sync_load(poll_ptr);
         C_STEP(0)
         C_STEP(1)
         cur ^= tog;
@@ -538,25 +580,30 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args) {
     f32x4 tcol[4], trow[4], tres[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
+    if (poll_ptr && !sync_wait(poll_ptr, poll_target, poll_seen))
+        __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the tables may have been written earlier in this launch by blocks on other XCDs (write-through stores): sc1 loads
     if (p_rcol) {
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_rcol) + size_t(b) * w * 4 * cout, 0, w * 4 * cout * 4, 0x00020000);
         if (ty0 > 0 && ty0 + C_TH < h) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + 0) * cout + coc);
+            const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned(((xc * 4 + 0) * cout + coc) * 4), 0, kAuxSc1));
 #pragma unroll
             for (int k = 0; k < 4; ++k) tcol[k] = v0;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int y = ty0 + rsel * 4 + k;
-                tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc);
+                tcol[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned(((xc * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc) * 4), 0, kAuxSc1));
             }
         }
     }
     if (p_rrow) {
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_rrow) + size_t(b) * h * 4 * cout, 0, h * 4 * cout * 4, 0x00020000);
         const int vx = x_edge_variant(xc, w);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int y = ty0 + rsel * 4 + k;
-            trow[k] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
+            trow[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned((((y < h ? y : 0) * 4 + vx) * cout + coc) * 4), 0, kAuxSc1));
         }
     }
     if (p_res) {
@@ -697,8 +744,40 @@ size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout,
     return off;
 }
 
+bool conv_rank1_inline_enabled() {
+    // default OFF: measured slower than the two stand-alone launches (profiles/r03_rank1_inline.txt) — a slot that hosts a
+    // producer starts its convolution tiles late by the producers' whole critical path, and with exactly 1-2 rounds of 27-us
+    // tiles per launch that delay is not absorbed
+    static const bool on = getenv("S3D_RANK1_INLINE") && atoi(getenv("S3D_RANK1_INLINE")) != 0;
+    return on;
+}
+
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st) {
+    R1Inline none;
+    memset(&none, 0, sizeof none);
+    return launch_conv_wino24s_r1(a, none, nullptr, st);
+}
+
+// r1.nprod != 0 on entry: r1.mf, r1.cin, r1.sync and job[].{vin, wgt, out, L} are set by the caller (Fwd::conv); the block
+// layout and the cumulative counter targets are filled in here (expect = the host mirror of the counters).
+int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24s conv: bad arguments");
+    if (r1.nprod) {
+        S3D_CHECK(a.njobs == 3 && expect && r1.sync && a.cout % 8 == 0, S3D_ERR_INVALID, "wino24s conv: in-launch rank-1 producers need the three planes of one TriplaneConv");
+        r1.n_tiles_n = a.cout / 8;
+        static const int aiters = getenv("S3D_R1_AITERS") ? std::max(1, atoi(getenv("S3D_R1_AITERS"))) : 1;
+        r1.a_iters = aiters;
+        const long long athreads = 4 * r1.mf.begin[6] * a.B;
+        r1.na = int((athreads + 256LL * r1.a_iters - 1) / (256LL * r1.a_iters));
+        int nb = 0;
+        for (int j = 0; j < 6; ++j) {
+            r1.job[j].tiles = (r1.job[j].L + 31) / 32;
+            r1.job[j].block_begin = nb;
+            nb += r1.job[j].tiles * r1.n_tiles_n * a.B;
+        }
+        r1.nb = nb;
+        r1.nprod = (r1.na + nb + 7) & ~7;
+    }
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
@@ -710,10 +789,21 @@ int launch_conv_wino24s(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
+    if (r1.nprod) {                                   // what each counter will have reached when this launch's producers are done
+        for (int k = 0; k < 8; ++k) {
+            expect[kSyncA + k] += unsigned(r1.na > k ? (r1.na - k + 7) / 8 : 0);
+            r1.a_target[k] = expect[kSyncA + k];
+        }
+        for (int p = 0; p < 3; ++p) {
+            expect[kSyncB + p] += unsigned((r1.job[2 * p].tiles + r1.job[2 * p + 1].tiles) * r1.n_tiles_n * a.B);
+            r1.b_target[p] = expect[kSyncB + p];
+        }
+    }
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
-    conv_note_kernel("k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks");
-    hipLaunchKernelGGL(k_conv_wino24s, dim3(blocks), dim3(256), 0, st, a);
+    conv_note_kernel(r1.nprod ? "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks, rollout means + rank-1 tables as in-launch producer blocks"
+                              : "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks");
+    hipLaunchKernelGGL(k_conv_wino24s, dim3(blocks + r1.nprod), dim3(256), 0, st, a, r1);
     S3D_HIP(hipGetLastError());
     return 0;
 }

@@ -256,6 +256,12 @@ class _TriplaneUNetBase(nn.Module):
         """Name of the kernel the most recent timed launch of class cls (0: 3x3, 1: 1x1, 2: rank-1) dispatched."""
         return (_lib.load().s3d_unet_profile_kernel(self._handle, int(cls)) or b"").decode()
 
+    def sync_errors(self):
+        """0 unless an in-launch hand-off of the rollout tables ever timed out (then results are invalid); synchronises."""
+        err = C.c_int(0)
+        _lib.check(_lib.load().s3d_unet_sync_errors(self._ensure_handle() and self._handle, C.byref(err)))
+        return int(err.value)
+
     def convert_to_fp16(self):
         raise NotImplementedError("fp16 is not runnable in the reference (see __init__)")
 

@@ -99,9 +99,10 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["24", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
+@pytest.mark.parametrize("variant", ["r1on", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
 def test_unet_forward_golden_other_conv_kernels(variant):
-    """Every 3x3 kernel on the golden planes (S3D_WINO=24: mixed Winograd F(2x4,3x3), 8x16-pixel blocks — the default;
+    """Every 3x3 kernel on the golden planes (r1on: the default mixed Winograd F(2x4,3x3) kernel with S3D_RANK1_INLINE=1, i.e.
+    the rollout's means + rank-1 tables as producer blocks of the convolution launch instead of two stand-alone launches;
     24big: its 16x16-pixel form forced onto every layer with S3D_WINO24_BIG_MIN_BLOCKS=0; 4 / 2: F(2x2) with one / two
     frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors, leaf convolutions and ragged
     shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual concat of
@@ -125,12 +126,55 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    e = relerr(y, g[f'{tag}.y'])\n"
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
-    env = {"24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
+    env = {"r1on": dict(S3D_RANK1_INLINE="1"), "24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
            "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0")}.get(variant, dict(S3D_WINO=variant))
     env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+R1_CASES = [(32, 2, (10, 14, 6)), (64, 3, (40, 24, 56)), (128, 2, (64, 48, 32)), (128, 1, (128, 128, 128))]
+
+
+def _r1_forward(mc, B, hwd, seed):
+    H, W, D = hwd
+    model = make_model(mc)
+    x = cu(T.synthetic_noise((B, 12, H + D, W + D), seed))
+    t = torch.arange(B, device=dev(), dtype=torch.float32) * 37.0 + 5.0
+    model.profile(1)
+    with torch.no_grad():
+        ys = [model(x, t, H=H, W=W, D=D) for _ in range(3)]        # repeated: the cumulative counter targets advance
+    model.profile_read()
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    assert model.sync_errors() == 0
+    return ys[0].cpu().numpy(), model.profile_kernel(0)
+
+
+def test_rank1_inline_is_bit_identical_and_is_what_runs(tmp_path):
+    """S3D_RANK1_INLINE=1: the rollout's means + rank-1 tables (unet_triplane.py:37-58) run as producer blocks INSIDE the 3x3
+    convolution launch (s3d_rank1.h; separate process — the switch is read once).  Same arithmetic in the same order: outputs
+    are bit-identical to the default stand-alone launches, repeated calls agree, no hand-off ever timed out, and the library
+    reports which form ran in either process."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import test_hip_parity as tp\n"
+        "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
+        "    y, name = tp._r1_forward(mc, B, hwd, 70 + i)\n"
+        "    assert 'in-launch producer' in name, name\n"
+        f"    np.save(r'{tmp_path}/r1_' + str(i) + '.npy', y)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_INLINE="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for i, (mc, B, hwd) in enumerate(R1_CASES):
+        y, name = _r1_forward(mc, B, hwd, 70 + i)
+        assert "k_conv_wino24s" in name and "producer" not in name, name
+        want = np.load(f"{tmp_path}/r1_{i}.npy")
+        assert np.array_equal(y, want), (mc, B, hwd, float(np.abs(y - want).max()))
 
 
 def test_unet_forward_vs_oracle_towerruins64(oracle):
