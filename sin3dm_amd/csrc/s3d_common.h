@@ -214,6 +214,8 @@ size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, 
 int launch_conv_wino24(ConvArgs& a, hipStream_t st);
 size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st);
+int launch_conv_wino24p(ConvArgs& a, hipStream_t st);           // the persistent form (S3D_WINO24_PERSIST=0 disables it)
+bool conv_wino24_takes_persistent(const ConvArgs& a);           // more tiles than co-resident blocks
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {

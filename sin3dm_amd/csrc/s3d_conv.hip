@@ -537,6 +537,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
             if (const int k24 = takes_wino24(a)) {
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = k24 == 2 ? a.job[j].wgt_wino24 : a.job[j].wgt_wino24s;
                 if (r1) return launch_conv_wino24s_r1(a, *r1, sync_expect, st);
+                if (k24 == 1 && conv_wino24_takes_persistent(a)) return launch_conv_wino24p(a, st);
                 return k24 == 2 ? launch_conv_wino24(a, st) : launch_conv_wino24s(a, st);
             }
             if (conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) {   // (its epilogue moves channel quads; GroupNorm'd layers always qualify)

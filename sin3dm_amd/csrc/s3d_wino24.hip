@@ -686,6 +686,431 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
     W24_STAMP(5)
 }
 
+// ------------------------------------------------------------------ the persistent form: a block owns SEVERAL tiles
+// k_conv_wino24s pays ~4 us before a tile's first MFMA (halo chunk 0: HBM/L2 -> registers -> LDS -> barrier -> operands) and
+// ~4 us after its last (operand loads, share images, finishing stores), and all co-resident blocks pay them together
+// (profiles/r02_wino_ubench.txt): 8 of every ~27 us at K = 128.  Here a launch has at most one block per slot (three per CU) and
+// block i walks tiles i, i + G, i + 2G, ... (G = grid size, a multiple of 8, so a block's tiles stay on its XCD's contiguous
+// range).  Same arithmetic in the same order as k_conv_wino24s — results are bit-identical — but across a tile boundary:
+//   * the NEXT tile's halo chunk 0 and first six weight fragments are requested during the LAST chunk of the current tile
+//     (that chunk has no successor of its own to fetch) and wait in registers; its second chunk's first half is requested
+//     with the epilogue operands;
+//   * the epilogue operands (rank-1 tables, residual) are requested before the share images are written, as before;
+//   * after the share images are consumed the parked halo goes to LDS and the next k-loop starts one barrier later; the
+//     finishing stores drain beside it.
+// What a boundary still exposes is LDS traffic and four barriers (~2 us) instead of two HBM round trips — per tile the phases
+// add up to 29.6 us against 32.9 us for k_conv_wino24s (batch 8, K = 128) — and yet the launch is SLOWER (601 vs 547 us), so the
+// form is off by default (S3D_WINO24_PERSIST=1 enables it; profiles/r03_wino_persistent.txt).  Two reasons, both structural:
+//   * on gfx9 stores share the in-order vmcnt counter with loads: whatever waits for a load issued after a tile's output
+//     stores also waits for their write acknowledgements.  A block of k_conv_wino24s ends behind its stores and the hardware
+//     starts the next block in its slot at once; a persistent block meets them at its next vmcnt wait (a scratch reload of a
+//     spilled value right behind the stores cost ~7 us per tile in the first version; with the stores moved last, the next
+//     k-loop's first weight wait is ~1.3 us behind them).  Hiding that needs ~40 more live registers across the boundary
+//     (parked halo, weight ring, second-chunk halo, finished outputs) than the 168 that three blocks per CU allow: every variant
+//     built spilled 22-68 registers around the boundary, and each reload is a vmcnt(0);
+//   * all blocks start together and own tiles of equal length, so every boundary — and its burst of operand loads and output
+//     stores — hits every CU at the same moment, tile after tile; hardware-dispatched blocks drift apart and keep the k-loops
+//     of their CU's neighbours running.  A deliberate one-third-tile start stagger (S3D_W24P_STAGGER) did not recover it.
+#ifndef W24P_EARLY_RING
+#define W24P_EARLY_RING 0          // 1: the next tile's first weight fragments + second-chunk halo are requested right after the share images are written (more live registers in the epilogue)
+#endif
+__global__ __launch_bounds__(256, 3) void k_conv_wino24p(ConvArgs args, int total_tiles, int stagger_ticks) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];
+    static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wlane = lane * 16;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);                 // row frequency of this wave
+    const int t16 = lane & 15, g = lane >> 4;                               // tile of the lane, channel quad of the lane
+    const int tr = t16 >> 2, tc = t16 & 3;
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(u == 1 ? 0x3F800000 : 0xBF800000));
+    const int qx = g ^ (((tr + (xrow >> 1)) & 3) << 1), qy = g ^ (((tr + (yrow >> 1)) & 3) << 1);
+    const int bx = ((2 * tr + xrow) * C_HW + 4 * tc) * C_LD * 4, by = ((2 * tr + yrow) * C_HW + 4 * tc) * C_LD * 4;
+    const int ax0 = bx + 16 * qx, ax1 = bx + 16 * (qx ^ 4), ay0 = by + 16 * qy, ay1 = by + 16 * (qy ^ 4);
+    const int cin = args.cin, cout = args.cout;
+    const int k16_total = cin / 16, nchunks = cin / C_KC;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // tile-independent halo staging geometry: item = it*256 + tid -> (pixel item>>3, channel quad item&7)
+    auto lds_off = [&](int it, int t) {
+        const int item = it * 256 + t;
+        const int pix = item >> 3, q = item & 7;
+        const int hy = pix / C_HW;
+        return pix * C_LD + ((q ^ (((hy >> 1) & 3) << 1)) << 2);
+    };
+    int loff[C_ITEMS_PT - 1];
+#pragma unroll
+    for (int it = 0; it < C_ITEMS_PT - 1; ++it) loff[it] = lds_off(it, tid);
+    const bool last_ok = (C_ITEMS_PT - 1) * 256 + tid < C_ITEMS;
+    auto item_store = [&](int it, int buf, f32x4 v) {
+        if (it < C_ITEMS_PT - 1) *reinterpret_cast<f32x4*>(smem + buf * C_ABUF + loff[it]) = v;
+        else if (last_ok) {            // the sixth round covers 160 items: its offset is recomputed (one register less across the k-loop; kept, it lived in scratch)
+            int wl = wlane;                         // = 16 * lane, live across the k-loop anyway (the weight fragments' offset)
+            asm volatile("" : "+v"(wl));
+            *reinterpret_cast<f32x4*>(smem + buf * C_ABUF + lds_off(C_ITEMS_PT - 1, (wl >> 4) + u * 64)) = v;
+        }
+    };
+
+    // per-tile context (wave-uniform except goff)
+    struct Ctx {
+        int j, n32, b, tile_idx, ty0, tx0, h, w;
+        __amdgpu_buffer_rsrc_t rs, wrs;
+        unsigned goff[C_ITEMS_PT];
+    };
+    const int G = int(gridDim.x);
+    const int xchunk = total_tiles >> 3;
+    auto setup = [&](int phys, Ctx& c) {
+        int bid = phys;
+        if ((args.xcd_swizzle & 1) && bid < (xchunk << 3)) bid = (bid & 7) * xchunk + (bid >> 3);
+        int j = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
+        const ConvJob& J = args.job[j];
+        int local = bid - J.block_begin;
+        c.j = j;
+        c.n32 = local % J.n_tiles_n; local /= J.n_tiles_n;
+        c.b = local / J.tiles_per_img; local %= J.tiles_per_img;
+        c.tile_idx = local;
+        c.ty0 = (local / J.tiles_x) * C_TH; c.tx0 = (local % J.tiles_x) * C_TW;
+        c.h = J.h; c.w = J.w;
+        c.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.in + size_t(c.b) * c.h * c.w * cin), 0, c.h * c.w * cin * 4, 0x00020000);
+        c.wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(J.wgt + ((size_t(c.n32) * k16_total) * 48 + u * 12) * 256), 0, k16_total * 48 * 1024, 0x00020000);
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));                  // recompute the halo geometry per tile: hoisted out of the tile loop it only lives in scratch
+#pragma unroll
+        for (int it = 0; it < C_ITEMS_PT; ++it) {
+            const int item = it * 256 + tid_;
+            const int pix = item >> 3, q = item & 7;
+            const int hy = pix / C_HW, hx = pix - hy * C_HW;
+            const int gy = c.ty0 - 1 + hy, gx = c.tx0 - 1 + hx;
+            const bool ok = item < C_ITEMS && gy >= 0 && gy < c.h && gx >= 0 && gx < c.w;
+            c.goff[it] = ok ? unsigned((gy * c.w + gx) * cin + q * 4) * 4u : 0x80000000u;
+        }
+    };
+    auto wfrag = [&](const __amdgpu_buffer_rsrc_t& rs, int step, int s) -> f32x4 {          // s = 2 * frequency + cout block
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wlane, (step * 48 + s) * 1024, 0));
+    };
+    auto item_load = [&](const Ctx& c, int it, int ch) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.rs, c.goff[it], ch * (C_KC * 4), 0));
+    };
+
+    Ctx cx, nx;
+    const int G_ = int(gridDim.x);
+    int phys = blockIdx.x;
+    setup(phys, cx);
+    if (stagger_ticks > 0) {
+        // the three blocks of a CU (dispatch order: ids b, b + G/3, b + 2G/3) start a third of a tile apart: their tile boundaries —
+        // LDS/barrier phases and the bursts of operand loads and output stores — then fall into each other's k-loops instead
+        // of hitting every CU and the memory system at the same moment, tile after tile
+        const int group = int(blockIdx.x) / ((G_ + 2) / 3);
+        const unsigned long long t0 = wall_clock64();
+        while (group > 0 && wall_clock64() - t0 < (unsigned long long)(group * stagger_ticks)) __builtin_amdgcn_s_sleep(32);
+    }
+    f32x4 V[6], ring[6], hN[C_ITEMS_PT], pre[3];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) { ring[s] = wfrag(cx.wrs, 0, s); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+    for (int it = 0; it < C_ITEMS_PT; ++it) hN[it] = item_load(cx, it, 0);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) pre[it] = item_load(cx, it, nchunks > 1 ? 1 : 0);
+
+#define C_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
+#define C_PIN(v) asm volatile("" : "+v"(v))
+#define C_COMB(T, X, Y) { _Pragma("unroll") for (int e = 0; e < 4; ++e) T[e] = fmaf(sgn, Y[e], X[e]); C_PIN(T); }
+    // WF(s_): the fragment that refills ring slot s_ % 6 — this step's fragment s_ + 6, or the NEXT step's fragment s_ - 6 (the
+    // next step is the next k-step of this tile, or step 0 of the next tile in the last step of a tile)
+#define P_GROUP(F, NB, WORK)                                                                                          \
+    {                                                                                                                 \
+        constexpr int s_ = 2 * (F) + (NB);                                                                            \
+        const f32x4 bq = ring[s_ % 6];                                                                                \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][0], bq[0], acc[F][NB], 0, 0, 0);                       \
+        if (s_ + 6 < 12) ring[s_ % 6] = wfrag(cx.wrs, step, s_ + 6); else if (P_NEXTSTEP) ring[s_ % 6] = wfrag(cx.wrs, nstep, s_ - 6);                       \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][1], bq[1], acc[F][NB], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        WORK                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][2], bq[2], acc[F][NB], 0, 0, 0);                       \
+        acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][3], bq[3], acc[F][NB], 0, 0, 0);                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+    // a k-step that also builds the next step's operands from the patch at byte addresses (rx, ry); LOADS: three halo requests
+#define P_STEP_BUILD(LOADS)                                                                                           \
+    {                                                                                                                 \
+        f32x4 cx0, cy0, cx1, cy1, t0, t1, t2, t3, t4, t5, s1, s2, s3, s4, v5n;                                        \
+        P_GROUP(0, 0, cx0 = C_LDS4(rx); cy0 = C_LDS4(ry); cx1 = C_LDS4(rx + C_LD * 4); cy1 = C_LDS4(ry + C_LD * 4);)  \
+        P_GROUP(0, 1, C_COMB(t0, cx0, cy0) C_COMB(t1, cx1, cy1) LOADS)                                                \
+        P_GROUP(1, 0, cx0 = C_LDS4(rx + 2 * C_LD * 4); cy0 = C_LDS4(ry + 2 * C_LD * 4); cx1 = C_LDS4(rx + 3 * C_LD * 4); cy1 = C_LDS4(ry + 3 * C_LD * 4);) \
+        P_GROUP(1, 1, C_COMB(t2, cx0, cy0) C_COMB(t3, cx1, cy1))                                                      \
+        P_GROUP(2, 0, cx0 = C_LDS4(rx + 4 * C_LD * 4); cy0 = C_LDS4(ry + 4 * C_LD * 4); cx1 = C_LDS4(rx + 5 * C_LD * 4); cy1 = C_LDS4(ry + 5 * C_LD * 4);) \
+        P_GROUP(2, 1, C_COMB(t4, cx0, cy0) C_COMB(t5, cx1, cy1))                                                      \
+        P_GROUP(3, 0, s1 = t4 - 4.f * t2; C_PIN(s1); s2 = t3 - 4.f * t1; C_PIN(s2); V[1] = s1 + s2; C_PIN(V[1]); V[2] = s1 - s2; C_PIN(V[2]);) \
+        P_GROUP(3, 1, V[0] = 4.f * t0 + (t4 - 5.f * t2); C_PIN(V[0]); s3 = t4 - t2; C_PIN(s3); s4 = t3 - t1; C_PIN(s4);) \
+        P_GROUP(4, 0, V[3] = s3 + 2.f * s4; C_PIN(V[3]);)                                                             \
+        P_GROUP(4, 1, v5n = 4.f * t1 + (t5 - 5.f * t3); C_PIN(v5n);)                                                  \
+        P_GROUP(5, 0, V[4] = s3 - 2.f * s4; C_PIN(V[4]);)                                                             \
+        P_GROUP(5, 1, ;)                                                                                              \
+        V[5] = v5n;                                                                                                   \
+    }
+    // the last k-step of a tile: nothing to build
+#define P_STEP_PLAIN(LOADS)                                                                                           \
+    {                                                                                                                 \
+        P_GROUP(0, 0, ;) P_GROUP(0, 1, LOADS) P_GROUP(1, 0, ;) P_GROUP(1, 1, ;) P_GROUP(2, 0, ;) P_GROUP(2, 1, ;)     \
+        P_GROUP(3, 0, ;) P_GROUP(3, 1, ;) P_GROUP(4, 0, ;) P_GROUP(4, 1, ;) P_GROUP(5, 0, ;) P_GROUP(5, 1, ;)         \
+    }
+
+    const int tog = C_ABUF * 4;
+#ifdef W24_TIMING
+#define P_STAMP(k) if (threadIdx.x == 0) g_w24time[size_t(phys) * 8 + (k)] = wall_clock64();
+#else
+#define P_STAMP(k)
+#endif
+    for (;;) {
+        const bool have_next = phys + G < total_tiles;
+        P_STAMP(0)
+        // ---- install the tile: its halo chunk 0 waits in hN, its first six weight fragments and the first half of chunk 1 were
+        // requested during the previous tile's epilogue (chunk 1 lands in buffer 1 after the first operands are built; the
+        // barrier of step (0,0) publishes it)
+#pragma unroll
+        for (int it = 0; it < C_ITEMS_PT; ++it) item_store(it, 0, hN[it]);
+        __syncthreads();
+        P_STAMP(1)
+        {
+            f32x4 t[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const f32x4 x = C_LDS4(ax0 + c * (C_LD * 4)), y = C_LDS4(ay0 + c * (C_LD * 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[c][e] = fmaf(sgn, y[e], x[e]);
+            }
+            const f32x4 s1 = t[4] - 4.f * t[2], s2 = t[3] - 4.f * t[1], s3 = t[4] - t[2], s4 = t[3] - t[1];
+            V[0] = 4.f * t[0] + (t[4] - 5.f * t[2]);
+            V[1] = s1 + s2; V[2] = s1 - s2;
+            V[3] = s3 + 2.f * s4; V[4] = s3 - 2.f * s4;
+            V[5] = 4.f * t[1] + (t[5] - 5.f * t[3]);
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) item_store(it, 1, pre[it]);
+
+        f32x4 acc[6][2];
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[f][nb] = zero4;
+
+        int cur = 0;                                  // byte offset of the buffer that holds the current chunk
+        P_STAMP(2)
+        __builtin_amdgcn_s_setprio(0);
+#define P_NEXTSTEP 1
+        for (int chunk = 0; chunk < nchunks - 1; ++chunk) {
+            const int cn1 = chunk + 1;
+            const int cn2 = chunk + 2 < nchunks ? chunk + 2 : nchunks - 1;
+            f32x4 pf[3];
+            {   // (chunk, 0): next operands = second 16 channels of the current buffer; halo items 3..5 of chunk c+1 -> other buffer; barrier
+                const int step = chunk * 2, nstep = step + 1;
+                const int rx = ax1 + cur, ry = ay1 + cur;
+                P_STEP_BUILD(pf[0] = item_load(cx, 3, cn1); pf[1] = item_load(cx, 4, cn1); pf[2] = item_load(cx, 5, cn1);)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) item_store(3 + t, (chunk + 1) & 1, pf[t]);
+                __syncthreads();
+            }
+            {   // (chunk, 1): next operands = first 16 channels of the other buffer; halo items 0..2 of chunk c+2 -> current buffer
+                const int step = chunk * 2 + 1, nstep = step + 1;
+                const int rx = ax0 + (cur ^ tog), ry = ay0 + (cur ^ tog);
+                P_STEP_BUILD(pf[0] = item_load(cx, 0, cn2); pf[1] = item_load(cx, 1, cn2); pf[2] = item_load(cx, 2, cn2);)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) item_store(t, chunk & 1, pf[t]);
+            }
+            cur ^= tog;
+        }
+        // the last chunk has no successor in this tile: its two steps request the NEXT tile's chunk 0 (parked in hN)
+        if (have_next) setup(phys + G, nx);
+        else {
+            nx.rs = cx.rs; nx.wrs = cx.wrs;
+#pragma unroll
+            for (int it = 0; it < C_ITEMS_PT; ++it) nx.goff[it] = 0x80000000u;     // out of range: the loads return zeros, no traffic
+        }
+        {
+            const int step = (nchunks - 1) * 2, nstep = step + 1;
+            const int rx = ax1 + cur, ry = ay1 + cur;
+            P_STEP_BUILD(hN[0] = item_load(nx, 0, 0); hN[1] = item_load(nx, 1, 0); hN[2] = item_load(nx, 2, 0);)
+        }
+        {
+            const int step = (nchunks - 1) * 2 + 1, nstep = 0;
+#undef P_NEXTSTEP
+#define P_NEXTSTEP 0                                  /* (the next tile's first fragments are requested when it is installed) */
+            P_STEP_PLAIN(hN[3] = item_load(nx, 3, 0); hN[4] = item_load(nx, 4, 0); hN[5] = item_load(nx, 5, 0);)
+        }
+        if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+        P_STAMP(3)
+
+        // ---- epilogue (as k_conv_wino24s): operands requested before the barrier and the share-image writes
+        const ConvJob& J = args.job[cx.j];
+        const float* __restrict__ p_bias = J.bias;
+        const float* __restrict__ p_bbias = J.bbias;
+        const float* __restrict__ p_rcol = J.rcol;
+        const float* __restrict__ p_rrow = J.rrow;
+        const float* __restrict__ p_res = J.res;
+        float* __restrict__ p_out = J.out;
+        double* p_gn = J.gn_part;
+        const int h = cx.h, w = cx.w, b = cx.b, ty0 = cx.ty0, tx0 = cx.tx0;
+        // the thread's epilogue geometry is re-derived per tile from a value that lives across the k-loop anyway (hoisted out of
+        // the tile loop it would only live in scratch, and a scratch reload is a vmcnt(0) wait)
+        int te = (wlane >> 4) + u * 64;
+        asm volatile("" : "+v"(te));
+        const int quad = te & 7, xl = (te >> 3) & 15, rsel = te >> 7;
+        const int lane_e = te & 63, t16e = lane_e & 15, ge = lane_e >> 4;
+        const int co4 = cx.n32 * 32 + quad * 4;
+        const bool c_ok = co4 < cout;
+        const int coc = c_ok ? co4 : 0;
+        const int x = tx0 + xl;
+        const bool x_ok = x < w && c_ok;
+        const int xc = x < w ? x : 0;
+        f32x4 base4 = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+        if (p_bbias) base4 += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+        f32x4 tcol[4], trow[4], tres[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
+        if (p_rcol) {
+            if (ty0 > 0 && ty0 + C_TH < h) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + 0) * cout + coc);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tcol[k] = v0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = ty0 + rsel * 4 + k;
+                    tcol[k] = *reinterpret_cast<const f32x4*>(p_rcol + ((size_t(b) * w + xc) * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc);
+                }
+            }
+        }
+        if (p_rrow) {
+            const int vx = x_edge_variant(xc, w);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                trow[k] = *reinterpret_cast<const f32x4*>(p_rrow + ((size_t(b) * h + (y < h ? y : 0)) * 4 + vx) * cout + coc);
+            }
+        }
+        if (p_res) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                     // all patch reads of the last step are done
+        {
+            float* img = smem + u * C_IMG + t16e;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r], m4 = acc[4][nb][r], m5 = acc[5][nb][r];
+                    const float p = m1 + m2, q = m1 - m2, rr = m3 + m4, s = m3 - m4;
+                    const int pp = (ge * C_TW + 4 * r) * 32 + nb * 16;
+                    img[pp] = (m0 + p) + rr; img[pp + 32] = fmaf(2.f, s, q); img[pp + 64] = fmaf(4.f, rr, p); img[pp + 96] = fmaf(8.f, s, q) + m5;
+                }
+        }
+#if W24P_EARLY_RING
+        if (have_next) {                                     // the accumulators are free: the next tile's first requests go out now
+            const int c1 = nchunks > 1 ? 1 : 0;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { ring[s] = wfrag(nx.wrs, 0, s); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) pre[it] = item_load(nx, it, c1);
+        }
+#endif
+        __syncthreads();                                     // the share images are complete
+        P_STAMP(4)
+        f32x4 gs4 = zero4, gss4 = zero4, vout[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int yl = rsel * 4 + k;
+            const float* sp = smem + (yl & 1) * C_IMG + ((yl >> 1) * C_TW + xl) * 32 + quad * 4;
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + C_IMG),
+                        kc = *reinterpret_cast<const f32x4*>(sp + 2 * C_IMG);
+            const f32x4 sum3 = (yl & 1) ? (ka - kb) - kc : (ka + kb) + kc;
+            vout[k] = (sum3 + base4) + ((tcol[k] + trow[k]) + tres[k]);
+            if (x_ok && ty0 + yl < h) { gs4 += vout[k]; gss4 += vout[k] * vout[k]; }
+        }
+        __shared__ float gred[4][8][8];
+        if (p_gn) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) { gs4[e] += __shfl_xor(gs4[e], off, 64); gss4[e] += __shfl_xor(gss4[e], off, 64); }
+            if (lane_e < 8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gred[u][lane_e][e] = gs4[e]; gred[u][lane_e][4 + e] = gss4[e]; }
+            }
+        }
+        __syncthreads();                                     // the share images are consumed (and the waves' GroupNorm sums have met)
+        // (the output stores come LAST, below: on gfx9 stores share the in-order vmcnt counter with loads, so anything that waits
+        //  for a load issued after them also waits for their write acknowledgements — microseconds under load)
+        float* const out_base = p_out + ((size_t(b) * h + ty0 + rsel * 4) * w + x) * cout + co4;
+        const int out_rows = x_ok ? min(4, h - (ty0 + rsel * 4)) : 0;
+        const size_t out_pitch = size_t(w) * cout;
+        if (p_gn && te < 64) {                                // lanes 0..7 of wave 0: channel quad `quad` = lane
+            const int lane = lane_e;
+            double ds[4], dss[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int l8 = lane & 7;
+                ds[e] = ((double(gred[0][l8][e]) + double(gred[1][l8][e])) + double(gred[2][l8][e])) + double(gred[3][l8][e]);
+                dss[e] = ((double(gred[0][l8][4 + e]) + double(gred[1][l8][4 + e])) + double(gred[2][l8][4 + e])) + double(gred[3][l8][4 + e]);
+            }
+            const int sg = args.gn_sg;
+            const int part = cx.tile_idx;
+            auto put = [&](int sub, double sv, double ssv) {
+                double* dst = p_gn + ((size_t(b) * 3 * args.gn_nsub + sub) * args.gn_maxparts + part) * 2;
+                dst[0] = sv; dst[1] = ssv;
+            };
+            if (sg >= 4) {
+                double sv = (ds[0] + ds[1]) + (ds[2] + ds[3]), ssv = (dss[0] + dss[1]) + (dss[2] + dss[3]);
+                for (int off = 1; off < (sg >> 2); off <<= 1) { sv += __shfl_xor(sv, off, 64); ssv += __shfl_xor(ssv, off, 64); }
+                if (lane < 8 && c_ok && (co4 % sg) == 0) put(co4 / sg, sv, ssv);
+            } else if (lane < 8 && c_ok) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    if (sg == 2) put((co4 + e) / 2, ds[e] + ds[e + 1], dss[e] + dss[e + 1]);
+                    else { put(co4 + e, ds[e], dss[e]); put(co4 + e + 1, ds[e + 1], dss[e + 1]); }
+                }
+            }
+        }
+        auto store_out = [&]() {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < out_rows) *reinterpret_cast<f32x4*>(out_base + k * out_pitch) = vout[k];
+        };
+        if (!have_next) { store_out(); P_STAMP(5) break; }
+        phys += G;
+        setup(phys, cx);                                     // (recomputed rather than carried: fewer live registers in the k-loop)
+#if !W24P_EARLY_RING
+        {
+            const int c1 = nchunks > 1 ? 1 : 0;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) { ring[s] = wfrag(cx.wrs, 0, s); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int it = 0; it < 3; ++it) pre[it] = item_load(cx, it, c1);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        store_out();
+        __builtin_amdgcn_sched_barrier(0);
+        phys -= G; P_STAMP(5) phys += G;
+
+    }
+#undef P_NEXTSTEP
+#undef P_STEP_PLAIN
+#undef P_STEP_BUILD
+#undef P_GROUP
+#undef C_COMB
+#undef C_LDS4
+#undef C_PIN
+}
+
 // ------------------------------------------------------------------ host side
 void wino24_gn_parts(const Geo& g, int nparts[3]) {      // one part per wave of a tile's block
     for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + X_TW - 1) / X_TW) * ((g.h[p] + X_TH - 1) / X_TH) * 4;
@@ -807,6 +1232,55 @@ int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect, hipStrea
     S3D_HIP(hipGetLastError());
     return 0;
 }
+
+static int conv_slots() {                     // co-resident 256-thread blocks of the 3x3 kernels: three per CU
+    static const int v = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return 3 * (cus > 0 ? cus : 256);
+    }();
+    return v;
+}
+bool conv_wino24_persistent_enabled() {
+    // default OFF: measured slower than one tile per block (profiles/r03_wino_persistent.txt)
+    static const bool on = getenv("S3D_WINO24_PERSIST") && atoi(getenv("S3D_WINO24_PERSIST")) != 0;
+    return on;
+}
+// The persistent form takes every launch that has more tiles than slots (each block then owns >= 2 tiles for some blocks);
+// smaller launches are one round of k_conv_wino24s anyway.  Results are bit-identical, so the choice may depend on the batch.
+int launch_conv_wino24p(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24p conv: bad arguments");
+    int blocks = 0;
+    for (int j = 0; j < a.njobs; ++j) {
+        ConvJob& J = a.job[j];
+        S3D_CHECK(size_t(J.h) * J.w * a.cin * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "wino24p conv: a plane of one sample must stay below 2 GiB");
+        J.tiles_x = (J.w + C_TW - 1) / C_TW;
+        J.tiles_per_img = J.tiles_x * ((J.h + C_TH - 1) / C_TH);
+        J.n_tiles_n = (a.cout + 31) / 32;
+        J.block_begin = blocks;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+    }
+    if (!blocks) return 0;
+    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
+    a.xcd_swizzle = xcd;
+    const int grid = std::min(blocks, conv_slots() & ~7);
+    // S3D_W24P_STAGGER = percent of a third of the estimated tile time by which the CU's second / third block start later
+    // (0 = off); only worth its one-off cost when a block owns many tiles
+    static const int stag_pct = getenv("S3D_W24P_STAGGER") ? atoi(getenv("S3D_W24P_STAGGER")) : 0;
+    static const int stag_min = getenv("S3D_W24P_STAGGER_MIN_TILES") ? atoi(getenv("S3D_W24P_STAGGER_MIN_TILES")) : 4;
+    const double tile_us = (a.cin / 32) * 4.8 + 6.0;
+    const int stagger_ticks = (stag_pct > 0 && blocks >= stag_min * grid) ? int(tile_us / 3.0 * stag_pct) : 0;      // 10-ns ticks: us * 100 * pct / 100
+    conv_note_kernel("k_conv_wino24p mixed Winograd F(2x4,3x3), 8x16-pixel tiles, persistent blocks (next tile's halo + weights prefetched across the tile boundary)");
+    hipLaunchKernelGGL(k_conv_wino24p, dim3(grid), dim3(256), 0, st, a, blocks, stagger_ticks);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+long long conv_wino24s_tiles(const ConvArgs& a) {
+    long long t = 0;
+    for (int j = 0; j < a.njobs; ++j) t += (long long)((a.job[j].w + C_TW - 1) / C_TW) * ((a.job[j].h + C_TH - 1) / C_TH) * ((a.cout + 31) / 32) * a.B;
+    return t;
+}
+bool conv_wino24_takes_persistent(const ConvArgs& a) { return conv_wino24_persistent_enabled() && conv_wino24s_tiles(a) > conv_slots(); }
 
 int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % X_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24 conv: bad arguments");

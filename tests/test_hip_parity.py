@@ -134,7 +134,8 @@ def test_unet_forward_golden_other_conv_kernels(variant):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-R1_CASES = [(32, 2, (10, 14, 6)), (64, 3, (40, 24, 56)), (128, 2, (64, 48, 32)), (128, 1, (128, 128, 128))]
+R1_CASES = [(32, 2, (10, 14, 6)), (64, 3, (40, 24, 56)), (128, 2, (64, 48, 32)), (128, 1, (128, 128, 128)),
+            (128, 3, (96, 80, 64))]      # the last two have more 8x16-pixel tiles than co-resident blocks (2, and 2-3 tiles per block)
 
 
 def _r1_forward(mc, B, hwd, seed):
@@ -151,11 +152,15 @@ def _r1_forward(mc, B, hwd, seed):
     return ys[0].cpu().numpy(), model.profile_kernel(0)
 
 
-def test_rank1_inline_is_bit_identical_and_is_what_runs(tmp_path):
-    """S3D_RANK1_INLINE=1: the rollout's means + rank-1 tables (unet_triplane.py:37-58) run as producer blocks INSIDE the 3x3
-    convolution launch (s3d_rank1.h; separate process — the switch is read once).  Same arithmetic in the same order: outputs
-    are bit-identical to the default stand-alone launches, repeated calls agree, no hand-off ever timed out, and the library
-    reports which form ran in either process."""
+@pytest.mark.parametrize("switch,value,other,default", [
+    ("S3D_RANK1_INLINE", "1", "in-launch producer", "k_conv_wino24"),
+    ("S3D_WINO24_PERSIST", "0", "k_conv_wino24s", "k_conv_wino24p")])
+def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, value, other, default):
+    """Two forms of the 3x3 launch that do the same arithmetic in the same order, each against the default in a separate
+    process (the switches are read once): S3D_RANK1_INLINE=1 — the rollout's means + rank-1 tables (unet_triplane.py:37-58) as
+    producer blocks INSIDE the convolution launch (s3d_rank1.h); S3D_WINO24_PERSIST=0 — one tile per block (k_conv_wino24s)
+    instead of the persistent blocks of k_conv_wino24p.  Outputs are bit-identical, repeated calls agree, no hand-off ever
+    timed out, and the library reports which kernel ran in either process (the last case has more tiles than slots)."""
     import os, subprocess, sys
     code = (
         "import numpy as np, sys\n"
@@ -163,16 +168,16 @@ def test_rank1_inline_is_bit_identical_and_is_what_runs(tmp_path):
         "import test_hip_parity as tp\n"
         "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
         "    y, name = tp._r1_forward(mc, B, hwd, 70 + i)\n"
-        "    assert 'in-launch producer' in name, name\n"
+        f"    assert i < 3 or {other!r} in name, name\n"
         f"    np.save(r'{tmp_path}/r1_' + str(i) + '.npy', y)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_INLINE="1"), capture_output=True,
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **{switch: value}), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     for i, (mc, B, hwd) in enumerate(R1_CASES):
         y, name = _r1_forward(mc, B, hwd, 70 + i)
-        assert "k_conv_wino24s" in name and "producer" not in name, name
+        assert "producer" not in name and (i < 3 or default in name), name
         want = np.load(f"{tmp_path}/r1_{i}.npy")
         assert np.array_equal(y, want), (mc, B, hwd, float(np.abs(y - want).max()))
 

@@ -22,10 +22,12 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> hw_(3 * wsz); for (auto& v : hw_) v = float(rand()) / RAND_MAX - 0.5f;
     CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemset(res, 0, npix * cout * 4)); CK(hipMemset(tab, 0, size_t(B) * hw * 4 * cout * 4));
-    const char* names[3] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px"};
-    const double frac[3] = {4.0 / 9, 1.0 / 3, 1.0 / 3};
-    for (int k = 0; k < 3; ++k) {
+    { std::vector<float> r(npix * cout); for (auto& v : r) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(res, r.data(), r.size() * 4, hipMemcpyHostToDevice));
+      std::vector<float> t(size_t(B) * hw * 4 * cout); for (auto& v : t) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice)); }
+    const char* names[4] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px", "wino24p F(2x4) persistent"};
+    const double frac[4] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3};
+    std::vector<float> ref_out;
+    for (int k = 0; k < 4; ++k) {
         ConvArgs a; memset(&a, 0, sizeof a);
         a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
         for (int p = 0; p < 3; ++p) {
@@ -33,7 +35,15 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
             a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
             if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
         }
-        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : launch_conv_wino24(a, 0)); };
+        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : (k == 2 ? launch_conv_wino24(a, 0) : launch_conv_wino24p(a, 0))); };
+        if (k == 1 || k == 3) {      // the persistent form must reproduce k_conv_wino24s bit for bit
+            CK(hipMemset(out, 0xFF, npix * cout * 4));
+            launch(); CK(hipDeviceSynchronize());
+            std::vector<float> o(npix * cout);
+            CK(hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost));
+            if (k == 1) ref_out.swap(o);
+            else printf("    persistent vs wino24s: %s\n", memcmp(o.data(), ref_out.data(), o.size() * 4) == 0 ? "bit-identical" : "MISMATCH");
+        }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         for (int i = 0; i < 3; ++i) launch();
         CK(hipDeviceSynchronize());
@@ -44,7 +54,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * npix;
         int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
 #ifdef W24_TIMING
-        if (k == 1) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
+        if (k == 1 || k == 3) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
             unsigned long long* tb = g_tb;
             launch(); CK(hipDeviceSynchronize());
             std::vector<unsigned long long> t(size_t(blocks) * 8);
@@ -57,7 +67,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
                 for (int q = 0; q < 5; ++q) ph[late][q] += (t[i * 8 + q + 1] - t[i * 8 + q]) * 0.01;
                 ++n[late];
             }
-            printf("    wino24s phases, span %.1f us:", (t5 - t0) * 0.01);
+            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : "wino24p (per tile; first-wave = each block's first tile)", (t5 - t0) * 0.01);
             for (int l = 0; l < 2; ++l)
                 if (n[l]) printf("  [%s %d blocks] halo->LDS %.1f | first operands %.1f | k-loop %.1f | barrier + share images + operand loads %.1f | finish + stores %.1f us",
                                  l ? "later" : "first-wave", n[l], ph[l][0] / n[l], ph[l][1] / n[l], ph[l][2] / n[l], ph[l][3] / n[l], ph[l][4] / n[l]);
