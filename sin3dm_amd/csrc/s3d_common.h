@@ -260,13 +260,19 @@ struct R1Job { const float* vin; const float* wgt; float* out; int L, tiles, blo
 struct R1Inline {
     int nprod;                // 0: plain convolution launch
     int na, nb, a_iters;      // an A block handles a_iters x 256 threads' worth of means_finalize items
-    int cin, n_tiles_n;       // mean-vector channels; cout / 8 column tiles of a table
+    int cin, cout, n_tiles_n; // mean-vector channels; the convolution's cout; ceil(cout / 8) column tiles of a table
     unsigned* sync;           // kSyncWords counters of the handle (never reset: targets are cumulative)
     unsigned a_target[8], b_target[3];
     R1Job job[6];             // job 2p: the row-indexed table of plane p, 2p + 1: the column-indexed one
     MeanFinArgs mf;
 };
 int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect /*host mirror of the counters*/, hipStream_t st);
+// block layout of the producer roles (r1.mf / job[].L set by the caller) and the cumulative counter targets of one launch
+void r1_layout(R1Inline& r1, int cout, int B);
+void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch);
+// means finalisation + rank-1 tables as ONE launch (A blocks, then B blocks that wait for them in-launch): s3d_conv.hip
+int launch_rank1_fused(R1Inline& r1, int cout, int B, unsigned* expect, hipStream_t st);
+bool conv_rank1_fused_enabled();          // S3D_RANK1_FUSED=1 (default off: measured slower)
 bool conv_rank1_inline_enabled();         // S3D_RANK1_INLINE=1 (default off: measured slower, profiles/r03_rank1_inline.txt)
 constexpr size_t kSyncWordsBytes = 12 * 32 * 4;   // = kSyncWords * 4 (s3d_rank1.h)
 

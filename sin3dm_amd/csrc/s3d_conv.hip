@@ -368,7 +368,60 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     blk.ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
     blk.b = local / J.tiles_per_img; blk.mtile = local % J.tiles_per_img;
     blk.vin = J.in; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.w; blk.cin = args.cin; blk.cout4 = args.cout; blk.n_tiles_n = J.n_tiles_n;
-    rank1_block<ROLL3, false>(blk, lds, []() {});
+    rank1_block<ROLL3, false, false>(blk, lds, []() {});
+}
+
+// means finalisation + rank-1 tables in ONE launch: the A blocks (lowest ids, dispatched first) finalize the six mean vectors
+// with write-through stores, the B blocks request their weights, wait for the A counters and build the tables (s3d_rank1.h).
+// Meant to take a launch boundary off the chain before every rollout convolution; same arithmetic in the same order as
+// k_means_finalize + k_rank1<true> (bit-identical) but MEASURED SLOWER (S3D_RANK1_FUSED=1 enables it).
+__global__ __launch_bounds__(256) void k_rank1_fused(R1Inline r1) {
+    __shared__ __attribute__((aligned(16))) float lds[kR1LdsFloats];
+    r1_producer_role<false>(r1, blockIdx.x, lds);
+}
+
+void r1_layout(R1Inline& r1, int cout, int B) {
+    r1.cout = cout;
+    r1.n_tiles_n = (cout + 7) / 8;
+    static const int aiters = getenv("S3D_R1_AITERS") ? std::max(1, atoi(getenv("S3D_R1_AITERS"))) : 1;
+    r1.a_iters = aiters;
+    const long long athreads = 4 * r1.mf.begin[6] * B;
+    r1.na = int((athreads + 256LL * r1.a_iters - 1) / (256LL * r1.a_iters));
+    int nb = 0;
+    for (int j = 0; j < 6; ++j) {
+        r1.job[j].tiles = (r1.job[j].L + 31) / 32;
+        r1.job[j].block_begin = nb;
+        nb += r1.job[j].tiles * r1.n_tiles_n * B;
+    }
+    r1.nb = nb;
+    r1.nprod = (r1.na + nb + 7) & ~7;
+}
+void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch) {
+    for (int k = 0; k < 8; ++k) {
+        expect[kSyncA + k] += unsigned(r1.na > k ? (r1.na - k + 7) / 8 : 0);
+        r1.a_target[k] = expect[kSyncA + k];
+    }
+    for (int p = 0; p < 3; ++p) {
+        if (tables_in_launch) expect[kSyncB + p] += unsigned((r1.job[2 * p].tiles + r1.job[2 * p + 1].tiles) * r1.n_tiles_n * B);
+        r1.b_target[p] = expect[kSyncB + p];
+    }
+}
+bool conv_rank1_fused_enabled() {
+    // default OFF: 22-25 us per launch against 5 + 9.5 us for the two stand-alone kernels (profiles/r03_rank1_inline.txt): an
+    // in-launch hand-off through memory (write-through store -> drain -> counter -> poll -> sc1 reload) costs ~8 us, a launch
+    // boundary ~2
+    static const bool on = getenv("S3D_RANK1_FUSED") && atoi(getenv("S3D_RANK1_FUSED")) != 0;
+    return on;
+}
+int launch_rank1_fused(R1Inline& r1, int cout, int B, unsigned* expect, hipStream_t st) {
+    S3D_CHECK(expect && r1.sync && cout % 4 == 0 && r1.cin % KC == 0, S3D_ERR_INVALID, "rank1_fused: bad arguments");
+    r1_layout(r1, cout, B);
+    if (!r1.nb) return 0;
+    r1_targets(r1, B, expect, false);
+    conv_note_kernel("k_rank1_fused (rollout means finalisation + three-tap rank-1 tables, one launch)");
+    hipLaunchKernelGGL(k_rank1_fused, dim3(r1.na + r1.nb), dim3(256), 0, st, r1);
+    S3D_HIP(hipGetLastError());
+    return 0;
 }
 
 // S3D_CONV_IMPL=naive counterpart of the ROLL3 form: one thread per table entry, plain loops over the same weight image

@@ -153,6 +153,17 @@ struct s3d_unet {
         prof_recs.push_back(r);
         return rc;
     }
+    template <class F>
+    int timed_launch(int cls, double flops, double mfma_flops, hipStream_t st, F fn) {
+        if (!prof_now) return fn();
+        ProfRec r{cls, prof_event(), prof_event(), flops, mfma_flops};
+        if (r.e0) (void)hipEventRecord(r.e0, st);
+        int rc = fn();
+        if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
+        if (r.e1) (void)hipEventRecord(r.e1, st);
+        prof_recs.push_back(r);
+        return rc;
+    }
     // side stream for work that is independent of the latency-bound norm/rank-1 chain (the 1x1 skip convolutions)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -279,8 +290,30 @@ struct Fwd {
         pend.active = false;
         return rank1_tables(pend.y, *pend.cw, pend.mp, pend.mv, pend.rrow, pend.rcol);
     }
+    void fill_r1(R1Inline& r1, const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
+        r1.nprod = 1;                                   // (the launcher fills in the layout)
+        r1.cin = y.C;
+        r1.mf = means_finalize_args(y.g, y.C, B, mp, mv);
+        // row-varying / column-varying vector of each plane
+        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
+        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
+        for (int p = 0; p < 3; ++p) {
+            r1.job[2 * p] = R1Job{rowvec[p], m->dev(cw.rrow[p]), const_cast<float*>(rrow[p]), y.g.h[p], 0, 0};
+            r1.job[2 * p + 1] = R1Job{colvec[p], m->dev(cw.rcol[p]), const_cast<float*>(rcol[p]), y.g.w[p], 0, 0};
+        }
+    }
     // th.mean over the axes + the six 1-D convolutions of the mean vectors (one launch each)
     int rank1_tables(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
+        if (conv_rank1_fused_enabled() && !conv_use_naive() && mv.base && cw.cout % 4 == 0) {
+            // one launch: A blocks finalize the means, B blocks wait for them in-launch and build the tables (s3d_rank1.h)
+            R1Inline r1; memset(&r1, 0, sizeof r1);
+            fill_r1(r1, y, cw, mp, mv, rrow, rcol);
+            S3D_TRY(m->sync_counters(st, &r1.sync));
+            double pos = 0;
+            for (int p = 0; p < 3; ++p) pos += y.g.h[p] + y.g.w[p];
+            const double fl = 2.0 * 9 * y.C * cw.cout * pos * B;
+            return m->timed_launch(2, fl, fl, st, [&]() { return launch_rank1_fused(r1, cw.cout, B, m->sync_expect, st); });
+        }
         S3D_TRY(launch_means_finalize(y.g, y.C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = y.C; ca.cout = cw.cout; ca.njobs = 6;
@@ -351,16 +384,8 @@ struct Fwd {
             else {
                 pend.active = false;
                 memset(&r1, 0, sizeof r1);
-                r1.nprod = 1;                                   // (the launcher fills in the layout)
-                r1.cin = pend.y.C;
+                fill_r1(r1, pend.y, cw, pend.mp, pend.mv, rrow, rcol);
                 S3D_TRY(m->sync_counters(st, &r1.sync));
-                r1.mf = means_finalize_args(pend.y.g, pend.y.C, B, pend.mp, pend.mv);
-                const float* rowvec[3] = {pend.mv.rowmean[1], pend.mv.rowmean[0], pend.mv.colmean[0]};   // as in rank1_tables
-                const float* colvec[3] = {pend.mv.rowmean[2], pend.mv.colmean[2], pend.mv.colmean[1]};
-                for (int p = 0; p < 3; ++p) {
-                    r1.job[2 * p] = R1Job{rowvec[p], m->dev(cw.rrow[p]), const_cast<float*>(rrow[p]), y.g.h[p], 0, 0};
-                    r1.job[2 * p + 1] = R1Job{colvec[p], m->dev(cw.rcol[p]), const_cast<float*>(rcol[p]), y.g.w[p], 0, 0};
-                }
             }
         }
         ConvArgs ca; memset(&ca, 0, sizeof ca);

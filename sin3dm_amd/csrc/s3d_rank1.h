@@ -108,11 +108,12 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
 // three taps o of the SUMMED-OUT axis (interior o0+o1+o2, first o1+o2, last o0+o1, single o1), so only the three per-tap
 // products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
 // 8 output channels = 24 weight rows — and the variants are formed while the four waves' partials are added.
-// SC1: the vector `vin` was written earlier in THIS launch (stage A): it is read with sc1 loads after `wait()` returns, and
-// the table leaves with 16-byte sc1 stores (requires cout % 4 == 0).  lds: kR1LdsFloats floats.
+// SC1: the vector `vin` was written earlier in THIS launch (stage A): it is read with sc1 loads after `wait()` returns.
+// SC1_OUT: the table is consumed later in THIS launch: it leaves with 16-byte sc1 stores (requires cout % 4 == 0).
+// lds: kR1LdsFloats floats.
 struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; };
 
-template <bool ROLL3, bool SC1, class Wait>
+template <bool ROLL3, bool SC1, bool SC1_OUT, class Wait>
 __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait wait) {
     float* sA = lds;
     float* sB0 = lds + 34 * kR1Ld;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
             const int r = (p & 3) + 4 * (p >> 3), l = ((p >> 2) & 1) * 32 + o * 8 + c8;
             return red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
         };
-        if (SC1) {
+        if (SC1_OUT) {
             // thread = (position, variant, channel quad of the block's eight): one 16-byte write-through store each
             const int p = tid >> 3, var = (tid >> 1) & 3, c4 = (tid & 1) * 4;
             const int row = mtile * 32 + p, co = ntile * 8 + c4;
@@ -244,6 +245,39 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
         const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
         if (row < L && col < cout4) J.out[(size_t(b) * L + row) * cout4 + col] = v;
     }
+}
+
+// ------------------------------------------------------------------ the producer roles of a launch with r1.nprod > 0
+// block ids [0, na) finalize the mean vectors (A), [na, na + nb) build the rank-1 tables from them (B), [na + nb, nprod) are
+// padding.  TABLES_IN_LAUNCH: the tables' consumers are blocks of the same launch (the 3x3 convolution's tiles): write-through
+// stores + a per-plane counter; otherwise the next launch reads them (stream order is the hand-off).
+template <bool TABLES_IN_LAUNCH>
+__device__ __forceinline__ void r1_producer_role(const R1Inline& r1, int bid, float* lds) {
+    const int tid = threadIdx.x;
+    if (bid < r1.na) {
+        for (int it = 0; it < r1.a_iters; ++it) means_finalize_thread<true>(r1.mf, ((long long)bid * r1.a_iters + it) * 256 + tid);
+        sync_publish(r1.sync + (kSyncA + (bid & 7)) * kSyncStride);
+        return;
+    }
+    const int lb = bid - r1.na;
+    if (lb >= r1.nb) return;
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 6; ++k) j += lb >= r1.job[k].block_begin ? 1 : 0;
+    const R1Job& J = r1.job[j];
+    int local = lb - J.block_begin;
+    R1Block blk;
+    blk.ntile = local % r1.n_tiles_n; local /= r1.n_tiles_n;
+    blk.b = local / J.tiles; blk.mtile = local % J.tiles;
+    blk.vin = J.vin; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.L; blk.cin = r1.cin; blk.cout4 = r1.cout; blk.n_tiles_n = r1.n_tiles_n;
+    rank1_block<true, true, TABLES_IN_LAUNCH>(blk, lds, [&]() {
+        if (tid < 8) {                                       // one lane per A counter
+            const unsigned* c = r1.sync + (kSyncA + tid) * kSyncStride;
+            if (!sync_wait(c, r1.a_target[tid], sync_load(c))) __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    });
+    if (TABLES_IN_LAUNCH) sync_publish(r1.sync + (kSyncB + (j >> 1)) * kSyncStride);
 }
 
 }  // namespace s3d

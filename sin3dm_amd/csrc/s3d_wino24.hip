@@ -347,36 +347,6 @@ constexpr int C_ITEMS_PT = (C_ITEMS + 255) / 256;            // 6 (the sixth rou
 constexpr int C_ABUF = C_HH * C_HW * C_LD;                   // floats per halo buffer (6480)
 constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image [4 tile rows][16 columns][32 channels]
 
-// The rollout's producer roles of a launch with r1.nprod > 0 (s3d_rank1.h): block ids [0, na) finalize the mean vectors,
-// [na, na + nb) build the rank-1 tables from them, [na + nb, nprod) are padding.
-__device__ __forceinline__ void wino24s_producer(const R1Inline& r1, int bid, float* smem) {
-    const int tid = threadIdx.x;
-    if (bid < r1.na) {
-        for (int it = 0; it < r1.a_iters; ++it) means_finalize_thread<true>(r1.mf, ((long long)bid * r1.a_iters + it) * 256 + tid);
-        sync_publish(r1.sync + (kSyncA + (bid & 7)) * kSyncStride);
-        return;
-    }
-    const int lb = bid - r1.na;
-    if (lb >= r1.nb) return;
-    int j = 0;
-#pragma unroll
-    for (int k = 1; k < 6; ++k) j += lb >= r1.job[k].block_begin ? 1 : 0;
-    const R1Job& J = r1.job[j];
-    int local = lb - J.block_begin;
-    R1Block blk;
-    blk.ntile = local % r1.n_tiles_n; local /= r1.n_tiles_n;
-    blk.b = local / J.tiles; blk.mtile = local % J.tiles;
-    blk.vin = J.vin; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.L; blk.cin = r1.cin; blk.cout4 = r1.n_tiles_n * 8; blk.n_tiles_n = r1.n_tiles_n;
-    rank1_block<true, true>(blk, smem, [&]() {
-        if (tid < 8) {                                       // one lane per A counter
-            const unsigned* c = r1.sync + (kSyncA + tid) * kSyncStride;
-            if (!sync_wait(c, r1.a_target[tid], sync_load(c))) __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    });
-    sync_publish(r1.sync + (kSyncB + (j >> 1)) * kSyncStride);
-}
-
 __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline r1) {
     __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];             // 51.8 KB: two halo buffers; four share images after the loop
     static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
@@ -384,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
     W24_STAMP(0)
     int bid = blockIdx.x;
     if (r1.nprod) {
-        if (bid < r1.nprod) { wino24s_producer(r1, bid, smem); return; }
+        if (bid < r1.nprod) { r1_producer_role<true>(r1, bid, smem); return; }
         bid -= r1.nprod;
     }
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
@@ -1189,19 +1159,7 @@ int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect, hipStrea
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24s conv: bad arguments");
     if (r1.nprod) {
         S3D_CHECK(a.njobs == 3 && expect && r1.sync && a.cout % 8 == 0, S3D_ERR_INVALID, "wino24s conv: in-launch rank-1 producers need the three planes of one TriplaneConv");
-        r1.n_tiles_n = a.cout / 8;
-        static const int aiters = getenv("S3D_R1_AITERS") ? std::max(1, atoi(getenv("S3D_R1_AITERS"))) : 1;
-        r1.a_iters = aiters;
-        const long long athreads = 4 * r1.mf.begin[6] * a.B;
-        r1.na = int((athreads + 256LL * r1.a_iters - 1) / (256LL * r1.a_iters));
-        int nb = 0;
-        for (int j = 0; j < 6; ++j) {
-            r1.job[j].tiles = (r1.job[j].L + 31) / 32;
-            r1.job[j].block_begin = nb;
-            nb += r1.job[j].tiles * r1.n_tiles_n * a.B;
-        }
-        r1.nb = nb;
-        r1.nprod = (r1.na + nb + 7) & ~7;
+        r1_layout(r1, a.cout, a.B);
     }
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
@@ -1214,16 +1172,7 @@ int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect, hipStrea
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    if (r1.nprod) {                                   // what each counter will have reached when this launch's producers are done
-        for (int k = 0; k < 8; ++k) {
-            expect[kSyncA + k] += unsigned(r1.na > k ? (r1.na - k + 7) / 8 : 0);
-            r1.a_target[k] = expect[kSyncA + k];
-        }
-        for (int p = 0; p < 3; ++p) {
-            expect[kSyncB + p] += unsigned((r1.job[2 * p].tiles + r1.job[2 * p + 1].tiles) * r1.n_tiles_n * a.B);
-            r1.b_target[p] = expect[kSyncB + p];
-        }
-    }
+    if (r1.nprod) r1_targets(r1, a.B, expect, true);    // what each counter will have reached when this launch's producers are done
     static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
     a.xcd_swizzle = xcd;
     conv_note_kernel(r1.nprod ? "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks, rollout means + rank-1 tables as in-launch producer blocks"

@@ -154,12 +154,15 @@ def _r1_forward(mc, B, hwd, seed):
 
 @pytest.mark.parametrize("switch,value,other,default", [
     ("S3D_RANK1_INLINE", "1", "in-launch producer", "k_conv_wino24"),
-    ("S3D_WINO24_PERSIST", "0", "k_conv_wino24s", "k_conv_wino24p")])
+    ("S3D_WINO24_PERSIST", "1", "k_conv_wino24p", "k_conv_wino24s"),
+    ("S3D_RANK1_FUSED", "1", "k_conv_wino24s", "k_conv_wino24s")])
 def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, value, other, default):
     """Two forms of the 3x3 launch that do the same arithmetic in the same order, each against the default in a separate
     process (the switches are read once): S3D_RANK1_INLINE=1 — the rollout's means + rank-1 tables (unet_triplane.py:37-58) as
-    producer blocks INSIDE the convolution launch (s3d_rank1.h); S3D_WINO24_PERSIST=0 — one tile per block (k_conv_wino24s)
-    instead of the persistent blocks of k_conv_wino24p.  Outputs are bit-identical, repeated calls agree, no hand-off ever
+    producer blocks INSIDE the convolution launch (s3d_rank1.h); S3D_WINO24_PERSIST=1 — persistent blocks that walk several
+    tiles (k_conv_wino24p) instead of one tile per block (k_conv_wino24s).  Both were measured slower and are off by default
+    (profiles/r03_rank1_inline.txt, r03_wino_persistent.txt); they stay tested.  S3D_RANK1_FUSED=1 — means finalisation and
+    rank-1 tables as one launch with an in-launch hand-off (k_rank1_fused) instead of two launches: slower too, same status.  Outputs are bit-identical, repeated calls agree, no hand-off ever
     timed out, and the library reports which kernel ran in either process (the last case has more tiles than slots)."""
     import os, subprocess, sys
     code = (
