@@ -581,11 +581,54 @@ def gen_formats():
         print(f"formats/{f}: {os.path.getsize(os.path.join(dst, f)) / 1024:.1f} KiB")
 
 
+def gen_ae_ckpt():
+    """formats/ckpt_final.pth: the dict ShapeAutoEncoder.save_ckpt writes (src/encoding/model.py:141-156 — {net, optimizer,
+    scheduler, Ka, Kd, Ks, Ns, aabb, featmap_size}), built from the reference's OWN objects: AutoEncoderGroupSkip.state_dict(),
+    the two-group AdamW of _set_optimizer (:129-139) after one step, its ExponentialLR.  ShapeAutoEncoder itself imports
+    tensorboard / mcubes at module level and cannot be imported here, hence the dict is assembled with its exact keys.  A
+    small network (up 16, hidden 32, 2 hidden layers) keeps the file small.  formats/ckpt_decode.npz: what the reference's
+    net.decode returns for that checkpoint (the load test's expectation)."""
+    from encoding.networks import AutoEncoderGroupSkip
+    from torch import optim
+    torch.set_grad_enabled(True)
+    cfg = dict(geo_feat_channels=4, tex_feat_channels=8, feat_channel_up=16, mlp_hidden_channels=32, mlp_hidden_layers=2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = AutoEncoderGroupSkip(*cfg.values())
+    sd = T.synthetic_state_dict(T.ae_param_shapes(**cfg, with_encoder=True), 6)
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected and missing == ["aabb"], (missing, unexpected)
+    aabb = torch.tensor([-0.6, -0.9, -0.5, 0.6, 0.9, 0.5])
+    net.reset_aabb(aabb)
+    lr, split, decay = 5e-3, 0.2, 0.999
+    opt = optim.AdamW([{"params": net.geo_parameters(), "lr": lr * split}, {"params": net.tex_parameters(), "lr": lr}], lr)
+    sched = optim.lr_scheduler.ExponentialLR(opt, decay)
+    H, W, D, N = 8, 12, 6, 64
+    vol = torch.tanh(rnd((1, 4, 2 * H, 2 * W, 2 * D), 1400))
+    pts = rnd((N, 3), 1401) * aabb[3:]
+    net.train()
+    net(vol, pts).square().mean().backward()
+    opt.step(); sched.step()
+    net.eval()
+    torch.set_grad_enabled(False)
+    dst = os.path.join(HERE, "formats")
+    os.makedirs(dst, exist_ok=True)
+    save_dict = {"net": net.cpu().state_dict(), "optimizer": opt.state_dict(), "scheduler": sched.state_dict(),
+                 "Ka": [1.0, 1.0, 1.0], "Kd": [0.8, 0.8, 0.8], "Ks": [0.5, 0.5, 0.5], "Ns": 250.0,
+                 "aabb": aabb.tolist(), "featmap_size": (H, W, D)}
+    torch.save(save_dict, os.path.join(dst, "ckpt_final.pth"))
+    fm = [torch.tanh(rnd(s, 1410 + i)) for i, s in enumerate(((1, 12, H, W), (1, 12, H, D), (1, 12, W, D)))]
+    q = rnd((96, 3), 1420) * aabb[3:] * 1.1                      # some points outside the box (border clamp)
+    pred = net.decode(q, fm)
+    save("formats/ckpt_decode", cfg=np.asarray(list(cfg.values())), xy=fm[0], xz=fm[1], yz=fm[2], pts=q, pred=pred,
+         first_param=net.state_dict()["geo_convs.in_layers.0.weight"].flatten()[:16])
+    print(f"formats/ckpt_final.pth: {os.path.getsize(os.path.join(dst, 'ckpt_final.pth')) / 1024:.1f} KiB")
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
                      ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
                      ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train), ("ae_train", gen_ae_train), ("respaced", gen_respaced_train),
-                     ("formats", gen_formats)):
+                     ("formats", gen_formats), ("ae_ckpt", gen_ae_ckpt)):
         if not only or name in only:
             fn()

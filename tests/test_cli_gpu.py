@@ -177,3 +177,30 @@ def test_reference_written_experiment_directory(tmp_path):
     assert diffusion.num_timesteps == 5
     s = diffusion.ddim_sample_loop(model, (2, 12, H + D, W + D), model_kwargs=dict(H=H, W=W, D=D))
     assert torch.isfinite(s).all() and float(s[..., H:, W:].abs().max()) == 0.0
+
+
+def test_reference_shaped_ae_checkpoint_loads_and_decodes(tmp_path):
+    """`<log_dir>/ckpt_final.pth` in the reference's own shape (src/encoding/model.py:141-156; fixture assembled from the
+    reference's net / AdamW / ExponentialLR objects by make_golden.py:gen_ae_ckpt) -> ShapeAutoEncoder.load_ckpt ->
+    decode_batch equals what the reference's net.decode returns for that checkpoint; aabb, featmap_size and the material
+    entries come back as the reference's load_ckpt (:158-176) would set them."""
+    import shutil
+    from types import SimpleNamespace
+    from test_formats import FMT
+    from conftest import relerr
+    from sin3dm_amd.encoding.model import ShapeAutoEncoder
+    g = np.load(os.path.join(FMT, "ckpt_decode.npz"))
+    geo, tex, up, hid, nl = (int(v) for v in g["cfg"])
+    log_dir = str(tmp_path / "encoding")
+    os.makedirs(log_dir)
+    shutil.copy(os.path.join(FMT, "ckpt_final.pth"), os.path.join(log_dir, "ckpt_final.pth"))
+    cfg = SimpleNamespace(enc_net_type="skip", fdim_geo=geo, fdim_tex=tex, fdim_up=up, hidden_dim=hid, n_hidden_layers=nl,
+                          data_type="sdftex", gpu_id=0)
+    ae = ShapeAutoEncoder(log_dir, cfg, device=torch.device("cuda:0"))
+    ae.load_ckpt("final")
+    assert tuple(ae.featmap_size) == (8, 12, 6) and ae.material["Ns"] == 250.0 and ae.material["Kd"] == [0.8, 0.8, 0.8]
+    assert np.allclose(ae.aabb.cpu().numpy(), [-0.6, -0.9, -0.5, 0.6, 0.9, 0.5])
+    assert np.array_equal(ae.net.state_dict()["geo_convs.in_layers.0.weight"].flatten()[:16].cpu().numpy(), g["first_param"])
+    fm = [torch.from_numpy(g[k]).cuda() for k in ("xy", "xz", "yz")]
+    pred = ae.decode_batch(fm, torch.from_numpy(g["pts"]).cuda())
+    assert relerr(pred.cpu().numpy(), g["pred"]) < 2e-5

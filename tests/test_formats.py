@@ -97,3 +97,21 @@ def test_reference_state_dict_loads_by_name(tmp_path):
         assert mine[k].dtype == sd[k].dtype and torch.equal(mine[k], sd[k]), k
     want = T.synthetic_state_dict(T.unet_param_shapes(model_channels=32, channel_mult="1"), 0)
     assert all(torch.equal(sd[k], want[k]) for k in want)                    # the generator's weights, bit for bit
+
+
+def test_reference_shaped_ae_checkpoint_parses():
+    """formats/ckpt_final.pth is the dict the reference's ShapeAutoEncoder.save_ckpt writes (src/encoding/model.py:141-156),
+    assembled by tests/golden/make_golden.py from the reference's own net / AdamW / ExponentialLR objects: every key the
+    reference's load_ckpt reads (:158-176) is there, and the net entry has exactly this build's state_dict names/shapes."""
+    import torch
+    from sin3dm_amd.encoding.networks import AutoEncoderGroupSkip
+    ck = torch.load(os.path.join(GOLDEN, "formats", "ckpt_final.pth"), map_location="cpu", weights_only=False)
+    assert list(ck) == ["net", "optimizer", "scheduler", "Ka", "Kd", "Ks", "Ns", "aabb", "featmap_size"]
+    g = np.load(os.path.join(GOLDEN, "formats", "ckpt_decode.npz"))
+    net = AutoEncoderGroupSkip(*[int(v) for v in g["cfg"]])
+    ours = net.state_dict()
+    assert set(ours) == set(ck["net"]), set(ours) ^ set(ck["net"])
+    for k, v in ck["net"].items():
+        assert tuple(ours[k].shape) == tuple(v.shape), k
+    assert len(ck["optimizer"]["param_groups"]) == 2 and ck["optimizer"]["param_groups"][0]["lr"] < ck["optimizer"]["param_groups"][1]["lr"]
+    assert len(ck["aabb"]) == 6 and tuple(ck["featmap_size"]) == (8, 12, 6)
