@@ -229,6 +229,12 @@ S3D_API int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, 
 /* d_out: gradient of the composed output [B,Cout,H+D,W+D].  grads: numel floats, every element is overwritten
  * (= the .grad of each parameter after loss.backward() from zeroed gradients). */
 S3D_API int s3d_unet_backward(s3d_unet* m, const float* d_out, float* grads, void* stream);
+/* The same with progress marks for a data-parallel trainer that overlaps the gradient all-reduce with the backward pass
+ * (the reference's DDP is commented out, src/diffusion/train_util.py:8-9, 98-99): events[k] (HIP events
+ * owned by the caller, n_events <= 2) are recorded on `stream` when a group of gradients is final — [0] out.* and
+ * output_blocks.* except their emb_layers, [1] input_blocks.* except their emb_layers and in_conv.*; time_embed.* and all
+ * emb_layers.* are final when the call's work is. */
+S3D_API int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void* stream, void** events, int n_events);
 
 /* q_sample (:189-207): x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise; tables fp32 [T] on the device, t int64 [B] */
 S3D_API int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,

@@ -162,7 +162,11 @@ struct Bwd {
 };
 
 // Backward of run_forward (s3d_unet.hip).  d_out: gradient of the composed output [B,Cout,H+D,W+D].
-static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream_t st) {
+// marks (optional): HIP events recorded on `st` when a group of parameter gradients is final — [0] after the output blocks
+// (out.* and output_blocks.* except the emb_layers), [1] after the input blocks and in_conv (input_blocks.* except the
+// emb_layers, in_conv.*); everything else (time_embed.*, every emb_layers.*) is final when the call's work is.  A data-parallel
+// trainer all-reduces the finished groups on a second stream while the rest of the backward pass runs.
+static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream_t st, hipEvent_t* marks = nullptr, int n_marks = 0) {
     const s3d_unet_cfg& c = m->cfg;
     const Tape& T = m->tape;
     const int B = T.B, mc = c.model_channels, ted = 4 * mc, nl = c.n_levels;
@@ -220,6 +224,8 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         d_h = d_prev;
     }
 
+    if (!meas && n_marks > 0 && marks[0]) S3D_HIP(hipEventRecord(marks[0], st));
+
     // ---- input blocks, deepest to first
     Tri d_x;                                        // gradient of the current level's resblock input
     for (int level = nl - 1; level >= 0; --level) {
@@ -254,6 +260,8 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
             S3D_TRY(launch_small_outer(so, st));
         }
     }
+
+    if (!meas && n_marks > 1 && marks[1]) S3D_HIP(hipEventRecord(marks[1], st));
 
     // ---- timestep MLP: film = Lf(silu(emb)), emb = L2(silu(pre1)), pre1 = L0(temb(t))
     {
@@ -356,12 +364,18 @@ int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, int B, i
 }
 
 int s3d_unet_backward(s3d_unet* m, const float* d_out, float* grads, void* stream) {
-    S3D_CHECK(m && d_out && grads, S3D_ERR_INVALID, "backward: null argument");
+    return s3d_unet_backward_marked(m, d_out, grads, stream, nullptr, 0);
+}
+
+int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void* stream, void** events, int n_events) {
+    S3D_CHECK(m && d_out && grads && n_events >= 0 && n_events <= 2 && (n_events == 0 || events), S3D_ERR_INVALID, "backward: bad argument");
     S3D_CHECK(m->tape.valid, S3D_ERR_INVALID, "backward: no forward_train activations (call s3d_unet_forward_train first; an "
               "inference forward in between discards them)");
     m->arena.off = m->tape.arena_off;
     m->tape.valid = false;                    // the tape is consumed: gradient buffers reuse no forward memory, but one backward per forward
-    return run_backward(m, d_out, grads, static_cast<hipStream_t>(stream));
+    hipEvent_t marks[2] = {nullptr, nullptr};
+    for (int k = 0; k < n_events; ++k) marks[k] = static_cast<hipEvent_t>(events[k]);
+    return run_backward(m, d_out, grads, static_cast<hipStream_t>(stream), marks, n_events);
 }
 
 int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, const int64_t* t, int B,

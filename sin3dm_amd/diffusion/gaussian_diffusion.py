@@ -357,7 +357,7 @@ class GaussianDiffusion:
         terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]
         return terms
 
-    def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None):
+    def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None, grad_marks=None):
         """Fast path of TrainLoop.forward_backward (train_util.py:205-236) without an autograd graph:
         loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`)."""
         if noise is None:
@@ -368,7 +368,7 @@ class GaussianDiffusion:
         target = self._training_target(x_start, x_t, t, noise).contiguous().float()
         mse = _mse_terms(out, target, H, W, D)
         wgt = (weights.to(out.device, th.float32) / out.shape[0])[:, None].expand(-1, 3).contiguous()
-        g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out)
+        g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out, **({"marks": grad_marks} if grad_marks else {}))
         terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2]}
         terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]       # the reference's order (:851), as training_losses
         return terms, g

@@ -113,6 +113,8 @@ class TrainLoop:
         if self.resume_step:
             self._load_optimizer_and_ema()
         self._grad = th.empty_like(self.model.flat_parameters)
+        self.overlap_allreduce = os.environ.get("S3D_OVERLAP_ALLREDUCE", "1") != "0"
+        self._marks = self._comm = self._groups = None
 
     # ------------------------------------------------------------------ resume
     def _load_optimizer_and_ema(self):
@@ -152,8 +154,21 @@ class TrainLoop:
         dev = self.model.flat_parameters.device
         micro = batch.to(dev)
         t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
-        losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
-        parallel.average_flat_(grad)                  # loss = mean over the GLOBAL batch: one all-reduce per step
+        if self.world > 1 and self.overlap_allreduce:
+            # loss = mean over the GLOBAL batch.  The backward pass fills the flat gradient from the output blocks towards
+            # the input; the groups that are final early are all-reduced on a communication stream while the rest of it
+            # runs (RCCL over xGMI on GPUs), joined before the optimizer step.  Bit-identical to the single all-reduce at
+            # world size 2 (tests/test_parallel.py); unmeasured on hardware until an 8-GPU node is available.
+            if self._marks is None:
+                self._marks = [th.cuda.Event(), th.cuda.Event()]
+                self._comm = th.cuda.Stream(device=dev)
+                self._groups = self.model.grad_ready_groups()
+            losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad,
+                                                                    grad_marks=self._marks)
+            parallel.average_flat_groups_(grad, self._groups, self._marks, self._comm)
+        else:
+            losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
+            parallel.average_flat_(grad)                  # one all-reduce of the whole flat vector per step
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
         if self.step % 10 == 0:

@@ -216,16 +216,31 @@ class _TriplaneUNetBase(nn.Module):
         self._train_inputs = (h, t)                # keep the tensors the tape points at alive until the backward
         return out
 
-    def backward_flat(self, d_out, out=None):
-        """Backward of the last forward_train: returns the flat gradient vector (layout of flat_parameters)."""
+    def backward_flat(self, d_out, out=None, marks=None):
+        """Backward of the last forward_train: returns the flat gradient vector (layout of flat_parameters).
+        marks: up to two torch.cuda.Event that the library records on the current stream when a group of gradients is final
+        (grad_ready_groups() says which ranges of the flat vector each one covers)."""
         lib = _lib.load()
         d_out = d_out.contiguous().float()
         g = out if out is not None else th.empty_like(self._flat)
         with th.cuda.device(d_out.device):
-            _lib.check(lib.s3d_unet_backward(self._handle, _lib.ptr(d_out), _lib.ptr(g), _lib.stream_ptr()))
+            if marks:
+                st = th.cuda.current_stream(d_out.device)
+                for ev in marks:
+                    ev.record(st)                      # (creates the underlying HIP event; re-recorded by the library at its mark)
+                evs = (C.c_void_p * len(marks))(*[C.c_void_p(ev.cuda_event) for ev in marks])
+                _lib.check(lib.s3d_unet_backward_marked(self._handle, _lib.ptr(d_out), _lib.ptr(g), _lib.stream_ptr(), evs, len(marks)))
+            else:
+                _lib.check(lib.s3d_unet_backward(self._handle, _lib.ptr(d_out), _lib.ptr(g), _lib.stream_ptr()))
         self._train_inputs = None
         self.last_flat_grad = g
         return g
+
+    def grad_ready_groups(self):
+        """[ranges final at mark 0, at mark 1, at the end of backward_flat]: merged (begin, end) ranges of the flat vector."""
+        from ..parallel import grad_ready_groups
+        self._ensure_flat()
+        return grad_ready_groups([(name, off, numel) for name, off, numel, _ in self._flat_layout])
 
     def split_flat(self, flat):
         """{name: view} of a vector laid out like flat_parameters."""

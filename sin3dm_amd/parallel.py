@@ -84,3 +84,77 @@ def average_flat_(flat):
         dist.all_reduce(flat)
         flat.mul_(1.0 / dist.get_world_size())
     return flat
+
+
+# ---- gradient exchange overlapped with the backward pass ("comm can simply overlap the tail of backward")
+def grad_ready_groups(layout):
+    """layout: [(parameter name, offset, numel)] of the flat vector in state-dict order.  The backward pass runs from the
+    output head towards the input, and the library marks two points (s3d_unet_backward_marked): returns three lists of merged
+    (begin, end) ranges — final at mark 0 (out.*, output_blocks.* except emb_layers), at mark 1 (input_blocks.* except
+    emb_layers, in_conv.*), and at the end (time_embed.*, every emb_layers.*: the stacked timestep linears come last)."""
+    groups = ([], [], [])
+    for name, off, numel in layout:
+        if "emb_layers" in name or name.startswith("time_embed"):
+            k = 2
+        elif name.startswith("out.") or name.startswith("output_blocks."):
+            k = 0
+        elif name.startswith("input_blocks.") or name.startswith("in_conv."):
+            k = 1
+        else:
+            k = 2
+        g = groups[k]
+        if g and g[-1][1] == off:
+            g[-1] = (g[-1][0], off + numel)
+        else:
+            g.append((off, off + numel))
+    assert sum(e - b for g in groups for b, e in g) == sum(n for _, _, n in layout)
+    return groups
+
+
+def _bucketed(flat, ranges, min_elems=1 << 16):
+    """Ranges as all-reduce calls: a large contiguous range is reduced in place; runs of small ones (norm weights, biases
+    between the emb_layers gaps) go through one packed staging buffer each, copied back afterwards."""
+    big = [(b, e) for b, e in ranges if e - b >= min_elems]
+    small = [(b, e) for b, e in ranges if e - b < min_elems]
+    return big, small
+
+
+def average_flat_groups_(flat, groups, marks=None, comm_stream=None):
+    """Mean over ranks of `flat`, group by group: bit-identical to average_flat_ at world size 2 (a two-term sum does not
+    depend on how the vector is cut).  On a GPU, with `marks` (the events the backward pass recorded) and `comm_stream`: each
+    group's all-reduces are enqueued on comm_stream behind its event, so they run while the main stream is still in the
+    backward pass; the caller's stream waits for comm_stream at the end.  Without them (CPU / gloo): sequential."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return flat
+    world = dist.get_world_size()
+    on_gpu = flat.is_cuda and comm_stream is not None
+    main = torch.cuda.current_stream(flat.device) if on_gpu else None
+
+    def reduce_group(ranges):
+        big, small = _bucketed(flat, ranges)
+        for b, e in big:
+            dist.all_reduce(flat[b:e])
+        if small:
+            stage = torch.cat([flat[b:e] for b, e in small])
+            dist.all_reduce(stage)
+            o = 0
+            for b, e in small:
+                flat[b:e].copy_(stage[o:o + e - b])
+                o += e - b
+
+    for k, ranges in enumerate(groups):
+        if not ranges:
+            continue
+        if on_gpu:
+            if marks is not None and k < len(marks):
+                comm_stream.wait_event(marks[k])
+            else:
+                comm_stream.wait_stream(main)             # the last group: everything the main stream has been given so far
+            with torch.cuda.stream(comm_stream):
+                reduce_group(ranges)
+        else:
+            reduce_group(ranges)
+    if on_gpu:
+        main.wait_stream(comm_stream)
+    flat.mul_(1.0 / world)
+    return flat

@@ -338,3 +338,38 @@ def test_adamw_ema_kernel_elementwise(wd):
         # moves the update by >= 1e-4
         assert np.max(np.abs(dp - dref)) < 1.5e-6, (s, np.max(np.abs(dp - dref)))
         assert np.max(np.abs(ema.double().cpu().numpy() - ema_ref.numpy())) < 1.5e-6, s
+
+
+def test_backward_progress_marks_and_overlapped_exchange_groups():
+    """s3d_unet_backward_marked: the same gradient bits as the unmarked call; its two events fire in order before the pass ends,
+    and at each of them the ranges grad_ready_groups() assigns to it already hold their final values (read on a second stream
+    behind the event — exactly what the data-parallel trainer's communication stream does with them)."""
+    import torch
+    g = golden("train_grads")
+    tag, mc, B = "mc32_a", 32, 2
+    m = _model(mc)
+    diffusion = _diffusion()
+    H, W, D, x0, noise = _inputs(g, tag, B)
+    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    w = torch.tensor([1.0, 0.5], device="cuda")
+    kw = dict(H=H, W=W, D=D)
+    _, g_plain = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+    g_plain = g_plain.clone()
+    groups = m.grad_ready_groups()
+    marks = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    end = torch.cuda.Event(enable_timing=True)
+    out = torch.full_like(g_plain, float("nan"))
+    side = torch.cuda.Stream()
+    _, g_marked = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise, grad_out=out, grad_marks=marks)
+    end.record()
+    snaps = []
+    for k in range(2):                                   # copy each early group out on the side stream as soon as its mark fires
+        side.wait_event(marks[k])
+        with torch.cuda.stream(side):
+            snaps.append([out[b:e].clone() for b, e in groups[k]])
+    torch.cuda.synchronize()
+    assert torch.equal(g_marked, g_plain)
+    assert marks[0].elapsed_time(marks[1]) > 0 and marks[1].elapsed_time(end) > 0
+    for k in range(2):
+        for (b, e), s in zip(groups[k], snaps[k]):
+            assert torch.equal(s, g_plain[b:e]), (k, b, e)

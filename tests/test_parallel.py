@@ -124,3 +124,70 @@ def test_two_rank_gloo_data_parallel_step(tmp_path):
         assert r["counts"] == [1, 1, 0, 2]                        # t=0 (rank 0), t=1 (rank 1), t=3 twice
         assert r["hist"][3] == [5.0, 6.0]                         # rank order
     assert res[0] == res[1]
+
+
+CHUNK_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["S3D_REPO"])
+import numpy as np, torch
+from sin3dm_amd import parallel, testing as T
+rank, local, world = parallel.init(backend="gloo")
+# the flat-vector layout of a real denoiser (state-dict order, as s3d_unet_param_offset lays it out)
+layout, off = [], 0
+for name, shp in T.unet_param_shapes(model_channels=32).items():
+    n = int(np.prod(shp)); layout.append((name, off, n)); off += n
+groups = parallel.grad_ready_groups(layout)
+g = torch.Generator().manual_seed(77 + rank)
+flat = torch.randn(off, generator=g) * torch.logspace(-6, 3, off)          # every magnitude: rounding differences would show
+whole = parallel.average_flat_(flat.clone())
+chunked = parallel.average_flat_groups_(flat.clone(), groups)
+covered = torch.zeros(off, dtype=torch.int32)
+for grp in groups:
+    for b, e in grp:
+        covered[b:e] += 1
+res = {"equal": bool(torch.equal(whole, chunked)), "covered_once": bool((covered == 1).all()), "n": off,
+       "ngroups": [len(x) for x in groups], "first": [x[0] if x else None for x in groups],
+       "sum": float(whole.double().sum())}
+out = parallel.gather_objects(res)
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+parallel.barrier()
+"""
+
+
+def test_grad_ready_groups_cover_the_flat_vector_in_backward_order():
+    import numpy as np
+    from sin3dm_amd import parallel, testing as T
+    layout, off = [], 0
+    for name, shp in T.unet_param_shapes(model_channels=32).items():
+        n = int(np.prod(shp)); layout.append((name, off, n)); off += n
+    g0, g1, g2 = parallel.grad_ready_groups(layout)
+    names = {k: [n for n, o, m in layout if any(b <= o < e for b, e in g)] for k, g in enumerate((g0, g1, g2))}
+    assert all(n.startswith(("out.", "output_blocks.")) and "emb_layers" not in n for n in names[0]) and names[0]
+    assert all(n.startswith(("input_blocks.", "in_conv.")) and "emb_layers" not in n for n in names[1]) and names[1]
+    assert all("emb_layers" in n or n.startswith("time_embed") for n in names[2]) and names[2]
+    assert sorted(names[0] + names[1] + names[2]) == sorted(n for n, _, _ in layout)
+    # the early groups carry nearly all the bytes (the 3x3 convolution weights): that is what overlaps with the backward pass
+    early = sum(e - b for g in (g0, g1) for b, e in g)
+    assert early > 0.8 * off
+
+
+def test_two_rank_gloo_chunked_allreduce_equals_whole_vector(tmp_path):
+    """The gradient all-reduce cut into the groups the backward pass finishes in order (parallel.average_flat_groups_, used by
+    TrainLoop.forward_backward with the library's progress marks on a GPU) gives bit for bit what ONE all-reduce of the whole
+    flat vector gives (world size 2, gloo)."""
+    import json
+    script = tmp_path / "chunk_worker.py"
+    script.write_text(CHUNK_WORKER)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-2000:]
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    for r in res:
+        assert r["equal"] and r["covered_once"], r
+    assert res[0]["sum"] == res[1]["sum"]
