@@ -586,12 +586,12 @@ def gen_ae_ckpt():
     scheduler, Ka, Kd, Ks, Ns, aabb, featmap_size}), built from the reference's OWN objects: AutoEncoderGroupSkip.state_dict(),
     the two-group AdamW of _set_optimizer (:129-139) after one step, its ExponentialLR.  ShapeAutoEncoder itself imports
     tensorboard / mcubes at module level and cannot be imported here, hence the dict is assembled with its exact keys.  A
-    small network (up 16, hidden 32, 2 hidden layers) keeps the file small.  formats/ckpt_decode.npz: what the reference's
+    small network (up 16, hidden 32) keeps the file small.  formats/ckpt_decode.npz: what the reference's
     net.decode returns for that checkpoint (the load test's expectation)."""
     from encoding.networks import AutoEncoderGroupSkip
     from torch import optim
     torch.set_grad_enabled(True)
-    cfg = dict(geo_feat_channels=4, tex_feat_channels=8, feat_channel_up=16, mlp_hidden_channels=32, mlp_hidden_layers=2)
+    cfg = dict(geo_feat_channels=4, tex_feat_channels=8, feat_channel_up=16, mlp_hidden_channels=32, mlp_hidden_layers=4)
     with contextlib.redirect_stdout(io.StringIO()):
         net = AutoEncoderGroupSkip(*cfg.values())
     sd = T.synthetic_state_dict(T.ae_param_shapes(**cfg, with_encoder=True), 6)
