@@ -531,8 +531,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    static const int xcd = getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1;
-    a.xcd_swizzle = xcd;
+    a.xcd_swizzle = 1;                       // XCD-aware block order (was switchable in rounds 1-2: always a win)
     conv_note_kernel(CFG::KH == 3 ? "k_conv_mfma<3x3> direct MFMA convolution" : (CFG::KH == 1 ? "k_conv_mfma<1x1> direct MFMA convolution" : "k_conv_mfma<5x5> direct MFMA convolution"));
     hipLaunchKernelGGL(k_conv_mfma<CFG>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());

@@ -164,24 +164,7 @@ struct s3d_unet {
         prof_recs.push_back(r);
         return rc;
     }
-    // side stream for work that is independent of the latency-bound norm/rank-1 chain (the 1x1 skip convolutions)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool side_ok() {
-        // measured neutral-to-slightly-negative at batch 1 (1.73 vs 1.72 ms/step): opt-in only
-        static const bool enabled = getenv("S3D_SIDE_STREAM") && strcmp(getenv("S3D_SIDE_STREAM"), "1") == 0;
-        if (!enabled) return false;
-        if (!side) {
-            if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
-            if (hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess) return false;
-        }
-        return ev_fork && ev_join;
-    }
     ~s3d_unet() {
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
-        if (side) (void)hipStreamDestroy(side);
         for (auto& r : prof_recs) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
         for (auto e : prof_pool) (void)hipEventDestroy(e);
     }
@@ -458,15 +441,12 @@ struct Fwd {
         const float* film_ptr = film ? film + rb.film_off : nullptr;
         Tri y1, h1, y2;
         const float *rr[3], *rc[3];
-        // skip_connection(x) only depends on x: enqueue it on the side stream first so it fills the CUs that the
-        // latency-bound norm / rank-1 chain and the Winograd conv's half-empty last round leave idle
+        // skip_connection(x) only depends on x (a second stream for it was measured in rounds 1 and 2: the event edges cost
+        // more than the overlap returns, DESIGN.md §5 — the switch is gone)
         Tri skip;
         const Tri* res = &x;
-        const bool fork = rb.has_skip && !ar().measuring && m->side_ok();
         if (rb.has_skip) {
-            if (fork) { S3D_HIP(hipEventRecord(m->ev_fork, st)); S3D_HIP(hipStreamWaitEvent(m->side, m->ev_fork, 0)); }
-            S3D_TRY(conv(x, rb.skip, nullptr, nullptr, nullptr, nullptr, skip, false, fork ? m->side : nullptr));
-            if (fork) S3D_HIP(hipEventRecord(m->ev_join, m->side));
+            S3D_TRY(conv(x, rb.skip, nullptr, nullptr, nullptr, nullptr, skip, false));
             res = &skip;
         }
         RBTape rt;
@@ -474,7 +454,6 @@ struct Fwd {
         S3D_TRY(norm_act(x, rb.n1, nullptr, &rb.c1, y1, rr, rc, T ? &T->n1 : nullptr));
         S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 2));   // partials only (norm_act adds them)      // (!ssn: h = h + emb_out, :298-303)
         S3D_TRY(norm_act(h1, rb.n2, ssn ? film_ptr : nullptr, &rb.c2, y2, rr, rc, T ? &T->n2 : nullptr));
-        if (fork) S3D_HIP(hipStreamWaitEvent(st, m->ev_join, 0));
         S3D_TRY(conv(y2, rb.c2, nullptr, rr, rc, res, out, out_stats_override >= 0 ? out_stats_override : (out_feeds_norm ? 1 : 0)));
         if (T) {
             rt.rb = &rb; rt.x = x; rt.y1 = y1; rt.h1 = h1; rt.y2 = y2;

@@ -675,8 +675,7 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
-    a.xcd_swizzle = xcd;
+    a.xcd_swizzle = 1 | 2;                   // XCD-aware block order + raised priority outside the k-loop (were switchable in rounds 1-2: always wins)
     conv_note_kernel(four ? "k_conv_wino4 Winograd F(2x2,3x3), one frequency row per wave" : "k_conv_wino2 Winograd F(2x2,3x3), two waves per SIMD");
     if (four) hipLaunchKernelGGL(k_conv_wino4, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_conv_wino2, dim3(blocks), dim3(256), 0, st, a);

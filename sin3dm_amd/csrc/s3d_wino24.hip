@@ -1173,8 +1173,7 @@ int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect, hipStrea
     }
     if (!blocks) return 0;
     if (r1.nprod) r1_targets(r1, a.B, expect, true);    // what each counter will have reached when this launch's producers are done
-    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
-    a.xcd_swizzle = xcd;
+    a.xcd_swizzle = 1 | 2;                   // XCD-aware block order + raised priority outside the k-loop (were switchable in rounds 1-2: always wins)
     conv_note_kernel(r1.nprod ? "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks, rollout means + rank-1 tables as in-launch producer blocks"
                               : "k_conv_wino24s mixed Winograd F(2x4,3x3), 8x16-pixel blocks");
     hipLaunchKernelGGL(k_conv_wino24s, dim3(blocks + r1.nprod), dim3(256), 0, st, a, r1);
@@ -1210,8 +1209,7 @@ int launch_conv_wino24p(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
-    a.xcd_swizzle = xcd;
+    a.xcd_swizzle = 1 | 2;                   // XCD-aware block order + raised priority outside the k-loop (were switchable in rounds 1-2: always wins)
     const int grid = std::min(blocks, conv_slots() & ~7);
     // S3D_W24P_STAGGER = percent of a third of the estimated tile time by which the CU's second / third block start later
     // (0 = off); only worth its one-off cost when a block owns many tiles
@@ -1244,8 +1242,7 @@ int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
     }
     if (!blocks) return 0;
-    static const int xcd = (getenv("S3D_XCD") ? atoi(getenv("S3D_XCD")) : 1) | (getenv("S3D_PRIO") ? atoi(getenv("S3D_PRIO")) * 2 : 2);
-    a.xcd_swizzle = xcd;
+    a.xcd_swizzle = 1 | 2;                   // XCD-aware block order + raised priority outside the k-loop (were switchable in rounds 1-2: always wins)
     conv_note_kernel("k_conv_wino24 mixed Winograd F(2x4,3x3), 16x16-pixel blocks");
     hipLaunchKernelGGL(k_conv_wino24, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());

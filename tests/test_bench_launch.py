@@ -44,9 +44,9 @@ def test_under_torchrun_environment_no_respawn():
 
 
 def test_switches_are_recorded():
-    r = _run("--gpus", "1", env={"S3D_WINO": "2", "S3D_XCD": "0"})
+    r = _run("--gpus", "1", env={"S3D_WINO": "2", "S3D_VCAT": "0"})
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert line["s3d_switches"] == {"S3D_WINO": "2", "S3D_XCD": "0"}
+    assert line["s3d_switches"] == {"S3D_WINO": "2", "S3D_VCAT": "0"}
 
 
 def test_peer_that_dies_before_rendezvous_ends_the_launch_within_seconds():
