@@ -458,6 +458,28 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #pragma unroll
     for (int it = 0; it < 3; ++it) item_store(it, 1, pre[it]);
 
+    // VERDICT r2 item 4, priced before built (tools/wino24_ubench.hip -DW24_GNSILU_PRICE; profiles/r03_gn_in_halo_price.txt): what
+    // GroupNorm-apply + FiLM + SiLU on the halo items between their load and their ds_write would cost the k-loop — two fmas, exp,
+    // rcp, mul and the padding select per element, constants per channel quad fetched per chunk.  (Arithmetic stand-in: results
+    // are meaningless in this build.)
+#ifdef W24_GNSILU_PRICE
+#define W24_PRICE_GNSILU                                                                                              \
+    {                                                                                                                 \
+        const f32x4 gA = *reinterpret_cast<const f32x4*>(J.wgt + ((lch * 32 + (tid & 7) * 4) % cout));                \
+        const f32x4 gB = *reinterpret_cast<const f32x4*>(J.wgt + ((lch * 32 + (tid & 7) * 4 + 4) % cout));            \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                               \
+            const bool ok_ = goff[it0 + t] != 0x80000000u;                                                            \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                           \
+                float v_ = fmaf(pf[t][e], gA[e], gB[e]);                                                              \
+                v_ = fmaf(v_, gB[e], gA[e]);                                                                          \
+                v_ = v_ * __builtin_amdgcn_rcpf(1.0f + __expf(-v_));                                                  \
+                pf[t][e] = ok_ ? v_ : 0.f;                                                                            \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+#else
+#define W24_PRICE_GNSILU
+#endif
     // One k-step (16 channels) = 12 groups {four MFMAs on one A operand + a piece of the other work}, pinned.
 #define C_GROUP(F, NB, WORK)                                                                                          \
     {                                                                                                                 \
@@ -500,6 +522,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
         C_GROUP(5, 0, V[4] = s3 - 2.f * s4; C_PIN(V[4]);)                                                             \
         C_GROUP(5, 1, ;)                                                                                              \
         V[5] = v5n;                                                                                                   \
+        W24_PRICE_GNSILU                                                                                              \
         _Pragma("unroll") for (int t = 0; t < 3; ++t) item_store(it0 + t, (KK) == 0 ? (chunk + 1) & 1 : chunk & 1, pf[t]); \
         if ((KK) == 0) __syncthreads();                                                                               \
     }
@@ -526,6 +549,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #undef C_COMB
 #undef C_LDS4
 #undef C_PIN
+#undef W24_PRICE_GNSILU
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     W24_STAMP(3)
     // ---- epilogue: as k_conv_wino24; lane (g, t16) holds output channel nb*16 + t16 of the tiles (tile row g, tile column r)

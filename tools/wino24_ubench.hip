@@ -2,7 +2,7 @@
 //   k_conv_wino4 (F(2x2), s3d_wino.hip), k_conv_wino24s and k_conv_wino24 (F(2x4), s3d_wino24.hip), random data, three square planes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino24_ubench.hip -o tools/ub_wino24
 #include "../sin3dm_amd/csrc/s3d_common.h"
-namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; }
+namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; } struct R1Inline; void r1_layout(R1Inline&, int, int) {} void r1_targets(R1Inline&, int, unsigned*, bool) {}
   size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
 #include "../sin3dm_amd/csrc/s3d_wino.hip"
 #include "../sin3dm_amd/csrc/s3d_wino24.hip"
