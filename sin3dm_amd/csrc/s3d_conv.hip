@@ -30,9 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;          // channels per K chunk
 constexpr int LDP = KC + 4;     // padded LDS row (floats)
 
-template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1>
+template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1, int PF_ = 0>
 struct ConvCfg {
     static constexpr int KS = KS_;       // independent partial accumulators over K (breaks the MFMA dependency chain)
+    static constexpr int PF = PF_;       // 1x1 only: K chunks of global loads kept in flight (0: the one-stage-ahead pipeline)
     static constexpr int TH = TH_, TW = TW_, KH = KH_, KW = KW_, WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
     static constexpr int BM = TH * TW, BN = WN * NTW * 32;
     static constexpr int HH = TH + KH - 1, HW = TW + KW - 1;
@@ -140,6 +141,64 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
     for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bbase + bDst[it]) = rb[it];
     __syncthreads();
 
+    if constexpr (TAPS == 1 && CFG::PF > 0) {
+        // 1x1 (round 3): a stage here is only KC/8 x MTW x NTW MFMAs (~0.3 us) — far less than a global round trip, so the
+        // one-stage-ahead pipeline below waits ~1.5 us in EVERY stage (33.7 us for 128->128 @128^2, MFMA pipe 23 % busy).
+        // Instead PF chunks of loads stay in flight in registers; a chunk is written to LDS when its turn comes, its register
+        // slot is refilled with chunk c + PF, one barrier per chunk.  (The prologue above already staged chunk 0.)
+        constexpr int PF = CFG::PF;
+        f32x4 qa[PF][CFG::NA], qb[PF][CFG::NB];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            const int ch = min(1 + d, nchunks - 1);
+#pragma unroll
+            for (int it = 0; it < CFG::NA; ++it) qa[d][it] = aSrc[it][ch * (KC / 4)];
+#pragma unroll
+            for (int it = 0; it < CFG::NB; ++it) qb[d][it] = bSrc[it][ch * (KC / 4)];
+        }
+        for (int c0 = 0; c0 < nchunks; c0 += PF) {
+#pragma unroll
+            for (int d = 0; d < PF; ++d) {
+                const int chunk = c0 + d;
+                if (chunk < nchunks) {
+                    const float* As = Abase + (chunk & 1) * CFG::A_ELEMS;
+                    const float* Bs = Bbase + (chunk & 1) * CFG::B_ELEMS;
+#pragma unroll
+                    for (int k8 = 0; k8 < KC / 8; ++k8) {
+                        f32x4 a4[MTW], b4[NTW];
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) a4[mt] = *reinterpret_cast<const f32x4*>(As + offA[mt] + k8 * 8);
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt) b4[nt] = *reinterpret_cast<const f32x4*>(Bs + offB[nt] + k8 * 8);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NTW; ++nt)
+                                    acc[(k8 * 4 + e) % KS][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt][e], b4[nt][e], acc[(k8 * 4 + e) % KS][mt][nt], 0, 0, 0);
+                    }
+                    // chunk + 1 (slot d) -> the other LDS buffer (its last readers passed the previous barrier), slot refilled
+                    if (chunk + 1 < nchunks) {
+                        float* Ad = Abase + ((chunk + 1) & 1) * CFG::A_ELEMS;
+                        float* Bd = Bbase + ((chunk + 1) & 1) * CFG::B_ELEMS;
+#pragma unroll
+                        for (int it = 0; it < CFG::NA; ++it) *reinterpret_cast<f32x4*>(Ad + aDst[it]) = aOk[it] ? qa[d][it] : zero4;
+#pragma unroll
+                        for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? qb[d][it] : zero4;
+                        const int ch = min(chunk + 1 + PF, nchunks - 1);
+                        if (chunk + 1 + PF < nchunks) {
+#pragma unroll
+                            for (int it = 0; it < CFG::NA; ++it) qa[d][it] = aSrc[it][ch * (KC / 4)];
+#pragma unroll
+                            for (int it = 0; it < CFG::NB; ++it) qb[d][it] = bSrc[it][ch * (KC / 4)];
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    } else
     // Pipeline: chunk-outer, taps fully unrolled.  The next chunk's A halo tile is fetched at the top of a chunk and
     // parked in registers for all TAPS stages; each stage fetches the next stage's B tile before its MFMA block and
     // writes it to the other LDS buffer after it.  The final stage re-fetches a clamped (valid) tile that nobody reads.
@@ -599,7 +658,14 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
             return launch_cfg<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>>(a, st);
         case CONV_1x1:         // (round-2 sweep in the step: 128 px x 64 cout 0.081, 64 x 128 0.078, 128 x 128 0.218, two K accumulators 0.081,
                                //  64-channel K chunks (70 KB LDS, two blocks per CU) 0.084, 16-channel chunks 0.077 vs 0.072 ms/step)
+        {
+            // global-load chunks in flight for the 1x1 kernels (round 3): 0 = one stage ahead 0.0713 ms/step,
+            // 2 = 0.0686, 4 = 0.0711 — the stages' memory latency is NOT what these launches wait for (profiles/r03_conv1x1.txt)
+            static const int pf = getenv("S3D_CONV1X1_PF") ? atoi(getenv("S3D_CONV1X1_PF")) : 2;
+            if (pf == 4) return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 4>>(a, st);
+            if (pf == 2) return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2>>(a, st);
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
+        }
         case CONV_1x3_VEC:
             return launch_rank1(a, st, false);
         case CONV_1x3_ROLL:
