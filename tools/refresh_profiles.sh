@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r02'
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r03'
 # Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
