@@ -104,6 +104,7 @@ struct ConvJob {
     const float* wgt_wino;// 3x3 only: Winograd-transformed weights in MFMA fragment order (s3d_wino.hip) or null
     const float* wgt_wino24;// 3x3 only: the F(2x4,3x3) image of the 16x16-pixel kernel (s3d_wino24.hip) or null
     const float* wgt_wino24s;// 3x3 only: the F(2x4,3x3) image of the 8x16-pixel kernel or null (both null: the F(2x2) kernels are used)
+    const float* wgt_wino44; // 3x3 only: set by the caller when this launch takes the F(4x4,3x3) kernel (s3d_wino44.hip), else null
     const float* bias;    // [cout] or null
     const float* bbias;   // [B][bbias_stride] per-sample bias (h + emb path) or null
     const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
@@ -152,6 +153,7 @@ struct ConvW {
     size_t wino[3] = {0, 0, 0};       // 3x3: G g G^T in fragment order (0 = not packed)
     size_t wino24[3] = {0, 0, 0};     // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24
     size_t wino24s[3] = {0, 0, 0};    // ... and of k_conv_wino24s
+    size_t wino44[3] = {0, 0, 0};     // 3x3: G g G^T of F(4x4,3x3) in the fragment order of k_conv_wino44 (0 = not packed)
     int cin = 0, cout = 0, k = 0;
     bool rollout = false;
 };
@@ -214,6 +216,13 @@ size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, 
 int launch_conv_wino24(ConvArgs& a, hipStream_t st);
 size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st);
+// full Winograd F(4x4,3x3) for launches with many tiles (s3d_wino44.hip); S3D_WINO44=0 disables it
+bool conv_wino44_enabled();
+bool conv_wino44_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B);   // does a launch over these planes / samples take it?
+void wino44_gn_parts(const Geo& g, int nparts[3]);
+size_t wino44_packed_floats(int cout, int cin);
+size_t pack_wino44_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
+int launch_conv_wino44(ConvArgs& a, hipStream_t st);
 int launch_conv_wino24p(ConvArgs& a, hipStream_t st);           // the persistent form (S3D_WINO24_PERSIST=0 disables it)
 bool conv_wino24_takes_persistent(const ConvArgs& a);           // more tiles than co-resident blocks
 

@@ -536,6 +536,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
 void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
+    if (wino24 == 3) { wino44_gn_parts(g, nparts); return; }
     if (wino24 == 2 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }
     if (wino24 == 1 && conv_use_wino24()) {                       // k_conv_wino24s: one part per 8x16-pixel block
         for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + 15) / 16) * ((g.h[p] + 7) / 8);
@@ -630,6 +631,7 @@ static int takes_wino24(const ConvArgs& a) {
     return 0;
 }
 double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
+    if (kind == CONV_3x3 && !conv_use_naive() && a.job[0].wgt_wino44) return 1.0 / 4.0;             // 36 multiplies per 4x4 outputs instead of 144
     if (kind == CONV_3x3 && !conv_use_naive() && takes_wino24(a)) return 1.0 / 3.0;      // 24 multiplies per 2x4 outputs instead of 72
     if (kind == CONV_3x3 && !conv_use_naive() && conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) return wino_exec_fraction();
     return 1.0;
@@ -637,7 +639,7 @@ double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
 
 int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsigned* sync_expect) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
-    S3D_CHECK(!r1 || (kind == CONV_3x3 && !conv_use_naive() && takes_wino24(a) == 1), S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
+    S3D_CHECK(!r1 || (kind == CONV_3x3 && !conv_use_naive() && !a.job[0].wgt_wino44 && takes_wino24(a) == 1), S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
     if (conv_use_naive()) return launch_conv_naive(kind, a, st);
     // Tile choice (measured, tools/conv_ubench.hip and in the step; for 1x1 again after the Winograd rework): the 64-pixel x 64-cout tile wins at every
@@ -645,6 +647,11 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
+            if (a.job[0].wgt_wino44) {                                     // the caller selected F(4x4) (conv_wino44_geo)
+                S3D_CHECK(!r1, S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
+                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino44;
+                return launch_conv_wino44(a, st);
+            }
             if (const int k24 = takes_wino24(a)) {
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = k24 == 2 ? a.job[j].wgt_wino24 : a.job[j].wgt_wino24s;
                 if (r1) return launch_conv_wino24s_r1(a, *r1, sync_expect, st);

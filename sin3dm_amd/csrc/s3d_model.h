@@ -80,6 +80,7 @@ struct s3d_unet {
     std::vector<ParamSpec> specs;
     std::map<std::string, std::vector<float>> host;     // as handed to set_param (PyTorch layouts)
     bool packed = false;
+    bool wino44_current = false;                         // the F(4x4) weight images match the parameters (host pack only)
 
     // packed parameters, one device allocation, offsets in floats
     DevBuf wbuf;
@@ -347,7 +348,11 @@ struct Fwd {
         if (!(cw.k == 3 && !conv_use_naive())) want_stats = 0;
         // the mixed Winograd kernel serves every forward (the tape keeps activations, not conv internals) and, on the transposed
         // image, the backward's dgrad (s3d_train.hip:conv_bwd)
-        const int w24 = cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) : 0;
+        // F(4x4) for inference launches with many tiles (the choice includes the batch; never under a training tape, whose
+        // backward pass has the mixed kernel's transposed operators)
+        const bool w44 = !tape && cw.k == 3 && cw.wino44[0] != 0 && m->wino44_current && !conv_use_naive() &&
+                         conv_wino44_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B);
+        const int w24 = w44 ? 3 : (cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) : 0);
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);
@@ -362,7 +367,7 @@ struct Fwd {
         // kernel on this stream; every other case gets the two stand-alone launches first
         R1Inline r1; r1.nprod = 0;
         if (pend.active) {
-            const bool mine = rrow && rcol && rrow[0] == pend.rrow[0] && w24 == 1 && !on && cw.cout % 8 == 0 && pend.cw == &cw;
+            const bool mine = rrow && rcol && rrow[0] == pend.rrow[0] && w24 == 1 && !on && cw.cout % 8 == 0 && pend.cw == &cw;   // (w24 == 3: F(4x4) -> flushed)
             if (!mine) S3D_TRY(flush_rank1());
             else {
                 pend.active = false;
@@ -380,6 +385,7 @@ struct Fwd {
             J.wgt_wino = cw.k == 3 && !w24 ? m->dev(cw.wino[p]) : nullptr;     // (the repack plan keeps only the image in use current)
             J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
             J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
+            J.wgt_wino44 = w44 ? m->dev(cw.wino44[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = fstride();
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.res_up = res && res_up ? 1 : 0; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];

@@ -105,6 +105,7 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
         if (k == 3 && cin % 32 == 0) {
             cw.wino24[p] = pack_wino24_weights(stage, W, cout, ctot, cin);
             cw.wino24s[p] = pack_wino24s_weights(stage, W, cout, ctot, cin);
+            if (conv_wino44_enabled() && cout % 4 == 0) cw.wino44[p] = pack_wino44_weights(stage, W, cout, ctot, cin);
         }
         if (!roll) continue;
         const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
@@ -214,6 +215,7 @@ int pack_all(s3d_unet* m) {
     S3D_TRY(upload(m->wbuf, m->stage.data(), m->stage.size() * sizeof(float)));
     m->stage.clear(); m->stage.shrink_to_fit();
     m->packed = true;
+    m->wino44_current = true;                         // (the device-side repack of the training tier does not rebuild the F(4x4) images)
     return 0;
 }
 

@@ -99,10 +99,12 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["r1on", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
+@pytest.mark.parametrize("variant", ["r1on", "44", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
 def test_unet_forward_golden_other_conv_kernels(variant):
     """Every 3x3 kernel on the golden planes (r1on: the default mixed Winograd F(2x4,3x3) kernel with S3D_RANK1_INLINE=1, i.e.
     the rollout's means + rank-1 tables as producer blocks of the convolution launch instead of two stand-alone launches;
+    44: the full Winograd F(4x4,3x3) kernel k_conv_wino44 (S3D_WINO44=1; measured slower, off by default) forced onto every
+    layer it can take with S3D_WINO44_MIN_TILES=0;
     24big: its 16x16-pixel form forced onto every layer with S3D_WINO24_BIG_MIN_BLOCKS=0; 4 / 2: F(2x2) with one / two
     frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors, leaf convolutions and ragged
     shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual concat of
@@ -126,7 +128,7 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    e = relerr(y, g[f'{tag}.y'])\n"
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
-    env = {"r1on": dict(S3D_RANK1_INLINE="1"), "24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
+    env = {"r1on": dict(S3D_RANK1_INLINE="1"), "44": dict(S3D_WINO44="1", S3D_WINO44_MIN_TILES="0"), "24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
            "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0")}.get(variant, dict(S3D_WINO=variant))
     env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

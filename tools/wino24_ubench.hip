@@ -6,6 +6,7 @@ namespace s3d { void set_error(const char*, ...) {} const char* get_error() { re
   size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
 #include "../sin3dm_amd/csrc/s3d_wino.hip"
 #include "../sin3dm_amd/csrc/s3d_wino24.hip"
+#include "../sin3dm_amd/csrc/s3d_wino44.hip"
 #include <cstdlib>
 using namespace s3d;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -15,7 +16,7 @@ static unsigned long long* g_tb = nullptr;
 static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     const size_t npix = size_t(3) * hw * hw * B;
     float *in, *wgt, *out, *res, *tab;
-    const size_t wsz = wino24_packed_floats(cout, cin);          // >= the F(2x2) image
+    const size_t wsz = wino44_packed_floats(cout, cin);          // >= the F(2x4) and F(2x2) images
     CK(hipMalloc(&in, npix * cin * 4)); CK(hipMalloc(&wgt, 3 * wsz * 4)); CK(hipMalloc(&out, npix * cout * 4)); CK(hipMalloc(&res, npix * cout * 4));
     CK(hipMalloc(&tab, size_t(B) * hw * 4 * cout * 4));
     std::vector<float> h(npix * cin); for (auto& v : h) v = float(rand()) / RAND_MAX - 0.5f;
@@ -24,10 +25,10 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
     { std::vector<float> r(npix * cout); for (auto& v : r) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(res, r.data(), r.size() * 4, hipMemcpyHostToDevice));
       std::vector<float> t(size_t(B) * hw * 4 * cout); for (auto& v : t) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice)); }
-    const char* names[4] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px", "wino24p F(2x4) persistent"};
-    const double frac[4] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3};
+    const char* names[5] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px", "wino24p F(2x4) persistent", "wino44 F(4x4) 16x16 px "};
+    const double frac[5] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 4};
     std::vector<float> ref_out;
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 5; ++k) {
         ConvArgs a; memset(&a, 0, sizeof a);
         a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
         for (int p = 0; p < 3; ++p) {
@@ -35,7 +36,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
             a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
             if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
         }
-        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : (k == 2 ? launch_conv_wino24(a, 0) : launch_conv_wino24p(a, 0))); };
+        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : (k == 2 ? launch_conv_wino24(a, 0) : (k == 3 ? launch_conv_wino24p(a, 0) : launch_conv_wino44(a, 0)))); };
         if (k == 1 || k == 3) {      // the persistent form must reproduce k_conv_wino24s bit for bit
             CK(hipMemset(out, 0xFF, npix * cout * 4));
             launch(); CK(hipDeviceSynchronize());
@@ -54,7 +55,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * npix;
         int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
 #ifdef W24_TIMING
-        if (k == 1 || k == 3) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
+        if (k == 1 || k == 3 || k == 4) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
             unsigned long long* tb = g_tb;
             launch(); CK(hipDeviceSynchronize());
             std::vector<unsigned long long> t(size_t(blocks) * 8);
@@ -67,7 +68,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
                 for (int q = 0; q < 5; ++q) ph[late][q] += (t[i * 8 + q + 1] - t[i * 8 + q]) * 0.01;
                 ++n[late];
             }
-            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : "wino24p (per tile; first-wave = each block's first tile)", (t5 - t0) * 0.01);
+            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : (k == 4 ? "wino44" : "wino24p (per tile; first-wave = each block's first tile)"), (t5 - t0) * 0.01);
             for (int l = 0; l < 2; ++l)
                 if (n[l]) printf("  [%s %d blocks] halo->LDS %.1f | first operands %.1f | k-loop %.1f | barrier + share images + operand loads %.1f | finish + stores %.1f us",
                                  l ? "later" : "first-wave", n[l], ph[l][0] / n[l], ph[l][1] / n[l], ph[l][2] / n[l], ph[l][3] / n[l], ph[l][4] / n[l]);
