@@ -126,6 +126,10 @@ struct ConvArgs {
     int gn_sg, gn_nsub, gn_maxparts;          // GroupNorm partial layout when job[].gn_part is set
     int relu;                                 // direct kernels only: ReLU in the epilogue (the decoder MLPs as 1x1 convs)
     int xcd_swizzle;                          // Winograd kernel: logical block order contiguous per XCD (set by the launcher)
+    // rank-1 rollout tables cut into two K slices (0 / 1: one table).  CONV_1x3_ROLL launches: a block contracts half of the
+    // 128-channel chunks and writes slice s at out + s * B * L * 4 * cout.  k_conv_wino24s: rrow / rcol are read as the sum of the
+    // two tables (slice stride B * h * 4 * cout / B * w * 4 * cout floats)
+    int r1_slices;
 };
 // CONV_1x3_ROLL: the forward rollout tables — args.cout = the convolution's cout, out [B][pos][4 variants][cout] (k_rank1<true>)
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3, CONV_1x3_ROLL = 4 };
@@ -225,6 +229,7 @@ size_t pack_wino44_weights(std::vector<float>& stage, const float* W, int cout, 
 int launch_conv_wino44(ConvArgs& a, hipStream_t st);
 int launch_conv_wino24p(ConvArgs& a, hipStream_t st);           // the persistent form (S3D_WINO24_PERSIST=0 disables it)
 bool conv_wino24_takes_persistent(const ConvArgs& a);           // more tiles than co-resident blocks
+bool conv_wino24_persistent_enabled();
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {
@@ -281,6 +286,9 @@ void r1_layout(R1Inline& r1, int cout, int B);
 void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch);
 // means finalisation + rank-1 tables as ONE launch (A blocks, then B blocks that wait for them in-launch): s3d_conv.hip
 int launch_rank1_fused(R1Inline& r1, int cout, int B, unsigned* expect, hipStream_t st);
+// how many K slices (1 or 2) the rank-1 tables of a rollout convolution with `cin` own channels are cut into when its consumer is
+// k_conv_wino24s (S3D_RANK1_SLICES=0: never): two from 256 channels on
+int conv_rank1_slices(int cin);
 bool conv_rank1_fused_enabled();          // S3D_RANK1_FUSED=1 (default off: measured slower)
 bool conv_rank1_inline_enabled();         // S3D_RANK1_INLINE=1 (default off: measured slower, profiles/r03_rank1_inline.txt)
 constexpr size_t kSyncWordsBytes = 12 * 32 * 4;   // = kSyncWords * 4 (s3d_rank1.h)

@@ -424,9 +424,16 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     const ConvJob& J = args.job[j];
     int local = bid - J.block_begin;
     R1Block blk;
+    const int nsl = ROLL3 && args.r1_slices > 1 ? args.r1_slices : 1;
+    const int sl = local % nsl; local /= nsl;                 // (the slices of a tile are neighbouring blocks)
     blk.ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
     blk.b = local / J.tiles_per_img; blk.mtile = local % J.tiles_per_img;
-    blk.vin = J.in; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.w; blk.cin = args.cin; blk.cout4 = args.cout; blk.n_tiles_n = J.n_tiles_n;
+    blk.vin = J.in; blk.wgt = J.wgt; blk.L = J.w; blk.cin = args.cin; blk.cout4 = args.cout; blk.n_tiles_n = J.n_tiles_n;
+    blk.out = J.out + size_t(sl) * args.B * J.w * 4 * args.cout;
+    if (nsl > 1) {                                            // two slices: chunks [0, ceil(n/2)) and [ceil(n/2), n)
+        const int nchunks = args.cin / kR1Chunk, first = (nchunks + 1) / 2;
+        blk.chunk0 = sl ? first : 0; blk.nch = sl ? nchunks - first : first;
+    }
     rank1_block<ROLL3, false, false>(blk, lds, []() {});
 }
 
@@ -464,6 +471,10 @@ void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch) {
         if (tables_in_launch) expect[kSyncB + p] += unsigned((r1.job[2 * p].tiles + r1.job[2 * p + 1].tiles) * r1.n_tiles_n * B);
         r1.b_target[p] = expect[kSyncB + p];
     }
+}
+int conv_rank1_slices(int cin) {
+    static const bool on = !(getenv("S3D_RANK1_SLICES") && atoi(getenv("S3D_RANK1_SLICES")) == 0);
+    return on && cin >= 2 * kR1Chunk && cin % kR1Chunk == 0 ? 2 : 1;
 }
 bool conv_rank1_fused_enabled() {
     // default OFF: 22-25 us per launch against 5 + 9.5 us for the two stand-alone kernels (profiles/r03_rank1_inline.txt): an
@@ -508,6 +519,7 @@ __global__ void k_rank1_roll_naive(ConvArgs args) {
 
 int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % KC == 0, S3D_ERR_INVALID, "rank1: bad arguments");
+    S3D_CHECK(a.r1_slices <= 1 || (roll3 && !conv_use_naive() && a.r1_slices == 2 && a.cin % kR1Chunk == 0 && a.cin >= 2 * kR1Chunk), S3D_ERR_INVALID, "rank1: two K slices of whole 128-channel chunks");
     if (conv_use_naive()) {
         if (!roll3) return launch_conv_naive(CONV_1x3_VEC, a, st);
         hipLaunchKernelGGL(k_rank1_roll_naive, dim3(512), dim3(256), 0, st, a);
@@ -520,7 +532,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         J.tiles_x = J.tiles_per_img = (J.w + 31) / 32;
         J.n_tiles_n = roll3 ? (a.cout + 7) / 8 : (a.cout + 31) / 32;
         J.block_begin = blocks;
-        blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+        blocks += J.tiles_per_img * J.n_tiles_n * a.B * (roll3 && a.r1_slices > 1 ? a.r1_slices : 1);
     }
     if (!blocks) return 0;
     // (measured in round 2 and dropped: whole-chunk stages with two chunks of loads in flight, and eight waves per block —

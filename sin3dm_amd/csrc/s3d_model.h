@@ -233,6 +233,15 @@ struct Fwd {
         return launch_gn_finalize(part, x.g, x.C, B, out, st);
     }
 
+    // K slices of the rank-1 tables of the rollout convolution `cw` over the activated tensor y (s3d_rank1.h): 2 when that launch
+    // goes to k_conv_wino24s (the only reader that adds slices), from 256 own channels on; 1 otherwise
+    int r1_slices_for(const Tri& y, const ConvW& cw) const {
+        if (cw.k != 3 || !cw.rollout || conv_use_naive() || conv_rank1_inline_enabled() || conv_rank1_fused_enabled()) return 1;
+        if (cw.wino24[0] == 0 || conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) != 1) return 1;
+        if (!tape && cw.wino44[0] != 0 && m->wino44_current && conv_wino44_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B)) return 1;
+        if (conv_wino24_persistent_enabled()) return 1;
+        return conv_rank1_slices(y.C);
+    }
     // workspace of a rollout convolution's rank-1 terms for the activated tensor y: axis-sum partials, mean vectors, tables
     int roll_buffers(const Tri& y, const ConvW& cw, bool roll, MeanPartials& mp, MeanVecs& mv, const float* rrow[3], const float* rcol[3]) {
         for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
@@ -250,8 +259,9 @@ struct Fwd {
             mp.colpart[p] = ar().alloc<float>(size_t(B) * ntr * w * y.C);
             mv.rowmean[p] = means; means += size_t(B) * h * y.C;
             mv.colmean[p] = means; means += size_t(B) * w * y.C;
-            rrow[p] = ar().alloc<float>(size_t(B) * h * 4 * cw.cout);
-            rcol[p] = ar().alloc<float>(size_t(B) * w * 4 * cw.cout);
+            const int nsl = r1_slices_for(y, cw);           // two K slices when the consumer adds them (k_conv_wino24s)
+            rrow[p] = ar().alloc<float>(size_t(nsl) * B * h * 4 * cw.cout);
+            rcol[p] = ar().alloc<float>(size_t(nsl) * B * w * 4 * cw.cout);
         }
         return 0;
     }
@@ -301,6 +311,7 @@ struct Fwd {
         S3D_TRY(launch_means_finalize(y.g, y.C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = y.C; ca.cout = cw.cout; ca.njobs = 6;
+        ca.r1_slices = r1_slices_for(y, cw);
         // row-varying / column-varying vector of each plane
         const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
         const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
@@ -379,6 +390,7 @@ struct Fwd {
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
         if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
+        ca.r1_slices = rrow && rcol && rrow[0] ? r1_slices_for(y, cw) : 1;
         for (int p = 0; p < 3; ++p) {
             ConvJob& J = ca.job[p];
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = no_bias ? nullptr : m->dev(cw.bias[p]);

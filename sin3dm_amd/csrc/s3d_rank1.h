@@ -111,7 +111,10 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
 // SC1: the vector `vin` was written earlier in THIS launch (stage A): it is read with sc1 loads after `wait()` returns.
 // SC1_OUT: the table is consumed later in THIS launch: it leaves with 16-byte sc1 stores (requires cout % 4 == 0).
 // lds: kR1LdsFloats floats.
-struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; };
+// chunk0 / nch: the 128-channel K chunks this block contracts (0 / 0 = all).  A table may be cut into K SLICES, one per
+// chunk, written by different blocks to out + slice * slice_stride and added by the consuming convolution's epilogue in slice
+// order: the stage chain of a block is then 3 stages whatever the channel count (256-channel layers: 14 -> 9.5 us).
+struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; int chunk0 = 0, nch = 0; };
 
 template <bool ROLL3, bool SC1, bool SC1_OUT, class Wait>
 __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait wait) {
@@ -173,16 +176,17 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
         }
     };
 
-    const int nstages = nchunks * 3;                       // stage s -> chunk = s / 3, tap = s % 3
-    loadB(0, 0);                                           // the weights do not depend on stage A: requested before the wait
+    const int ch0 = J.nch > 0 ? J.chunk0 : 0;
+    const int nstages = (J.nch > 0 ? J.nch : nchunks) * 3; // stage s -> chunk = ch0 + s / 3, tap = s % 3
+    loadB(0, ch0);                                         // the weights do not depend on stage A: requested before the wait
     wait();
-    loadA(0);
+    loadA(ch0);
     storeA(); storeB(0);
     __syncthreads();
     for (int s = 0; s < nstages; ++s) {
-        const int chunk = s / 3, tap = s - chunk * 3;
+        const int chunk = ch0 + s / 3, tap = s - (s / 3) * 3;
         const int ns = s + 1 < nstages ? s + 1 : s;
-        const int nchunk = ns / 3, ntap = ns - nchunk * 3;
+        const int nchunk = ch0 + ns / 3, ntap = ns - (ns / 3) * 3;
         loadB(ntap, nchunk);
         const bool newA = nchunk != chunk;
         if (newA) loadA(nchunk);

@@ -576,28 +576,45 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
     for (int k = 0; k < 4; ++k) { tcol[k] = zero4; trow[k] = zero4; tres[k] = zero4; }
     if (poll_ptr && !sync_wait(poll_ptr, poll_target, poll_seen))
         __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the tables may have been written earlier in this launch by blocks on other XCDs (write-through stores): sc1 loads
-    if (p_rcol) {
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_rcol) + size_t(b) * w * 4 * cout, 0, w * 4 * cout * 4, 0x00020000);
-        if (ty0 > 0 && ty0 + C_TH < h) {
-            const f32x4 v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned(((xc * 4 + 0) * cout + coc) * 4), 0, kAuxSc1));
+    // the tables may have been written earlier in this launch by blocks on other XCDs (write-through stores): sc1 loads.
+    // args.r1_slices == 2: each table is the sum of two K slices (s3d_rank1.h) — both requested now, added behind the barrier
+    const bool two = args.r1_slices == 2;
+    f32x4 tcol2[4], trow2[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tcol[k] = v0;
+    for (int k = 0; k < 4; ++k) { tcol2[k] = zero4; trow2[k] = zero4; }
+    auto tload = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAuxSc1)); };
+    if (p_rcol) {
+        const float* base = p_rcol + size_t(b) * w * 4 * cout;
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, w * 4 * cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * w * 4 * cout : 0)), 0, w * 4 * cout * 4, 0x00020000);
+        if (ty0 > 0 && ty0 + C_TH < h) {
+            const unsigned off = unsigned(((xc * 4 + 0) * cout + coc) * 4);
+            const f32x4 v0 = tload(trs, off);
+            f32x4 v1 = zero4;
+            if (two) v1 = tload(trs2, off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { tcol[k] = v0; tcol2[k] = v1; }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int y = ty0 + rsel * 4 + k;
-                tcol[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned(((xc * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc) * 4), 0, kAuxSc1));
+                const unsigned off = unsigned(((xc * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc) * 4);
+                tcol[k] = tload(trs, off);
+                if (two) tcol2[k] = tload(trs2, off);
             }
         }
     }
     if (p_rrow) {
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p_rrow) + size_t(b) * h * 4 * cout, 0, h * 4 * cout * 4, 0x00020000);
+        const float* base = p_rrow + size_t(b) * h * 4 * cout;
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, h * 4 * cout * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * h * 4 * cout : 0)), 0, h * 4 * cout * 4, 0x00020000);
         const int vx = x_edge_variant(xc, w);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int y = ty0 + rsel * 4 + k;
-            trow[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, unsigned((((y < h ? y : 0) * 4 + vx) * cout + coc) * 4), 0, kAuxSc1));
+            const unsigned off = unsigned((((y < h ? y : 0) * 4 + vx) * cout + coc) * 4);
+            trow[k] = tload(trs, off);
+            if (two) trow2[k] = tload(trs2, off);
         }
     }
     if (p_res) {
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
         const f32x4 ka = *reinterpret_cast<const f32x4*>(sp), kb = *reinterpret_cast<const f32x4*>(sp + C_IMG),
                     kc = *reinterpret_cast<const f32x4*>(sp + 2 * C_IMG);
         const f32x4 sum3 = (yl & 1) ? (ka - kb) - kc : (ka + kb) + kc;
-        const f32x4 v = (sum3 + base4) + ((tcol[k] + trow[k]) + tres[k]);
+        const f32x4 v = (sum3 + base4) + (((tcol[k] + tcol2[k]) + (trow[k] + trow2[k])) + tres[k]);     // (x + 0 = x: one-slice tables add exact zeros)
         if (x_ok && y < h) {
             *reinterpret_cast<f32x4*>(p_out + ((size_t(b) * h + y) * w + x) * cout + co4) = v;
             gs4 += v; gss4 += v * v;
@@ -1221,6 +1238,7 @@ bool conv_wino24_persistent_enabled() {
 // The persistent form takes every launch that has more tiles than slots (each block then owns >= 2 tiles for some blocks);
 // smaller launches are one round of k_conv_wino24s anyway.  Results are bit-identical, so the choice may depend on the batch.
 int launch_conv_wino24p(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.r1_slices <= 1, S3D_ERR_INVALID, "wino24p conv: sliced rank-1 tables are read by k_conv_wino24s only");
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24p conv: bad arguments");
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
@@ -1254,6 +1272,7 @@ long long conv_wino24s_tiles(const ConvArgs& a) {
 bool conv_wino24_takes_persistent(const ConvArgs& a) { return conv_wino24_persistent_enabled() && conv_wino24s_tiles(a) > conv_slots(); }
 
 int launch_conv_wino24(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.r1_slices <= 1, S3D_ERR_INVALID, "wino24 conv: sliced rank-1 tables are read by k_conv_wino24s only");
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % X_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24 conv: bad arguments");
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {

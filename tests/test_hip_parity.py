@@ -616,3 +616,28 @@ def test_config1_towerruins64_ddim10_whole_run(oracle):
             x, _ = tp_ddim(out, x, tab, i)
     assert relerr(got.cpu().numpy(), x.numpy()) < TOL_FWD
     assert float(got[..., H:, W:].abs().max()) == 0.0
+
+
+def test_rank1_table_slices_agree_with_the_unsliced_tables(tmp_path):
+    """From 256 own channels on, the rank-1 rollout tables (unet_triplane.py:37-58) are built as two K slices by twice as many
+    k_rank1 blocks with half the stage chain each, and k_conv_wino24s adds the slices in its epilogue (s3d_rank1.h).  Only the
+    order of one fp32 addition changes: the 128-channel cases (256- and 384-channel rollout inputs) against S3D_RANK1_SLICES=0 in
+    a separate process, to 2e-6 of the output's scale — and the sliced default keeps its golden / oracle gates elsewhere."""
+    import os, subprocess, sys
+    cases = [c for c in R1_CASES if c[0] == 128]
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import test_hip_parity as tp\n"
+        "for i, (mc, B, hwd) in enumerate([c for c in tp.R1_CASES if c[0] == 128]):\n"
+        "    y, name = tp._r1_forward(mc, B, hwd, 90 + i)\n"
+        f"    np.save(r'{tmp_path}/sl_' + str(i) + '.npy', y)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_SLICES="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for i, (mc, B, hwd) in enumerate(cases):
+        y, _ = _r1_forward(mc, B, hwd, 90 + i)
+        want = np.load(f"{tmp_path}/sl_{i}.npy")
+        assert relerr(y, want) < 2e-6, (mc, B, hwd, relerr(y, want))
