@@ -206,7 +206,10 @@ def test_torch_optimizer_also_works():
                                       (64, (92, 128, 92), 1)])         # the last one is BASELINE config 4's towerruins size
 def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
     """Wider models (2 and 4 channels per GroupNorm group, 64-wide MFMA tiles with several K slices) against the
-    CPU oracle's autograd (oracle/torch_port.py, itself pinned to the reference's gradients)."""
+    CPU oracle's autograd (oracle/torch_port.py, itself pinned to the reference's gradients).  The towerruins-size case runs at
+    batch 1 — BASELINE config 4's per-GPU batch is 4 — because the CPU oracle's autograd at that size costs ~20 s per sample;
+    every kernel of the step is batch-parallel over independent samples (GroupNorm statistics and rollout means are per sample),
+    tools/bench_train.py times the real batch of 4, and test_full_size_directional_derivative runs batch 2."""
     import torch
     import torch_port as tp
     H, W, D = hwd
@@ -233,7 +236,8 @@ def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
 
 
 def test_full_size_directional_derivative():
-    """BASELINE config 4 per GPU (64-ch UNet, towerruins (92,128,92), batch 2 here): the gradient of the whole step agrees
+    """BASELINE config 4 per GPU (64-ch UNet, towerruins (92,128,92); batch 2 here where the config's per-GPU batch is 4 — three
+    loss evaluations + one backward at this size per test; the step is batch-parallel): the gradient of the whole step agrees
     with a central finite difference of the loss along a random parameter direction — a size-independent check that
     needs no reference output."""
     import torch
