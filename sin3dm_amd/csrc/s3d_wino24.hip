@@ -536,22 +536,37 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
     unsigned poll_seen = poll_target;
     W24_STAMP(2)
     __builtin_amdgcn_s_setprio(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int cn1 = chunk + 1 < nchunks ? chunk + 1 : nchunks - 1;
+    for (int chunk = 0; chunk < nchunks - 1; ++chunk) {
+        const int cn1 = chunk + 1;
         const int cn2 = chunk + 2 < nchunks ? chunk + 2 : nchunks - 1;
-        if (poll_ptr && chunk == nchunks - 1) poll_seen = sync_load(poll_ptr);
         C_STEP(0)
         C_STEP(1)
         cur ^= tog;
     }
-#undef C_STEP
-#undef C_GROUP
-#undef C_COMB
-#undef C_LDS4
-#undef C_PIN
-#undef W24_PRICE_GNSILU
-    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
-    W24_STAMP(3)
+    // The last chunk is peeled (round 3): it has no successor to fetch, and its second step has no operands to build — the
+    // registers and issue slots that frees carry the EPILOGUE's residual request (the operand that comes from HBM / the MALL),
+    // which used to go out only after the last MFMA and was waited for behind the share-image barrier; the rank-1 tables
+    // (L2-hot, written by the launch before) are still requested after the loop: all of them early spills 32 registers.
+    if (poll_ptr) poll_seen = sync_load(poll_ptr);
+    {
+        const int chunk = nchunks - 1;
+        const int step = chunk * 2, nstep = step + 1;
+        const int rx = ax1 + cur, ry = ay1 + cur;
+        f32x4 cx0, cy0, cx1, cy1, t0, t1, t2, t3, t4, t5, s1, s2, s3, s4, v5n;
+        C_GROUP(0, 0, cx0 = C_LDS4(rx); cy0 = C_LDS4(ry); cx1 = C_LDS4(rx + C_LD * 4); cy1 = C_LDS4(ry + C_LD * 4);)
+        C_GROUP(0, 1, C_COMB(t0, cx0, cy0) C_COMB(t1, cx1, cy1))
+        C_GROUP(1, 0, cx0 = C_LDS4(rx + 2 * C_LD * 4); cy0 = C_LDS4(ry + 2 * C_LD * 4); cx1 = C_LDS4(rx + 3 * C_LD * 4); cy1 = C_LDS4(ry + 3 * C_LD * 4);)
+        C_GROUP(1, 1, C_COMB(t2, cx0, cy0) C_COMB(t3, cx1, cy1))
+        C_GROUP(2, 0, cx0 = C_LDS4(rx + 4 * C_LD * 4); cy0 = C_LDS4(ry + 4 * C_LD * 4); cx1 = C_LDS4(rx + 5 * C_LD * 4); cy1 = C_LDS4(ry + 5 * C_LD * 4);)
+        C_GROUP(2, 1, C_COMB(t4, cx0, cy0) C_COMB(t5, cx1, cy1))
+        C_GROUP(3, 0, s1 = t4 - 4.f * t2; C_PIN(s1); s2 = t3 - 4.f * t1; C_PIN(s2); V[1] = s1 + s2; C_PIN(V[1]); V[2] = s1 - s2; C_PIN(V[2]);)
+        C_GROUP(3, 1, V[0] = 4.f * t0 + (t4 - 5.f * t2); C_PIN(V[0]); s3 = t4 - t2; C_PIN(s3); s4 = t3 - t1; C_PIN(s4);)
+        C_GROUP(4, 0, V[3] = s3 + 2.f * s4; C_PIN(V[3]);)
+        C_GROUP(4, 1, v5n = 4.f * t1 + (t5 - 5.f * t3); C_PIN(v5n);)
+        C_GROUP(5, 0, V[4] = s3 - 2.f * s4; C_PIN(V[4]);)
+        C_GROUP(5, 1, ;)
+        V[5] = v5n;
+    }
     // ---- epilogue: as k_conv_wino24; lane (g, t16) holds output channel nb*16 + t16 of the tiles (tile row g, tile column r)
     const float* __restrict__ p_bias = J.bias;
     const float* __restrict__ p_bbias = J.bbias;
@@ -583,47 +598,65 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #pragma unroll
     for (int k = 0; k < 4; ++k) { tcol2[k] = zero4; trow2[k] = zero4; }
     auto tload = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAuxSc1)); };
-    if (p_rcol) {
-        const float* base = p_rcol + size_t(b) * w * 4 * cout;
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, w * 4 * cout * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * w * 4 * cout : 0)), 0, w * 4 * cout * 4, 0x00020000);
-        if (ty0 > 0 && ty0 + C_TH < h) {
-            const unsigned off = unsigned(((xc * 4 + 0) * cout + coc) * 4);
-            const f32x4 v0 = tload(trs, off);
-            f32x4 v1 = zero4;
-            if (two) v1 = tload(trs2, off);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { tcol[k] = v0; tcol2[k] = v1; }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int y = ty0 + rsel * 4 + k;
-                const unsigned off = unsigned(((xc * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc) * 4);
-                tcol[k] = tload(trs, off);
-                if (two) tcol2[k] = tload(trs2, off);
+    auto request_tables = [&]() {
+        if (p_rcol) {
+            const float* base = p_rcol + size_t(b) * w * 4 * cout;
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, w * 4 * cout * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * w * 4 * cout : 0)), 0, w * 4 * cout * 4, 0x00020000);
+            if (ty0 > 0 && ty0 + C_TH < h) {
+                const unsigned off = unsigned(((xc * 4 + 0) * cout + coc) * 4);
+                const f32x4 v0 = tload(trs, off);
+                f32x4 v1 = zero4;
+                if (two) v1 = tload(trs2, off);
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) { tcol[k] = v0; tcol2[k] = v1; }
+            } else {
+    #pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int y = ty0 + rsel * 4 + k;
+                    const unsigned off = unsigned(((xc * 4 + x_edge_variant(y < h ? y : 0, h)) * cout + coc) * 4);
+                    tcol[k] = tload(trs, off);
+                    if (two) tcol2[k] = tload(trs2, off);
+                }
             }
         }
-    }
-    if (p_rrow) {
-        const float* base = p_rrow + size_t(b) * h * 4 * cout;
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, h * 4 * cout * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * h * 4 * cout : 0)), 0, h * 4 * cout * 4, 0x00020000);
-        const int vx = x_edge_variant(xc, w);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int y = ty0 + rsel * 4 + k;
-            const unsigned off = unsigned((((y < h ? y : 0) * 4 + vx) * cout + coc) * 4);
-            trow[k] = tload(trs, off);
-            if (two) trow2[k] = tload(trs2, off);
+        if (p_rrow) {
+            const float* base = p_rrow + size_t(b) * h * 4 * cout;
+            const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, h * 4 * cout * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t trs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (two ? size_t(args.B) * h * 4 * cout : 0)), 0, h * 4 * cout * 4, 0x00020000);
+            const int vx = x_edge_variant(xc, w);
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                const unsigned off = unsigned((((y < h ? y : 0) * 4 + vx) * cout + coc) * 4);
+                trow[k] = tload(trs, off);
+                if (two) trow2[k] = tload(trs2, off);
+            }
         }
-    }
-    if (p_res) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int y = ty0 + rsel * 4 + k;
-            tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+    };
+    auto request_residual = [&]() {
+        if (p_res) {
+    #pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = ty0 + rsel * 4 + k;
+                tres[k] = *reinterpret_cast<const f32x4*>(p_res + ((size_t(b) * h + (y < h ? y : 0)) * w + xc) * cout + coc);
+            }
         }
+    };
+    {   // the tile's last k-step: MFMAs only; the operand requests go out behind its first groups
+        const int step = (nchunks - 1) * 2 + 1, nstep = step;
+        C_GROUP(0, 0, ;) C_GROUP(0, 1, request_residual();) C_GROUP(1, 0, ;) C_GROUP(1, 1, ;) C_GROUP(2, 0, ;) C_GROUP(2, 1, ;)
+        C_GROUP(3, 0, ;) C_GROUP(3, 1, ;) C_GROUP(4, 0, ;) C_GROUP(4, 1, ;) C_GROUP(5, 0, ;) C_GROUP(5, 1, ;)
     }
+#undef C_STEP
+#undef C_GROUP
+#undef C_COMB
+#undef C_LDS4
+#undef C_PIN
+#undef W24_PRICE_GNSILU
+    if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
+    W24_STAMP(3)
+    request_tables();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                     // all patch reads and halo stores of the last step are done
     {

@@ -159,32 +159,37 @@ def _r1_forward(mc, B, hwd, seed):
     ("S3D_WINO24_PERSIST", "1", "k_conv_wino24p", "k_conv_wino24s"),
     ("S3D_RANK1_FUSED", "1", "k_conv_wino24s", "k_conv_wino24s")])
 def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, value, other, default):
-    """Two forms of the 3x3 launch that do the same arithmetic in the same order, each against the default in a separate
-    process (the switches are read once): S3D_RANK1_INLINE=1 — the rollout's means + rank-1 tables (unet_triplane.py:37-58) as
-    producer blocks INSIDE the convolution launch (s3d_rank1.h); S3D_WINO24_PERSIST=1 — persistent blocks that walk several
-    tiles (k_conv_wino24p) instead of one tile per block (k_conv_wino24s).  Both were measured slower and are off by default
-    (profiles/r03_rank1_inline.txt, r03_wino_persistent.txt); they stay tested.  S3D_RANK1_FUSED=1 — means finalisation and
-    rank-1 tables as one launch with an in-launch hand-off (k_rank1_fused) instead of two launches: slower too, same status.  Outputs are bit-identical, repeated calls agree, no hand-off ever
-    timed out, and the library reports which kernel ran in either process (the last case has more tiles than slots)."""
+    """Forms of the 3x3 launch / its rollout tables that do the same arithmetic in the same order, each against the plain form in
+    separate processes (the switches are read once): S3D_RANK1_INLINE=1 — the rollout's means + rank-1 tables
+    (unet_triplane.py:37-58) as producer blocks INSIDE the convolution launch (s3d_rank1.h); S3D_WINO24_PERSIST=1 — persistent
+    blocks that walk several tiles (k_conv_wino24p) instead of one tile per block (k_conv_wino24s); S3D_RANK1_FUSED=1 — means
+    finalisation and rank-1 tables as one launch with an in-launch hand-off (k_rank1_fused).  All three were measured slower and
+    are off by default (profiles/r03_rank1_inline.txt, r03_wino_persistent.txt); they stay tested.  Both processes run with
+    S3D_RANK1_SLICES=0: the default's two-slice tables (a different order of one addition) are only built for the plain form.
+    Outputs are bit-identical, repeated calls agree, no hand-off ever timed out, and the library reports which kernel ran (the
+    last two cases have more tiles than slots)."""
     import os, subprocess, sys
-    code = (
-        "import numpy as np, sys\n"
-        "sys.path.insert(0, 'tests')\n"
-        "import test_hip_parity as tp\n"
-        "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
-        "    y, name = tp._r1_forward(mc, B, hwd, 70 + i)\n"
-        f"    assert i < 3 or {other!r} in name, name\n"
-        f"    np.save(r'{tmp_path}/r1_' + str(i) + '.npy', y)\n"
-        "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, **{switch: value}), capture_output=True,
-                       text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+    def run(tag, env, expect):
+        code = (
+            "import numpy as np, sys\n"
+            "sys.path.insert(0, 'tests')\n"
+            "import test_hip_parity as tp\n"
+            "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
+            "    y, name = tp._r1_forward(mc, B, hwd, 70 + i)\n"
+            f"    assert i < 3 or {expect!r} in name, name\n"
+            f"    np.save(r'{tmp_path}/{tag}_' + str(i) + '.npy', y)\n"
+            "print('ok')\n")
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_SLICES="0", **env),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+    run("plain", {}, default)
+    run("form", {switch: value}, other)
     for i, (mc, B, hwd) in enumerate(R1_CASES):
-        y, name = _r1_forward(mc, B, hwd, 70 + i)
-        assert "producer" not in name and (i < 3 or default in name), name
-        want = np.load(f"{tmp_path}/r1_{i}.npy")
-        assert np.array_equal(y, want), (mc, B, hwd, float(np.abs(y - want).max()))
+        a, b = np.load(f"{tmp_path}/plain_{i}.npy"), np.load(f"{tmp_path}/form_{i}.npy")
+        assert np.array_equal(a, b), (mc, B, hwd, float(np.abs(a - b).max()))
 
 
 def test_unet_forward_vs_oracle_towerruins64(oracle):
