@@ -394,16 +394,27 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
     const float* inb = J.in + size_t(b) * h * w * cin;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, h * w * cin * 4, 0x00020000);
+    // (round 3) the first weight fragments leave before the halo addressing is worked out, and that addressing avoids the
+    // quarter-rate 32-bit multiplies: the byte offset of a halo item is two 24-bit multiply-adds with wave-uniform strides (the
+    // launcher guarantees a plane below 2 GiB, so row stride < 2^24 holds for every supported shape) and pix / 18 is a
+    // multiply-shift, exact for the 180 pixels of a halo
+    f32x4 ring[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) { ring[s] = wfrag(0, s); __builtin_amdgcn_sched_barrier(0); }
     unsigned goff[C_ITEMS_PT];
     int loff[C_ITEMS_PT];
+    const unsigned rowstride = unsigned(w) * unsigned(cin) * 4u, pixstride = unsigned(cin) * 4u;
+    const bool small_strides = rowstride < (1u << 24) && h < (1 << 24);
 #pragma unroll
     for (int it = 0; it < C_ITEMS_PT; ++it) {
         const int item = it * 256 + tid;
         const int pix = item >> 3, q = item & 7;
-        const int hy = pix / C_HW, hx = pix - hy * C_HW;
+        const int hy = (pix * 57) >> 10, hx = pix - hy * C_HW;             // pix / 18 for pix < 192
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
         const bool ok = item < C_ITEMS && gy >= 0 && gy < h && gx >= 0 && gx < w;
-        goff[it] = ok ? unsigned((gy * w + gx) * cin + q * 4) * 4u : 0x80000000u;
+        const unsigned off = small_strides ? __umul24(unsigned(gy), rowstride) + __umul24(unsigned(gx), pixstride) + unsigned(q) * 16u
+                                           : unsigned((gy * w + gx) * cin + q * 4) * 4u;
+        goff[it] = ok ? off : 0x80000000u;
         loff[it] = pix * C_LD + ((q ^ (((hy >> 1) & 3) << 1)) << 2);
     }
     const bool last_ok = (C_ITEMS_PT - 1) * 256 + tid < C_ITEMS;
@@ -421,9 +432,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
         for (int nb = 0; nb < 2; ++nb) acc[f][nb] = zero4;
 
     const int nchunks = cin / C_KC;
-    f32x4 V[6], ring[6];
-#pragma unroll
-    for (int s = 0; s < 6; ++s) { ring[s] = wfrag(0, s); __builtin_amdgcn_sched_barrier(0); }
+    f32x4 V[6];
     // chunk 0 into buffer 0, then the barrier; the first half of chunk 1 is requested with it but lands in buffer 1 only
     // after the first operands are built (the barrier of step (0,0) publishes it): it is off the prologue's critical path
     f32x4 pre[3];
