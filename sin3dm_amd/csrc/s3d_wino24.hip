@@ -490,12 +490,13 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #define W24_PRICE_GNSILU
 #endif
     // One k-step (16 channels) = 12 groups {four MFMAs on one A operand + a piece of the other work}, pinned.
+#define C_HAS_NEXT 1                                  /* 0 in a tile's last k-step: no next step's weight fragments to request */
 #define C_GROUP(F, NB, WORK)                                                                                          \
     {                                                                                                                 \
         constexpr int s_ = 2 * (F) + (NB);                                                                            \
         const f32x4 bq = ring[s_ % 6];                                                                                \
         acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][0], bq[0], acc[F][NB], 0, 0, 0);                       \
-        ring[s_ % 6] = s_ + 6 < 12 ? wfrag(step, s_ + 6) : wfrag(nstep, s_ - 6);                                      \
+        if (s_ + 6 < 12) ring[s_ % 6] = wfrag(step, s_ + 6); else if (C_HAS_NEXT) ring[s_ % 6] = wfrag(nstep, s_ - 6);     \
         acc[F][NB] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[F][1], bq[1], acc[F][NB], 0, 0, 0);                       \
         __builtin_amdgcn_sched_barrier(0);                                                                            \
         WORK                                                                                                          \
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #pragma unroll
     for (int k = 0; k < 4; ++k) { tcol2[k] = zero4; trow2[k] = zero4; }
     auto tload = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, kAuxSc1)); };
-    auto request_tables = [&]() {
+    auto request_col_tables = [&]() {
         if (p_rcol) {
             const float* base = p_rcol + size_t(b) * w * 4 * cout;
             const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, w * 4 * cout * 4, 0x00020000);
@@ -629,6 +630,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
                 }
             }
         }
+    };
+    auto request_row_tables = [&]() {
         if (p_rrow) {
             const float* base = p_rrow + size_t(b) * h * 4 * cout;
             const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, h * 4 * cout * 4, 0x00020000);
@@ -652,11 +655,14 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
             }
         }
     };
+#undef C_HAS_NEXT
+#define C_HAS_NEXT 0
     {   // the tile's last k-step: MFMAs only; the operand requests go out behind its first groups
-        const int step = (nchunks - 1) * 2 + 1, nstep = step;
+        const int step = (nchunks - 1) * 2 + 1, nstep = step; (void)nstep;
         C_GROUP(0, 0, ;) C_GROUP(0, 1, request_residual();) C_GROUP(1, 0, ;) C_GROUP(1, 1, ;) C_GROUP(2, 0, ;) C_GROUP(2, 1, ;)
         C_GROUP(3, 0, ;) C_GROUP(3, 1, ;) C_GROUP(4, 0, ;) C_GROUP(4, 1, ;) C_GROUP(5, 0, ;) C_GROUP(5, 1, ;)
     }
+#undef C_HAS_NEXT
 #undef C_STEP
 #undef C_GROUP
 #undef C_COMB
@@ -665,7 +671,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 #undef W24_PRICE_GNSILU
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
     W24_STAMP(3)
-    request_tables();
+    request_row_tables();                                // (requesting the row tables a k-step early as well measured the same)
+    request_col_tables();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();                                     // all patch reads and halo stores of the last step are done
     {
