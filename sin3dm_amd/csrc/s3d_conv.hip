@@ -414,9 +414,13 @@ __global__ void k_conv_naive(ConvArgs args, int KH, int KW) {
 // products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
 // 8 output channels = 24 weight rows (a quarter fewer weight bytes than four pre-summed variants: the kernel is bound by
 // streaming them once) — and the variants are formed while the four waves' partials are added.
-template <bool ROLL3>
+// NS = 2 (batch > 1): a block takes two samples of its (position tile, column tile) and stages each weight tile once for both
+// (s3d_rank1.h); 69.7 KB of dynamic LDS, two blocks per CU.
+template <bool ROLL3, int NS = 1>
 __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
-    __shared__ __attribute__((aligned(16))) float lds[kR1LdsFloats];
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];          // NS = 2: kR1LdsFloats + 34 * kR1Ld floats
+    __shared__ __attribute__((aligned(16))) float lds_static[NS == 1 ? kR1LdsFloats : 4];
+    float* lds = NS == 1 ? lds_static : lds_dyn;
     const int bid = blockIdx.x;
     int j = 0;                                             // independent kernarg loads (a while loop chains up to five of them)
 #pragma unroll
@@ -427,14 +431,15 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     const int nsl = ROLL3 && args.r1_slices > 1 ? args.r1_slices : 1;
     const int sl = local % nsl; local /= nsl;                 // (the slices of a tile are neighbouring blocks)
     blk.ntile = local % J.n_tiles_n; local /= J.n_tiles_n;
-    blk.b = local / J.tiles_per_img; blk.mtile = local % J.tiles_per_img;
+    blk.b = (local / J.tiles_per_img) * NS; blk.mtile = local % J.tiles_per_img;
+    blk.bcount = min(NS, args.B - blk.b);
     blk.vin = J.in; blk.wgt = J.wgt; blk.L = J.w; blk.cin = args.cin; blk.cout4 = args.cout; blk.n_tiles_n = J.n_tiles_n;
     blk.out = J.out + size_t(sl) * args.B * J.w * 4 * args.cout;
     if (nsl > 1) {                                            // two slices: chunks [0, ceil(n/2)) and [ceil(n/2), n)
         const int nchunks = args.cin / kR1Chunk, first = (nchunks + 1) / 2;
         blk.chunk0 = sl ? first : 0; blk.nch = sl ? nchunks - first : first;
     }
-    rank1_block<ROLL3, false, false>(blk, lds, []() {});
+    rank1_block<ROLL3, false, false, NS>(blk, lds, []() {});
 }
 
 // means finalisation + rank-1 tables in ONE launch: the A blocks (lowest ids, dispatched first) finalize the six mean vectors
@@ -526,20 +531,28 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         S3D_HIP(hipGetLastError());
         return 0;
     }
+    // two samples per block from batch 2 on (S3D_RANK1_BATCH=0: one): same sums per sample, the weight tiles staged half as often
+    static const bool pair_ok = !(getenv("S3D_RANK1_BATCH") && atoi(getenv("S3D_RANK1_BATCH")) == 0);
+    const int ns = roll3 && pair_ok && a.B >= 2 ? 2 : 1;
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
         ConvJob& J = a.job[j];
         J.tiles_x = J.tiles_per_img = (J.w + 31) / 32;
         J.n_tiles_n = roll3 ? (a.cout + 7) / 8 : (a.cout + 31) / 32;
         J.block_begin = blocks;
-        blocks += J.tiles_per_img * J.n_tiles_n * a.B * (roll3 && a.r1_slices > 1 ? a.r1_slices : 1);
+        blocks += J.tiles_per_img * J.n_tiles_n * ((a.B + ns - 1) / ns) * (roll3 && a.r1_slices > 1 ? a.r1_slices : 1);
     }
     if (!blocks) return 0;
     // (measured in round 2 and dropped: whole-chunk stages with two chunks of loads in flight, and eight waves per block —
     // 9.4 / 14.7 / 18.7 us at 128 / 256 / 384 channels either way: the launch is bound by the ~21 MB per 128-channel chunk that
     // 384 blocks pull through L2 at once, not by its stage latency or its MFMA chains)
     conv_note_kernel(roll3 ? "k_rank1<true> (three-tap rollout tables)" : "k_rank1<false>");
-    if (roll3) hipLaunchKernelGGL(k_rank1<true>, dim3(blocks), dim3(256), 0, st, a);
+    constexpr size_t lds1 = kR1LdsFloats * sizeof(float), lds2 = lds1 + 34 * kR1Ld * sizeof(float);
+    if (ns == 2) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank1<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds2));
+        S3D_HIP(attr);
+        hipLaunchKernelGGL((k_rank1<true, 2>), dim3(blocks), dim3(256), lds2, st, a);
+    } else if (roll3) hipLaunchKernelGGL(k_rank1<true>, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_rank1<false>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;

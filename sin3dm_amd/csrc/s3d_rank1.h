@@ -114,12 +114,17 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
 // chunk0 / nch: the 128-channel K chunks this block contracts (0 / 0 = all).  A table may be cut into K SLICES, one per
 // chunk, written by different blocks to out + slice * slice_stride and added by the consuming convolution's epilogue in slice
 // order: the stage chain of a block is then 3 stages whatever the channel count (256-channel layers: 14 -> 9.5 us).
-struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; int chunk0 = 0, nch = 0; };
+// NS (1 / 2) samples per block, b .. b + bcount - 1: the weight tile of a stage is staged once and contracted with each
+// sample's vector tile (batch > 1: a stage's bytes per sample drop from 23 to 14.5 KB); every sample's sums are formed in the
+// same order as with NS = 1.  lds: kR1LdsFloats + (NS - 1) * 34 * kR1Ld floats.
+struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; int chunk0 = 0, nch = 0; int bcount = 1; };
 
-template <bool ROLL3, bool SC1, bool SC1_OUT, class Wait>
+template <bool ROLL3, bool SC1, bool SC1_OUT, int NS = 1, class Wait>
 __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait wait) {
+    static_assert(NS == 1 || (!SC1 && !SC1_OUT), "the in-launch producers take one sample per block");
+    constexpr int kATile = 34 * kR1Ld;
     float* sA = lds;
-    float* sB0 = lds + 34 * kR1Ld;
+    float* sB0 = lds + NS * kATile;
     const int L = J.L, cin = J.cin, cout4 = J.cout4, mtile = J.mtile, ntile = J.ntile, b = J.b;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i = lane & 31, half = lane >> 5;
     const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
@@ -128,25 +133,29 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
     const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, L * cin * 4, 0x00020000);
     const size_t tapStride = ROLL3 ? size_t(J.n_tiles_n) * 24 * cin : size_t(cout4) * cin;
     const r1_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    r1_f32x16 acc;
+    r1_f32x16 acc[NS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     // staging items: A has 34 rows (positions mtile*32-1 .. +32), B 32 rows (columns ntile*32 ..); <= 5 + 4 float4 each
     constexpr int NA = (34 * (kR1Chunk / 4) + 255) / 256, NB = (32 * (kR1Chunk / 4) + 255) / 256;
-    r1_f32x4 ra[NA], rb[NB];
+    r1_f32x4 ra[NS][NA], rb[NB];
     auto loadA = [&](int chunk) {
         const int c0 = chunk * kR1Chunk, wq = (min(cin - c0, kR1Chunk)) / 4;
+#pragma unroll
+        for (int n = 0; n < NS; ++n)
 #pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
             const int pos = mtile * 32 - 1 + row;
-            const bool ok = row < 34 && pos >= 0 && pos < L && q < wq;
+            const bool ok = row < 34 && pos >= 0 && pos < L && q < wq && n < J.bcount;
             if (SC1) {                                      // out-of-range offset: the hardware returns zeros
-                ra[it] = __builtin_bit_cast(r1_f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, ok ? unsigned((pos * cin + c0 + q * 4) * 4) : 0x80000000u, 0, kAuxSc1));
+                ra[n][it] = __builtin_bit_cast(r1_f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, ok ? unsigned((pos * cin + c0 + q * 4) * 4) : 0x80000000u, 0, kAuxSc1));
             } else {
-                ra[it] = ((r1_gf4ptr)(uintptr_t)(vb + size_t(ok ? pos : 0) * cin + c0 + (ok ? q : 0) * 4))[0];
-                if (!ok) ra[it] = zero4;
+                ra[n][it] = ((r1_gf4ptr)(uintptr_t)(vb + (size_t(ok ? n : 0) * L + (ok ? pos : 0)) * cin + c0 + (ok ? q : 0) * 4))[0];
+                if (!ok) ra[n][it] = zero4;
             }
         }
     };
@@ -163,9 +172,11 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
     };
     auto storeA = [&]() {
 #pragma unroll
+        for (int n = 0; n < NS; ++n)
+#pragma unroll
         for (int it = 0; it < NA; ++it) {
             const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
-            if (row < 34) *reinterpret_cast<r1_f32x4*>(sA + row * kR1Ld + q * 4) = ra[it];
+            if (row < 34) *reinterpret_cast<r1_f32x4*>(sA + n * kATile + row * kR1Ld + q * 4) = ra[n][it];
         }
     };
     auto storeB = [&](int buf) {
@@ -197,10 +208,13 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
         const int k8n = min(cin - chunk * kR1Chunk, kR1Chunk) / 32;
         for (int k8 = 0; k8 < k8n; ++k8) {
             const int c = (wid * k8n + k8) * 8;
-            const r1_f32x4 a4 = *reinterpret_cast<const r1_f32x4*>(Ar + c);
             const r1_f32x4 b4 = *reinterpret_cast<const r1_f32x4*>(Br + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc, 0, 0, 0);
+            for (int n = 0; n < NS; ++n) {
+                const r1_f32x4 a4 = *reinterpret_cast<const r1_f32x4*>(Ar + n * kATile + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[n], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (newA) __syncthreads();                          // everyone is done reading the old A tile
@@ -208,46 +222,54 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
         if (newA) storeA();
         __syncthreads();
     }
-    // add the four waves' partials (reuse the B tiles as [4][16][64] floats = 16 KB)
-    float* red = sB0;
+    // add the four waves' partials (reuse the B tiles as [NS][4][16][64] floats = 16 KB per sample)
+    float* red0 = sB0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(wid * 16 + r) * 64 + lane] = acc[r];
+    for (int n = 0; n < NS; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red0[n * 4096 + (wid * 16 + r) * 64 + lane] = acc[n][r];
     __syncthreads();
-    if (ROLL3) {
-        // MFMA row p sits in register (p&3) + 4*(p>>3) of lane half (p>>2)&1
-        auto usum = [&](int p, int c8, int o) {
-            const int r = (p & 3) + 4 * (p >> 3), l = ((p >> 2) & 1) * 32 + o * 8 + c8;
-            return red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-        };
-        if (SC1_OUT) {
-            // thread = (position, variant, channel quad of the block's eight): one 16-byte write-through store each
-            const int p = tid >> 3, var = (tid >> 1) & 3, c4 = (tid & 1) * 4;
-            const int row = mtile * 32 + p, co = ntile * 8 + c4;
-            r1_f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u0 = usum(p, c4 + e, 0), u1 = usum(p, c4 + e, 1), u2 = usum(p, c4 + e, 2);
-                v[e] = var == 0 ? (u0 + u1) + u2 : (var == 1 ? u1 + u2 : (var == 2 ? u0 + u1 : u1));
+    for (int n = 0; n < NS; ++n) {
+        if (n >= J.bcount) break;
+        const float* red = red0 + n * 4096;
+        const int bs = b + n;
+        if (ROLL3) {
+            // MFMA row p sits in register (p&3) + 4*(p>>3) of lane half (p>>2)&1
+            auto usum = [&](int p, int c8, int o) {
+                const int r = (p & 3) + 4 * (p >> 3), l = ((p >> 2) & 1) * 32 + o * 8 + c8;
+                return red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+            };
+            if (SC1_OUT) {
+                // thread = (position, variant, channel quad of the block's eight): one 16-byte write-through store each
+                const int p = tid >> 3, var = (tid >> 1) & 3, c4 = (tid & 1) * 4;
+                const int row = mtile * 32 + p, co = ntile * 8 + c4;
+                r1_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u0 = usum(p, c4 + e, 0), u1 = usum(p, c4 + e, 1), u2 = usum(p, c4 + e, 2);
+                    v[e] = var == 0 ? (u0 + u1) + u2 : (var == 1 ? u1 + u2 : (var == 2 ? u0 + u1 : u1));
+                }
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J.out + size_t(bs) * L * 4 * cout4, 0, L * 4 * cout4 * 4, 0x00020000);
+                if (row < L && co < cout4)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v), rs, unsigned(((row * 4 + var) * cout4 + co) * 4), 0, kAuxSc1);
+                continue;
             }
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J.out + size_t(b) * L * 4 * cout4, 0, L * 4 * cout4 * 4, 0x00020000);
-            if (row < L && co < cout4)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v), rs, unsigned(((row * 4 + var) * cout4 + co) * 4), 0, kAuxSc1);
-            return;
+            const int p = tid >> 3, c8 = tid & 7;
+            const float u0 = usum(p, c8, 0), u1 = usum(p, c8, 1), u2 = usum(p, c8, 2);
+            const int row = mtile * 32 + p, co = ntile * 8 + c8;
+            if (row < L && co < cout4) {
+                float* o4 = J.out + (size_t(bs) * L + row) * 4 * cout4 + co;      // [pos][variant][cout]
+                o4[0] = (u0 + u1) + u2; o4[cout4] = u1 + u2; o4[2 * cout4] = u0 + u1; o4[3 * cout4] = u1;
+            }
+            continue;
         }
-        const int p = tid >> 3, c8 = tid & 7;
-        const float u0 = usum(p, c8, 0), u1 = usum(p, c8, 1), u2 = usum(p, c8, 2);
-        const int row = mtile * 32 + p, co = ntile * 8 + c8;
-        if (row < L && co < cout4) {
-            float* o4 = J.out + (size_t(b) * L + row) * 4 * cout4 + co;      // [pos][variant][cout]
-            o4[0] = (u0 + u1) + u2; o4[cout4] = u1 + u2; o4[2 * cout4] = u0 + u1; o4[3 * cout4] = u1;
+        for (int it = tid; it < 1024; it += 256) {
+            const int r = it >> 6, l = it & 63;
+            const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
+            const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
+            if (row < L && col < cout4) J.out[(size_t(bs) * L + row) * cout4 + col] = v;
         }
-        return;
-    }
-    for (int it = tid; it < 1024; it += 256) {
-        const int r = it >> 6, l = it & 63;
-        const float v = red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
-        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = ntile * 32 + (l & 31);
-        if (row < L && col < cout4) J.out[(size_t(b) * L + row) * cout4 + col] = v;
     }
 }
 

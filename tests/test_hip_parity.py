@@ -192,6 +192,30 @@ def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, va
         assert np.array_equal(a, b), (mc, B, hwd, float(np.abs(a - b).max()))
 
 
+def test_rank1_sample_pairs_are_bit_identical(tmp_path):
+    """Batch >= 2: a k_rank1 block builds the rollout tables (unet_triplane.py:37-58) of TWO samples per staged weight tile
+    (s3d_rank1.h, NS = 2; an odd batch leaves a one-sample block).  Each sample's sums are formed in the same order as with one
+    sample per block: the default against S3D_RANK1_BATCH=0 in a separate process, K slices on in both, bit for bit."""
+    import os, subprocess, sys
+    cases = [(i, c) for i, c in enumerate(R1_CASES) if c[1] >= 2]
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "import test_hip_parity as tp\n"
+        "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
+        "    if B < 2: continue\n"
+        "    y, name = tp._r1_forward(mc, B, hwd, 110 + i)\n"
+        f"    np.save(r'{tmp_path}/one_' + str(i) + '.npy', y)\n"
+        "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_BATCH="0"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for i, (mc, B, hwd) in cases:
+        y, _ = _r1_forward(mc, B, hwd, 110 + i)
+        assert np.array_equal(y, np.load(f"{tmp_path}/one_{i}.npy")), (mc, B, hwd)
+
+
 def test_unet_forward_vs_oracle_towerruins64(oracle):
     """BASELINE config 1 shape: 64-ch, (H,W,D)=(46,64,46) — non-square planes, ragged tiles."""
     mc, (H, W, D) = 64, (46, 64, 46)
