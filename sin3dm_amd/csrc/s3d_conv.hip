@@ -454,8 +454,7 @@ __global__ __launch_bounds__(256) void k_rank1_fused(R1Inline r1) {
 void r1_layout(R1Inline& r1, int cout, int B) {
     r1.cout = cout;
     r1.n_tiles_n = (cout + 7) / 8;
-    static const int aiters = getenv("S3D_R1_AITERS") ? std::max(1, atoi(getenv("S3D_R1_AITERS"))) : 1;
-    r1.a_iters = aiters;
+    r1.a_iters = 1;                                         // (2 / 4 items per A thread measured: no difference)
     const long long athreads = 4 * r1.mf.begin[6] * B;
     r1.na = int((athreads + 256LL * r1.a_iters - 1) / (256LL * r1.a_iters));
     int nb = 0;
@@ -666,7 +665,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
     S3D_CHECK(!r1 || (kind == CONV_3x3 && !conv_use_naive() && !a.job[0].wgt_wino44 && takes_wino24(a) == 1), S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
-    if (conv_use_naive()) return launch_conv_naive(kind, a, st);
+    if (conv_use_naive()) return kind == CONV_1x3_ROLL ? launch_rank1(a, st, true) : launch_conv_naive(kind, a, st);   // (the three-tap table form has its own plain kernel)
     // Tile choice (measured, tools/conv_ubench.hip and in the step; for 1x1 again after the Winograd rework): the 64-pixel x 64-cout tile wins at every
     // size of this network because three blocks stay resident per CU (47 KB LDS each) and their staggered barriers keep
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).

@@ -770,11 +770,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24s(ConvArgs args, R1Inline
 //     built spilled 22-68 registers around the boundary, and each reload is a vmcnt(0);
 //   * all blocks start together and own tiles of equal length, so every boundary — and its burst of operand loads and output
 //     stores — hits every CU at the same moment, tile after tile; hardware-dispatched blocks drift apart and keep the k-loops
-//     of their CU's neighbours running.  A deliberate one-third-tile start stagger (S3D_W24P_STAGGER) did not recover it.
+//     of their CU's neighbours running.  A deliberate one-third-tile start stagger of a CU's three blocks did not recover it (measured, removed).
 #ifndef W24P_EARLY_RING
 #define W24P_EARLY_RING 0          // 1: the next tile's first weight fragments + second-chunk halo are requested right after the share images are written (more live registers in the epilogue)
 #endif
-__global__ __launch_bounds__(256, 3) void k_conv_wino24p(ConvArgs args, int total_tiles, int stagger_ticks) {
+__global__ __launch_bounds__(256, 3) void k_conv_wino24p(ConvArgs args, int total_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[2 * C_ABUF];
     static_assert(4 * C_IMG <= 2 * C_ABUF, "LDS plan");
     if (args.xcd_swizzle & 2) __builtin_amdgcn_s_setprio(2);
@@ -856,17 +856,8 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24p(ConvArgs args, int tota
     };
 
     Ctx cx, nx;
-    const int G_ = int(gridDim.x);
     int phys = blockIdx.x;
     setup(phys, cx);
-    if (stagger_ticks > 0) {
-        // the three blocks of a CU (dispatch order: ids b, b + G/3, b + 2G/3) start a third of a tile apart: their tile boundaries —
-        // LDS/barrier phases and the bursts of operand loads and output stores — then fall into each other's k-loops instead
-        // of hitting every CU and the memory system at the same moment, tile after tile
-        const int group = int(blockIdx.x) / ((G_ + 2) / 3);
-        const unsigned long long t0 = wall_clock64();
-        while (group > 0 && wall_clock64() - t0 < (unsigned long long)(group * stagger_ticks)) __builtin_amdgcn_s_sleep(32);
-    }
     f32x4 V[6], ring[6], hN[C_ITEMS_PT], pre[3];
 #pragma unroll
     for (int s = 0; s < 6; ++s) { ring[s] = wfrag(cx.wrs, 0, s); __builtin_amdgcn_sched_barrier(0); }
@@ -1302,14 +1293,8 @@ int launch_conv_wino24p(ConvArgs& a, hipStream_t st) {
     if (!blocks) return 0;
     a.xcd_swizzle = 1 | 2;                   // XCD-aware block order + raised priority outside the k-loop (were switchable in rounds 1-2: always wins)
     const int grid = std::min(blocks, conv_slots() & ~7);
-    // S3D_W24P_STAGGER = percent of a third of the estimated tile time by which the CU's second / third block start later
-    // (0 = off); only worth its one-off cost when a block owns many tiles
-    static const int stag_pct = getenv("S3D_W24P_STAGGER") ? atoi(getenv("S3D_W24P_STAGGER")) : 0;
-    static const int stag_min = getenv("S3D_W24P_STAGGER_MIN_TILES") ? atoi(getenv("S3D_W24P_STAGGER_MIN_TILES")) : 4;
-    const double tile_us = (a.cin / 32) * 4.8 + 6.0;
-    const int stagger_ticks = (stag_pct > 0 && blocks >= stag_min * grid) ? int(tile_us / 3.0 * stag_pct) : 0;      // 10-ns ticks: us * 100 * pct / 100
     conv_note_kernel("k_conv_wino24p mixed Winograd F(2x4,3x3), 8x16-pixel tiles, persistent blocks (next tile's halo + weights prefetched across the tile boundary)");
-    hipLaunchKernelGGL(k_conv_wino24p, dim3(grid), dim3(256), 0, st, a, blocks, stagger_ticks);
+    hipLaunchKernelGGL(k_conv_wino24p, dim3(grid), dim3(256), 0, st, a, blocks);
     S3D_HIP(hipGetLastError());
     return 0;
 }

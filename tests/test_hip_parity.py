@@ -99,7 +99,7 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["r1on", "44", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit"])
+@pytest.mark.parametrize("variant", ["r1on", "44", "24big", "4", "2", "0", "novcat", "oldhead", "gnsplit", "pf0", "pf4", "naive"])
 def test_unet_forward_golden_other_conv_kernels(variant):
     """Every 3x3 kernel on the golden planes (r1on: the default mixed Winograd F(2x4,3x3) kernel with S3D_RANK1_INLINE=1, i.e.
     the rollout's means + rank-1 tables as producer blocks of the convolution launch instead of two stand-alone launches;
@@ -109,8 +109,9 @@ def test_unet_forward_golden_other_conv_kernels(variant):
     frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors, leaf convolutions and ragged
     shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual concat of
     Fwd::resblock_cat; oldhead: S3D_OUT_HEAD=0, the thread-per-quad output head; gnsplit: S3D_GN_FUSED=0, every GroupNorm
-    statistic through k_gn_finalize instead of being added inside k_gn_act.  The choices are read once per process, hence
-    the subprocess."""
+    statistic through k_gn_finalize instead of being added inside k_gn_act; pf0 / pf4: S3D_CONV1X1_PF, one stage / the whole K
+    of the 1x1 kernels' loads in flight instead of two chunks; naive: S3D_CONV_IMPL=naive, the one-thread-per-output
+    convolutions used for triangulation).  The choices are read once per process, hence the subprocess."""
     import os, subprocess, sys
     code = (
         "import numpy as np, torch, sys\n"
@@ -129,7 +130,8 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
     env = {"r1on": dict(S3D_RANK1_INLINE="1"), "44": dict(S3D_WINO44="1", S3D_WINO44_MIN_TILES="0"), "24big": dict(S3D_WINO="24", S3D_WINO24_BIG_MIN_BLOCKS="0"), "novcat": dict(S3D_VCAT="0"),
-           "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0")}.get(variant, dict(S3D_WINO=variant))
+           "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0"), "pf0": dict(S3D_CONV1X1_PF="0"), "pf4": dict(S3D_CONV1X1_PF="4"),
+           "naive": dict(S3D_CONV_IMPL="naive")}.get(variant, dict(S3D_WINO=variant))
     env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
