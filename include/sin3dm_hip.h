@@ -106,12 +106,6 @@ typedef struct {
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
 S3D_API const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls);
-/* The 3x3 convolution launches run the rollout's means + rank-1 tables (unet_triplane.py:37-58) as producer blocks of the same
- * launch; consumers poll with a bound.  *err = 0 if no block ever gave up waiting since the handle was created (1: a table
- * producer timed out on the means, 2: a convolution block timed out on the tables — results are then invalid).
- * Synchronises the device. */
-S3D_API int s3d_unet_sync_errors(s3d_unet* m, int* err);
-
 /* ------------------------------------------------------------------------------------------
  * Sampler update: GaussianDiffusion.p_mean_variance + p_sample / ddim_sample
  *   src/diffusion/gaussian_diffusion.py:233-327, 396-440, 538-600
@@ -145,6 +139,14 @@ typedef struct {
 } s3d_sampler_args;
 
 S3D_API int s3d_sampler_step(const s3d_sampler_args* a, void* stream);
+
+/* One whole denoising step of the sampling loops (p_sample_loop_progressive / ddim_sample_loop_progressive,
+ * src/diffusion/gaussian_diffusion.py:488-536, 687-734): the UNet forward on x_t = step->x with the FiLM row(s) of
+ * s3d_unet_film, its output head (unet_triplane.py:441-445, 507-508) and the sampler update above in the head's launch
+ * ("K8: fuse with K9") — the model output is not stored unless model_out != NULL (step->model_out is
+ * ignored).  Same arithmetic in the same order as s3d_unet_forward_film followed by s3d_sampler_step: identical bits. */
+S3D_API int s3d_unet_step_film(s3d_unet* m, const float* film, int film_stride, int B, int H, int W, int D,
+                       const s3d_sampler_args* step, float* model_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Leaf operators, exported so the parity tests can pin each kernel to the reference op it replaces

@@ -197,21 +197,25 @@ def schedule_tables_named(steps=1000):
             "sqrt_one_minus_alphas_cumprod": np.sqrt(1.0 - tab[1])}
 
 
-def p_sample_update(model_out, x, eps, tab, t, clip=True):
+def p_sample_update(model_out, x, eps, tab, t, clip=True, mean_eps=False, var_small=False, want_mean=False):
+    """(sample, pred_xstart[, mean]) of p_sample; mean_eps: the model predicts the noise (ModelMeanType.EPSILON);
+    var_small: ModelVarType.FIXED_SMALL."""
     (mo, a), (x, b), (eps, c) = _f(model_out), _f(x), _f(eps)
     s, p = np.empty_like(mo), np.empty_like(mo)
+    m = np.empty_like(mo) if want_mean else None
     tab = np.ascontiguousarray(tab, np.float64)
-    lib().orc_p_sample_update(a, b, c, s.ctypes.data_as(c_fp), p.ctypes.data_as(c_fp), C.c_size_t(mo.size),
-                              tab.ctypes.data_as(c_dp), tab.shape[1], int(t), int(clip))
-    return s, p
+    lib().orc_p_sample_update_ex(a, b, c, s.ctypes.data_as(c_fp), p.ctypes.data_as(c_fp),
+                                 m.ctypes.data_as(c_fp) if want_mean else None, C.c_size_t(mo.size),
+                                 tab.ctypes.data_as(c_dp), tab.shape[1], int(t), int(clip), int(mean_eps), int(var_small))
+    return (s, p, m) if want_mean else (s, p)
 
 
-def ddim_update(model_out, x, noise, tab, t, clip=True, eta=0.0):
+def ddim_update(model_out, x, noise, tab, t, clip=True, eta=0.0, mean_eps=False):
     (mo, a), (x, b), (noise, c) = _f(model_out), _f(x), _f(noise)
     s, p = np.empty_like(mo), np.empty_like(mo)
     tab = np.ascontiguousarray(tab, np.float64)
-    lib().orc_ddim_update(a, b, c, s.ctypes.data_as(c_fp), p.ctypes.data_as(c_fp), C.c_size_t(mo.size),
-                          tab.ctypes.data_as(c_dp), tab.shape[1], int(t), int(clip), C.c_float(eta))
+    lib().orc_ddim_update_ex(a, b, c, s.ctypes.data_as(c_fp), p.ctypes.data_as(c_fp), C.c_size_t(mo.size),
+                             tab.ctypes.data_as(c_dp), tab.shape[1], int(t), int(clip), C.c_float(eta), int(mean_eps))
     return s, p
 
 

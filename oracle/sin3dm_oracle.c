@@ -503,38 +503,59 @@ ORC_API int orc_respace_betas(const double* base_betas, int T, const uint8_t* ke
     return n;
 }
 
-/* p_mean_variance (START_X, FIXED_LARGE, clip) + p_sample.  src/diffusion/gaussian_diffusion.py:233-327, 396-440.
- * model_out = x0 prediction. coefficients are gathered from float64 tables then cast to float (:944). */
-ORC_API void orc_p_sample_update(const float* model_out, const float* x, const float* eps, float* sample,
-                                 float* pred_xstart, size_t n, const double* tab, int T, int t, int clip) {
+/* p_mean_variance + p_sample.  src/diffusion/gaussian_diffusion.py:233-327, 396-440.
+ * mean_eps == 0: model_out is the x0 prediction (ModelMeanType.START_X, :307-308); 1: it is the noise prediction and
+ * x0 = sqrt_recip_alphas_cumprod[t] x - sqrt_recipm1_alphas_cumprod[t] model_out (EPSILON, :309-312, :329-335).
+ * var_small == 0: FIXED_LARGE, variance [posterior_variance[1], betas[1:]] (:282-285); 1: FIXED_SMALL, the posterior variance with
+ * its clipped log (:286-289, :163-165).  clip: process_xstart's clamp (:294-299).
+ * Coefficients are gathered from float64 tables then cast to float (:944).  mean_out (optional): the model mean. */
+/* The reference evaluates these expressions as separate fp32 tensor operations: no fused multiply-add (GNU C contracts a * b + c
+ * by default; the EPSILON branch subtracts two products of magnitude ~157 at t = 999, where a contracted fma shows) */
+#define ORC_NO_FMA __attribute__((optimize("fp-contract=off")))
+ORC_NO_FMA ORC_API void orc_p_sample_update_ex(const float* model_out, const float* x, const float* eps, float* sample,
+                                    float* pred_xstart, float* mean_out, size_t n, const double* tab, int T, int t, int clip,
+                                    int mean_eps, int var_small) {
     const float c1 = (float)tab[6 * T + t], c2 = (float)tab[7 * T + t];
-    const double var = t == 0 ? tab[5 * T + 1] : tab[t];            /* [posterior_variance[1], betas[1:]] (:282-285) */
+    const float sr = (float)tab[3 * T + t], srm1 = (float)tab[4 * T + t];
+    double var;
+    if (var_small) var = tab[5 * T + (t == 0 ? 1 : t)];              /* posterior_log_variance_clipped */
+    else var = t == 0 ? tab[5 * T + 1] : tab[t];                      /* [posterior_variance[1], betas[1:]] */
     const float logvar = (float)log(var);
     const float sigma = expf(0.5f * logvar);
     const float mask = t != 0 ? 1.f : 0.f;
     for (size_t i = 0; i < n; ++i) {
-        float x0 = model_out[i];
+        float x0 = mean_eps ? sr * x[i] - srm1 * model_out[i] : model_out[i];
         if (clip) x0 = x0 < -1.f ? -1.f : (x0 > 1.f ? 1.f : x0);
         const float mean = c1 * x0 + c2 * x[i];
         sample[i] = mean + mask * sigma * eps[i];
         pred_xstart[i] = x0;
+        if (mean_out) mean_out[i] = mean;
     }
 }
-/* ddim_sample.  src/diffusion/gaussian_diffusion.py:538-600 (+ _predict_eps_from_xstart :346-350) */
-ORC_API void orc_ddim_update(const float* model_out, const float* x, const float* noise, float* sample,
-                             float* pred_xstart, size_t n, const double* tab, int T, int t, int clip, float eta) {
+ORC_API void orc_p_sample_update(const float* model_out, const float* x, const float* eps, float* sample,
+                                 float* pred_xstart, size_t n, const double* tab, int T, int t, int clip) {
+    orc_p_sample_update_ex(model_out, x, eps, sample, pred_xstart, NULL, n, tab, T, t, clip, 0, 0);
+}
+/* ddim_sample.  src/diffusion/gaussian_diffusion.py:538-600 (+ _predict_eps_from_xstart :346-350); mean_eps as above
+ * (the variance type does not enter the DDIM update) */
+ORC_NO_FMA ORC_API void orc_ddim_update_ex(const float* model_out, const float* x, const float* noise, float* sample,
+                                float* pred_xstart, size_t n, const double* tab, int T, int t, int clip, float eta, int mean_eps) {
     const float sr = (float)tab[3 * T + t], srm1 = (float)tab[4 * T + t];
     const float ab = (float)tab[1 * T + t], abp = (float)tab[2 * T + t];
     const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
     const float mask = t != 0 ? 1.f : 0.f;
     const float ca = sqrtf(abp), cb = sqrtf(1.f - abp - sigma * sigma);
     for (size_t i = 0; i < n; ++i) {
-        float x0 = model_out[i];
+        float x0 = mean_eps ? sr * x[i] - srm1 * model_out[i] : model_out[i];
         if (clip) x0 = x0 < -1.f ? -1.f : (x0 > 1.f ? 1.f : x0);
         const float e = (sr * x[i] - x0) / srm1;
         sample[i] = x0 * ca + cb * e + mask * sigma * noise[i];
         pred_xstart[i] = x0;
     }
+}
+ORC_API void orc_ddim_update(const float* model_out, const float* x, const float* noise, float* sample,
+                             float* pred_xstart, size_t n, const double* tab, int T, int t, int clip, float eta) {
+    orc_ddim_update_ex(model_out, x, noise, sample, pred_xstart, n, tab, T, t, clip, eta, 0);
 }
 
 /* ------------------------------------------------------------------ autoencoder decode ---- */

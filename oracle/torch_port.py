@@ -114,13 +114,14 @@ def q_sample(x0, noise, sqrt_ac, sqrt_1mac, t):
     return a * x0 + b * noise
 
 
-def training_losses(sd, x0, t, noise, tabs, H, W, D, **unet_kw):
-    """training_losses with MSE / START_X (gaussian_diffusion.py:771-856): per-plane mean-squared errors summed.
+def training_losses(sd, x0, t, noise, tabs, H, W, D, predict_xstart=True, **unet_kw):
+    """training_losses with MSE (gaussian_diffusion.py:771-856): per-plane mean-squared errors summed; the target is x0
+    (ModelMeanType.START_X) or, with predict_xstart=False, the noise (EPSILON, :829-835).
     sd tensors may require grad; returns {"mse_xy","mse_xz","mse_yz","loss"} each [B], and x_t."""
     x_t = q_sample(x0, noise, tabs["sqrt_alphas_cumprod"], tabs["sqrt_one_minus_alphas_cumprod"], t)
     out = unet_forward(sd, x_t, t.float(), H, W, D, **unet_kw)
     terms = {}
-    for name, tgt, o in zip(PLANES, _decompose(x0, H, W, D), _decompose(out, H, W, D)):
+    for name, tgt, o in zip(PLANES, _decompose(x0 if predict_xstart else noise, H, W, D), _decompose(out, H, W, D)):
         terms["mse_" + name] = ((tgt - o) ** 2).flatten(1).mean(1)
     terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]
     return terms, x_t

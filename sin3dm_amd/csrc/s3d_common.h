@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -40,6 +41,19 @@ const char* get_error();
         int rc__ = (expr);                                                                         \
         if (rc__ != 0) return rc__;                                                                \
     } while (0)
+
+// Opt a kernel in to more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair: it is set once per
+// device the calling code ever launches on (`opted` = the call site's bit mask of devices done); a failure is reported and not
+// remembered, so a transient error does not poison later launches.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& opted) {
+    int dev = 0;
+    S3D_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (opted.load(std::memory_order_acquire) & bit)) return 0;
+    S3D_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (bit) opted.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 // ------------------------------------------------------------------ device memory helpers
 struct DevBuf {                       // owning device allocation (grow-only)
@@ -102,9 +116,7 @@ struct ConvJob {
     const float* in;      // [B][h][w][cin] NHWC
     const float* wgt;     // packed [taps][cout][cin]
     const float* wgt_wino;// 3x3 only: Winograd-transformed weights in MFMA fragment order (s3d_wino.hip) or null
-    const float* wgt_wino24;// 3x3 only: the F(2x4,3x3) image of the 16x16-pixel kernel (s3d_wino24.hip) or null
-    const float* wgt_wino24s;// 3x3 only: the F(2x4,3x3) image of the 8x16-pixel kernel or null (both null: the F(2x2) kernels are used)
-    const float* wgt_wino44; // 3x3 only: set by the caller when this launch takes the F(4x4,3x3) kernel (s3d_wino44.hip), else null
+    const float* wgt_wino24s;// 3x3 only: the mixed F(2x4,3x3) image of k_conv_wino24s / k_conv_wino24w (s3d_wino24.hip) or null (null: the F(2x2) kernels are used)
     const float* bias;    // [cout] or null
     const float* bbias;   // [B][bbias_stride] per-sample bias (h + emb path) or null
     const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
@@ -134,10 +146,7 @@ struct ConvArgs {
 // CONV_1x3_ROLL: the forward rollout tables — args.cout = the convolution's cout, out [B][pos][4 variants][cout] (k_rank1<true>)
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3, CONV_1x3_ROLL = 4 };
 // Enqueue all jobs (same B/cin/cout/kind) as ONE launch.  cin must be a multiple of 32.
-struct R1Inline;
-// r1 (3x3 only, and only when conv_wino24_geo() == 1, i.e. the launch goes to k_conv_wino24s): the rollout's means + tables run
-// as producer blocks of this launch; sync_expect = the host mirror of the handle's hand-off counters
-int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1 = nullptr, unsigned* sync_expect = nullptr);
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st);
 // Debug/triangulation path: a plain one-thread-per-output direct convolution (no MFMA, no LDS).
 // Selected with S3D_CONV_IMPL=naive; never the default.
 int launch_conv_naive(ConvKind kind, ConvArgs& a, hipStream_t st);
@@ -155,9 +164,7 @@ struct ConvW {
     size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3 taps][ceil(cout/8)*24][C], row (co/8)*24 + o*8 + co%8
     size_t rcol[3] = {0, 0, 0};       // rank-1 weights for the column-varying mean vector
     size_t wino[3] = {0, 0, 0};       // 3x3: G g G^T in fragment order (0 = not packed)
-    size_t wino24[3] = {0, 0, 0};     // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24
-    size_t wino24s[3] = {0, 0, 0};    // ... and of k_conv_wino24s
-    size_t wino44[3] = {0, 0, 0};     // 3x3: G g G^T of F(4x4,3x3) in the fragment order of k_conv_wino44 (0 = not packed)
+    size_t wino24s[3] = {0, 0, 0};    // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24s / k_conv_wino24w
     int cin = 0, cout = 0, k = 0;
     bool rollout = false;
 };
@@ -201,7 +208,7 @@ void gn_up_parts(const Geo& out_g, int nparts[3]);             // parts per plan
 int launch_gn_partials_up(const Tri& u, int B, int sg, GnPartials out, hipStream_t st);
 int launch_gn_finalize_cat(const GnPartials& pu, const GnPartials& ps, const Geo& g, int C, int B, GnStats out, hipStream_t st);
 // how many parts per plane a convolution epilogue writes for a given geometry (must match s3d_conv.hip's tiling)
-void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24 = 0);
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], bool wino24 = false);
 // Winograd F(2x2,3x3) path for the 3x3 convolutions (s3d_wino.hip); S3D_WINO=0 selects the direct kernel
 bool conv_use_wino();
 void wino_gn_parts(const Geo& g, int nparts[3]);
@@ -210,26 +217,14 @@ int launch_conv_wino(ConvArgs& a, hipStream_t st);
 double wino_exec_fraction();
 // mixed Winograd F(2x4,3x3) (s3d_wino24.hip): the default 3x3 kernel of the inference forward (S3D_WINO=4 / 2 / 0 select the others)
 bool conv_use_wino24();
-bool conv_wino24_big_enabled();                     // S3D_WINO24_BIG_MIN_BLOCKS set: the 16x16-pixel variant may be chosen
 bool conv_wino24_channels(int cin, int cout);       // the mixed kernel takes every 3x3 launch of these widths
-// which mixed kernel a launch over these planes / channels / samples takes: 0 none (F(2x2)), 1 the 8x16-pixel form, 2 the 16x16-pixel form
-int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B);
-void wino24_gn_parts(const Geo& g, int nparts[3]);
 size_t wino24_packed_floats(int cout, int cin);
-size_t pack_wino24_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
-int launch_conv_wino24(ConvArgs& a, hipStream_t st);
 size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
+// k_conv_wino24s (32 output channels per block) or, for launches of several rounds of blocks, k_conv_wino24w (64): the two are
+// bit-identical, so the choice may depend on the batch size (S3D_WINO24W=0 never / =1 whenever the widths allow)
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st);
-// full Winograd F(4x4,3x3) for launches with many tiles (s3d_wino44.hip); S3D_WINO44=0 disables it
-bool conv_wino44_enabled();
-bool conv_wino44_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B);   // does a launch over these planes / samples take it?
-void wino44_gn_parts(const Geo& g, int nparts[3]);
-size_t wino44_packed_floats(int cout, int cin);
-size_t pack_wino44_weights(std::vector<float>& stage, const float* W, int cout, int ctot, int cin);
-int launch_conv_wino44(ConvArgs& a, hipStream_t st);
-int launch_conv_wino24p(ConvArgs& a, hipStream_t st);           // the persistent form (S3D_WINO24_PERSIST=0 disables it)
-bool conv_wino24_takes_persistent(const ConvArgs& a);           // more tiles than co-resident blocks
-bool conv_wino24_persistent_enabled();
+int launch_conv_wino24_narrow(ConvArgs& a, hipStream_t st);     // k_conv_wino24s, whatever the launch size
+int launch_conv_wino24_wide(ConvArgs& a, hipStream_t st);       // k_conv_wino24w (cout % 64 == 0)
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {
@@ -254,44 +249,20 @@ bool gn_act_can_add_parts(const GnPartials& part, int C);
 int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                       hipStream_t st);
 // finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
-// base / bytes: when the six vectors are ONE allocation (Fwd::roll_buffers) — the in-launch form stores them through one buffer descriptor
-struct MeanVecs { float* rowmean[3]; float* colmean[3]; float* base = nullptr; size_t bytes = 0; };
+struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
 struct MeanFinArgs {
     const float* rowpart[3]; const float* colpart[3];
     float* rowmean[3]; float* colmean[3];
     int h[3], w[3];
     int C, cq, B;
     long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
-    float* mean_base; unsigned mean_bytes;
 };
 MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv);
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);
 
-// The rollout's small dependent stages run INSIDE the 3x3 convolution launch (s3d_rank1.h): blocks [0, na) finalize the six
-// mean vectors, blocks [na, na + nb) build the rank-1 tables, blocks [nprod, ...) are the convolution's tiles (nprod = na + nb
-// rounded up to a multiple of 8 so that block id % 8 — the XCD — means the same for the tiles as without producers).
-struct R1Job { const float* vin; const float* wgt; float* out; int L, tiles, block_begin; };
-struct R1Inline {
-    int nprod;                // 0: plain convolution launch
-    int na, nb, a_iters;      // an A block handles a_iters x 256 threads' worth of means_finalize items
-    int cin, cout, n_tiles_n; // mean-vector channels; the convolution's cout; ceil(cout / 8) column tiles of a table
-    unsigned* sync;           // kSyncWords counters of the handle (never reset: targets are cumulative)
-    unsigned a_target[8], b_target[3];
-    R1Job job[6];             // job 2p: the row-indexed table of plane p, 2p + 1: the column-indexed one
-    MeanFinArgs mf;
-};
-int launch_conv_wino24s_r1(ConvArgs& a, R1Inline& r1, unsigned* expect /*host mirror of the counters*/, hipStream_t st);
-// block layout of the producer roles (r1.mf / job[].L set by the caller) and the cumulative counter targets of one launch
-void r1_layout(R1Inline& r1, int cout, int B);
-void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch);
-// means finalisation + rank-1 tables as ONE launch (A blocks, then B blocks that wait for them in-launch): s3d_conv.hip
-int launch_rank1_fused(R1Inline& r1, int cout, int B, unsigned* expect, hipStream_t st);
 // how many K slices (1 or 2) the rank-1 tables of a rollout convolution with `cin` own channels are cut into when its consumer is
 // k_conv_wino24s (S3D_RANK1_SLICES=0: never): two from 256 channels on
 int conv_rank1_slices(int cin);
-bool conv_rank1_fused_enabled();          // S3D_RANK1_FUSED=1 (default off: measured slower)
-bool conv_rank1_inline_enabled();         // S3D_RANK1_INLINE=1 (default off: measured slower, profiles/r03_rank1_inline.txt)
-constexpr size_t kSyncWordsBytes = 12 * 32 * 4;   // = kSyncWords * 4 (s3d_rank1.h)
 
 // part != null: pixel-chunk form that also emits the GroupNorm partials of y (kGnChunks parts per plane, 32 groups)
 int launch_avgpool(const Tri& x, int B, Tri& y, hipStream_t st, const GnPartials* part = nullptr);
@@ -305,8 +276,12 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
                       hipStream_t st);
 
 // out head: GN + SiLU + 1x1 conv (C -> Cout small) + compose into NCHW [B,Cout,H+D,W+D] with zero corner
+// fuse != null: + the sampler update of the step on the model output (in the same launch when out_head_fuses_sampler(); then
+// `out` may be null and the model output is never stored)
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
-                    const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st);
+                    const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st,
+                    const s3d_sampler_args* fuse = nullptr);
+bool out_head_fuses_sampler(int C, int Cout);
 
 // small dense layers for the timestep path: y[b][o] = act_out( sum_i f(in[b][i]) * W[o][i] + bias[o] )
 // in_mode 0: plain, 1: SiLU(in), 2: in is t[b] -> sinusoidal embedding of width I (cos | sin)

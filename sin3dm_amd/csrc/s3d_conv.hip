@@ -439,63 +439,12 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
         const int nchunks = args.cin / kR1Chunk, first = (nchunks + 1) / 2;
         blk.chunk0 = sl ? first : 0; blk.nch = sl ? nchunks - first : first;
     }
-    rank1_block<ROLL3, false, false, NS>(blk, lds, []() {});
+    rank1_block<ROLL3, NS>(blk, lds);
 }
 
-// means finalisation + rank-1 tables in ONE launch: the A blocks (lowest ids, dispatched first) finalize the six mean vectors
-// with write-through stores, the B blocks request their weights, wait for the A counters and build the tables (s3d_rank1.h).
-// Meant to take a launch boundary off the chain before every rollout convolution; same arithmetic in the same order as
-// k_means_finalize + k_rank1<true> (bit-identical) but MEASURED SLOWER (S3D_RANK1_FUSED=1 enables it).
-__global__ __launch_bounds__(256) void k_rank1_fused(R1Inline r1) {
-    __shared__ __attribute__((aligned(16))) float lds[kR1LdsFloats];
-    r1_producer_role<false>(r1, blockIdx.x, lds);
-}
-
-void r1_layout(R1Inline& r1, int cout, int B) {
-    r1.cout = cout;
-    r1.n_tiles_n = (cout + 7) / 8;
-    r1.a_iters = 1;                                         // (2 / 4 items per A thread measured: no difference)
-    const long long athreads = 4 * r1.mf.begin[6] * B;
-    r1.na = int((athreads + 256LL * r1.a_iters - 1) / (256LL * r1.a_iters));
-    int nb = 0;
-    for (int j = 0; j < 6; ++j) {
-        r1.job[j].tiles = (r1.job[j].L + 31) / 32;
-        r1.job[j].block_begin = nb;
-        nb += r1.job[j].tiles * r1.n_tiles_n * B;
-    }
-    r1.nb = nb;
-    r1.nprod = (r1.na + nb + 7) & ~7;
-}
-void r1_targets(R1Inline& r1, int B, unsigned* expect, bool tables_in_launch) {
-    for (int k = 0; k < 8; ++k) {
-        expect[kSyncA + k] += unsigned(r1.na > k ? (r1.na - k + 7) / 8 : 0);
-        r1.a_target[k] = expect[kSyncA + k];
-    }
-    for (int p = 0; p < 3; ++p) {
-        if (tables_in_launch) expect[kSyncB + p] += unsigned((r1.job[2 * p].tiles + r1.job[2 * p + 1].tiles) * r1.n_tiles_n * B);
-        r1.b_target[p] = expect[kSyncB + p];
-    }
-}
 int conv_rank1_slices(int cin) {
     static const bool on = !(getenv("S3D_RANK1_SLICES") && atoi(getenv("S3D_RANK1_SLICES")) == 0);
     return on && cin >= 2 * kR1Chunk && cin % kR1Chunk == 0 ? 2 : 1;
-}
-bool conv_rank1_fused_enabled() {
-    // default OFF: 22-25 us per launch against 5 + 9.5 us for the two stand-alone kernels (profiles/r03_rank1_inline.txt): an
-    // in-launch hand-off through memory (write-through store -> drain -> counter -> poll -> sc1 reload) costs ~8 us, a launch
-    // boundary ~2
-    static const bool on = getenv("S3D_RANK1_FUSED") && atoi(getenv("S3D_RANK1_FUSED")) != 0;
-    return on;
-}
-int launch_rank1_fused(R1Inline& r1, int cout, int B, unsigned* expect, hipStream_t st) {
-    S3D_CHECK(expect && r1.sync && cout % 4 == 0 && r1.cin % KC == 0, S3D_ERR_INVALID, "rank1_fused: bad arguments");
-    r1_layout(r1, cout, B);
-    if (!r1.nb) return 0;
-    r1_targets(r1, B, expect, false);
-    conv_note_kernel("k_rank1_fused (rollout means finalisation + three-tap rank-1 tables, one launch)");
-    hipLaunchKernelGGL(k_rank1_fused, dim3(r1.na + r1.nb), dim3(256), 0, st, r1);
-    S3D_HIP(hipGetLastError());
-    return 0;
 }
 
 // S3D_CONV_IMPL=naive counterpart of the ROLL3 form: one thread per table entry, plain loops over the same weight image
@@ -548,8 +497,8 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     conv_note_kernel(roll3 ? "k_rank1<true> (three-tap rollout tables)" : "k_rank1<false>");
     constexpr size_t lds1 = kR1LdsFloats * sizeof(float), lds2 = lds1 + 34 * kR1Ld * sizeof(float);
     if (ns == 2) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rank1<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds2));
-        S3D_HIP(attr);
+        static std::atomic<unsigned long long> opted{0};
+        S3D_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(&k_rank1<true, 2>), int(lds2), opted));
         hipLaunchKernelGGL((k_rank1<true, 2>), dim3(blocks), dim3(256), lds2, st, a);
     } else if (roll3) hipLaunchKernelGGL(k_rank1<true>, dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_rank1<false>, dim3(blocks), dim3(256), 0, st, a);
@@ -557,12 +506,10 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     return 0;
 }
 
-void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], int wino24) {
+void conv_gn_parts(ConvKind kind, const Geo& g, int nparts[3], bool wino24) {
     // must mirror launch_conv's tile choice for the kinds whose epilogue emits GroupNorm partials (3x3 only)
     (void)kind;
-    if (wino24 == 3) { wino44_gn_parts(g, nparts); return; }
-    if (wino24 == 2 && conv_use_wino24()) { wino24_gn_parts(g, nparts); return; }
-    if (wino24 == 1 && conv_use_wino24()) {                       // k_conv_wino24s: one part per 8x16-pixel block
+    if (wino24 && conv_use_wino24()) {                            // k_conv_wino24s / k_conv_wino24w: one part per 8x16-pixel tile
         for (int p = 0; p < 3; ++p) nparts[p] = ((g.w[p] + 15) / 16) * ((g.h[p] + 7) / 8);
         return;
     }
@@ -629,41 +576,17 @@ static long long count_tiles(const ConvArgs& a) {
     return t * a.B;
 }
 
-// Mixed Winograd F(2x4,3x3): the 8x16-pixel kernel (three blocks per CU, as many blocks as the F(2x2) kernel) is the default;
-// the 16x16-pixel kernel (two blocks per CU, half the halo and weight traffic per flop) takes over from
-// S3D_WINO24_BIG_MIN_BLOCKS per-sample blocks of its own size.  The choice must not depend on the batch size: a sample's
-// result may not depend on what it is batched with.
-static long long wino24_big_min() {
-    static const long long v = getenv("S3D_WINO24_BIG_MIN_BLOCKS") ? atoll(getenv("S3D_WINO24_BIG_MIN_BLOCKS")) : (1LL << 60);
-    return v;
-}
-bool conv_wino24_big_enabled() { return conv_use_wino24() && wino24_big_min() < (1LL << 60); }
+// Mixed Winograd F(2x4,3x3) takes every 3x3 launch of these widths (which of its two bit-identical kernels: launch_conv_wino24s)
 bool conv_wino24_channels(int cin, int cout) { return conv_use_wino24() && cout % 4 == 0 && cin % 32 == 0; }
-int conv_wino24_geo(const int* h, const int* w, int nplanes, int cin, int cout, int B) {
-    if (!conv_wino24_channels(cin, cout)) return 0;
-    const long long big_min = wino24_big_min();
-    long long blocks = 0;
-    for (int j = 0; j < nplanes; ++j) blocks += (long long)B * ((w[j] + 15) / 16) * ((h[j] + 15) / 16) * ((cout + 31) / 32);
-    return blocks >= big_min ? 2 : 1;
-}
-static int takes_wino24(const ConvArgs& a) {
-    int h[kMaxConvJobs], w[kMaxConvJobs];
-    for (int j = 0; j < a.njobs; ++j) { h[j] = a.job[j].h; w[j] = a.job[j].w; }
-    const int k = conv_wino24_geo(h, w, a.njobs, a.cin, a.cout, a.B);
-    if (k == 2 && a.job[0].wgt_wino24) return 2;
-    if (k >= 1 && a.job[0].wgt_wino24s) return 1;
-    return 0;
-}
+static bool takes_wino24(const ConvArgs& a) { return conv_wino24_channels(a.cin, a.cout) && a.job[0].wgt_wino24s; }
 double conv_exec_fraction(ConvKind kind, const ConvArgs& a) {
-    if (kind == CONV_3x3 && !conv_use_naive() && a.job[0].wgt_wino44) return 1.0 / 4.0;             // 36 multiplies per 4x4 outputs instead of 144
     if (kind == CONV_3x3 && !conv_use_naive() && takes_wino24(a)) return 1.0 / 3.0;      // 24 multiplies per 2x4 outputs instead of 72
     if (kind == CONV_3x3 && !conv_use_naive() && conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) return wino_exec_fraction();
     return 1.0;
 }
 
-int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsigned* sync_expect) {
+int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs, S3D_ERR_INVALID, "conv: %d jobs", a.njobs);
-    S3D_CHECK(!r1 || (kind == CONV_3x3 && !conv_use_naive() && !a.job[0].wgt_wino44 && takes_wino24(a) == 1), S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
     S3D_CHECK(a.cin % KC == 0 && a.cin > 0, S3D_ERR_INVALID, "conv: cin=%d must be a positive multiple of %d", a.cin, KC);
     if (conv_use_naive()) return kind == CONV_1x3_ROLL ? launch_rank1(a, st, true) : launch_conv_naive(kind, a, st);   // (the three-tap table form has its own plain kernel)
     // Tile choice (measured, tools/conv_ubench.hip and in the step; for 1x1 again after the Winograd rework): the 64-pixel x 64-cout tile wins at every
@@ -671,16 +594,9 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
     // the matrix pipe fed; the 128-pixel tiles halve the staging traffic but leave 1-2 blocks per CU (85 vs 102 TF, profiles/r01_tile_sweep.txt).
     switch (kind) {
         case CONV_3x3:
-            if (a.job[0].wgt_wino44) {                                     // the caller selected F(4x4) (conv_wino44_geo)
-                S3D_CHECK(!r1, S3D_ERR_INVALID, "conv: in-launch rank-1 producers need the k_conv_wino24s path");
-                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino44;
-                return launch_conv_wino44(a, st);
-            }
-            if (const int k24 = takes_wino24(a)) {
-                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = k24 == 2 ? a.job[j].wgt_wino24 : a.job[j].wgt_wino24s;
-                if (r1) return launch_conv_wino24s_r1(a, *r1, sync_expect, st);
-                if (k24 == 1 && conv_wino24_takes_persistent(a)) return launch_conv_wino24p(a, st);
-                return k24 == 2 ? launch_conv_wino24(a, st) : launch_conv_wino24s(a, st);
+            if (takes_wino24(a)) {
+                for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino24s;
+                return launch_conv_wino24s(a, st);
             }
             if (conv_use_wino() && a.job[0].wgt_wino && a.cout % 4 == 0) {   // (its epilogue moves channel quads; GroupNorm'd layers always qualify)
                 for (int j = 0; j < a.njobs; ++j) a.job[j].wgt = a.job[j].wgt_wino;
@@ -689,14 +605,9 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st, R1Inline* r1, unsign
             return launch_cfg<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1>>(a, st);
         case CONV_1x1:         // (round-2 sweep in the step: 128 px x 64 cout 0.081, 64 x 128 0.078, 128 x 128 0.218, two K accumulators 0.081,
                                //  64-channel K chunks (70 KB LDS, two blocks per CU) 0.084, 16-channel chunks 0.077 vs 0.072 ms/step)
-        {
-            // global-load chunks in flight for the 1x1 kernels (round 3): 0 = one stage ahead 0.0713 ms/step,
-            // 2 = 0.0686, 4 = 0.0711 — the stages' memory latency is NOT what these launches wait for (profiles/r03_conv1x1.txt)
-            static const int pf = getenv("S3D_CONV1X1_PF") ? atoi(getenv("S3D_CONV1X1_PF")) : 2;
-            if (pf == 4) return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 4>>(a, st);
-            if (pf == 2) return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2>>(a, st);
-            return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1>>(a, st);
-        }
+            // two K chunks of global loads in flight (round 3: one stage ahead 0.0713 ms/step, 2 chunks 0.0686, whole K 0.0711 — the
+            // stages' memory latency is NOT what these launches wait for, profiles/r03_conv1x1.txt)
+            return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2>>(a, st);
         case CONV_1x3_VEC:
             return launch_rank1(a, st, false);
         case CONV_1x3_ROLL:

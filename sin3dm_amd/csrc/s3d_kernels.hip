@@ -8,6 +8,7 @@
 // bit-repeatable run to run.
 #include "s3d_common.h"
 #include "s3d_rank1.h"
+#include "s3d_sampler.h"
 
 namespace s3d {
 
@@ -770,12 +771,11 @@ int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const A
 // th.mean over one axis of the activated planes (src/diffusion/unet_triplane.py:38-46): add the tile partials
 // in index order and divide by the axis length.
 __global__ __launch_bounds__(256) void k_means_finalize(MeanFinArgs a) {
-    means_finalize_thread<false>(a, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+    means_finalize_thread(a, (long long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv) {
     MeanFinArgs a;
     a.C = C; a.cq = C / 4; a.B = B; a.begin[0] = 0;
-    a.mean_base = mv.base; a.mean_bytes = (unsigned)mv.bytes;
     for (int p = 0; p < 3; ++p) {
         a.rowpart[p] = mp.rowpart[p]; a.colpart[p] = mp.colpart[p];
         a.rowmean[p] = mv.rowmean[p]; a.colmean[p] = mv.colmean[p];
@@ -1119,8 +1119,13 @@ __global__ void k_out_head(OutHeadArgs a) {
 // that are wave-uniform (scalar loads), and the four partial sums per (pixel, cout) meet in LDS for a coalesced NCHW store.
 // 28.7 -> 12 us at 128 channels, 128^3 (the thread-per-quad form above spends its time in 12 LDS reduction rounds).
 constexpr int kOhPx = 64;
-template <int CQ>                                          // channel quads per pixel: 16, 32 or 64
-__global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2) {
+// FUSED (SURVEY.md §2b "K8: fuse with K9"; the sampling loops): the model output of a composed position is not stored (unless
+// a.out is set) — the p_sample / ddim_sample update of s3d_sampler.h is applied to it where it is formed, x_t and the noise are
+// read and x_{t-1} + pred_xstart written with the same coalesced NCHW accesses; the D x D corner takes the update with a model
+// output of exactly 0 (compose_featmaps' zero fill, src/utils/triplane_util.py:7-18).  Same arithmetic in the same order as
+// k_out_head_px<CQ, false> followed by k_sampler: bit-identical results.
+template <int CQ, bool FUSED>                              // channel quads per pixel: 16, 32 or 64
+__global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2, s3d_sampler_args sa) {
     constexpr int C = 4 * CQ, CPW = C / 4, LANES = 256 / CQ, LD = C + 4;
     __shared__ __attribute__((aligned(16))) float sx[kOhPx * LD];
     __shared__ float sp[4][16][kOhPx];
@@ -1131,9 +1136,13 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
     if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; if (blk >= segs2) { blk -= segs2; p = 3; } } }
     if (p == 3) {                                           // the D x D corner of compose_featmaps: zeros
         const long long n = (long long)a.Cout * a.D * a.D;
+        SamplerCoef sc;
+        if (FUSED) sc = sampler_coef(sa, int(sa.t[b]));
         for (long long i = (long long)blk * 256 + tid; i < n; i += 256LL * (gridDim.x - segs0 - segs1 - segs2)) {
             const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
-            a.out[((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx] = 0.f;
+            const size_t o = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
+            if (!FUSED || a.out) a.out[o] = 0.f;
+            if (FUSED) sampler_element(sa, sc, (long long)o, 0.f);
         }
         return;
     }
@@ -1187,17 +1196,29 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
             sp[wv][co][e] = s0a + s1a;
         }
     }
+    SamplerCoef sc;
+    if (FUSED) sc = sampler_coef(sa, int(sa.t[b]));          // (requested before the barrier: scalar table loads)
     __syncthreads();
     for (int it = tid; it < a.Cout * kOhPx; it += 256) {
         const int co = it >> 6, e = it & 63;
         if (s0 + e >= len) continue;
         const float v = ((sp[0][co][e] + sp[1][co][e]) + (sp[2][co][e] + sp[3][co][e])) + a.bias[p * a.Cout + co];
         const int sy = p == 2 ? a.H + line : line, sx0 = p == 1 ? a.W + s0 : s0;
-        a.out[((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx0 + e] = v;
+        const size_t o = ((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx0 + e;
+        if (!FUSED || a.out) a.out[o] = v;
+        if (FUSED) sampler_element(sa, sc, (long long)o, v);
     }
 }
+static bool out_head_px_form(int C, int Cout) {
+    static const bool px_form = !(getenv("S3D_OUT_HEAD") && strcmp(getenv("S3D_OUT_HEAD"), "0") == 0);
+    return px_form && (C == 64 || C == 128 || C == 256) && Cout <= 16;
+}
+bool out_head_fuses_sampler(int C, int Cout) { return out_head_px_form(C, Cout); }
+// fuse != null: the sampler update of one denoising step is applied to the model output (fuse->model_out is ignored).  When
+// the pixel-chunk form takes the launch it happens in the same kernel and `out` may be null (the model output is then never
+// stored); otherwise `out` is required and the stand-alone k_sampler follows.
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const float* w, const float* bias,
-                    int Cout, int H, int W, int D, float* out, hipStream_t st) {
+                    int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse) {
     OutHeadArgs a;
     int maxpix = D * D ? 1 : 0;
     for (int p = 0; p < 3; ++p) {
@@ -1209,21 +1230,32 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
     thread_shape(x.C, a.cq, a.ppb);
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "out head: C=%d unsupported", x.C);
     if (!maxpix || !B) return 0;
-    static const bool px_form = !(getenv("S3D_OUT_HEAD") && strcmp(getenv("S3D_OUT_HEAD"), "0") == 0);
-    if (px_form && (x.C == 64 || x.C == 128 || x.C == 256) && Cout <= 16) {
+    if (fuse) S3D_CHECK(fuse->batch == B && fuse->per_sample == (long long)Cout * (H + D) * (W + D), S3D_ERR_INVALID, "out head: the sampler step does not match the model output's shape");
+    if (out_head_px_form(x.C, Cout)) {
         int segs[3];
         for (int p = 0; p < 3; ++p) { const int len = p == 2 ? a.h[p] : a.wd[p], lines = p == 2 ? a.wd[p] : a.h[p]; segs[p] = lines * cdiv(len, kOhPx); }
         const int corner = D * D ? std::min(64, cdiv(Cout * D * D, 256)) : 0;
         const dim3 grid(segs[0] + segs[1] + segs[2] + corner, B);
-        if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2]);
-        else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2]);
-        else hipLaunchKernelGGL((k_out_head_px<64>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2]);
+        s3d_sampler_args sa;
+        memset(&sa, 0, sizeof sa);
+        if (fuse) {
+            sa = *fuse;
+            if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+            else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+            else hipLaunchKernelGGL((k_out_head_px<64, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+        } else {
+            if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16, false>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+            else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32, false>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+            else hipLaunchKernelGGL((k_out_head_px<64, false>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
+        }
         S3D_HIP(hipGetLastError());
         return 0;
     }
+    S3D_CHECK(out, S3D_ERR_INVALID, "out head: this width needs a model-output buffer");
     size_t shm = std::max(size_t(64), size_t(a.ppb) * kOutCo * (a.cq + 1)) * sizeof(float);
     hipLaunchKernelGGL(k_out_head, dim3(cdiv(maxpix, a.ppb), 4, B), dim3(a.cq * a.ppb), shm, st, a);
     S3D_HIP(hipGetLastError());
+    if (fuse) { s3d_sampler_args sa = *fuse; sa.model_out = out; return launch_sampler(sa, st); }
     return 0;
 }
 
@@ -1275,41 +1307,13 @@ int launch_linear(const float* in, int B, int I, const float* W, const float* bi
 }
 
 // ------------------------------------------------------------------ sampler update
-// p_mean_variance (START_X | EPSILON, FIXED_* variance, clip) + p_sample / ddim_sample in one pass.
-// src/diffusion/gaussian_diffusion.py:233-327, 346-350, 396-440, 538-600.  Coefficients are the fp32
-// casts of the float64 tables, gathered per sample by t (as _extract_into_tensor does, :934-947).
+// the stand-alone form of s3d_sampler.h (s3d_sampler_step; the sampling loops use the form fused into the output head)
 __global__ void k_sampler(s3d_sampler_args a) {
     const long long n = a.batch * a.per_sample;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int b = int(i / a.per_sample);
-        const int t = int(a.t[b]);
-        const float sr = a.tables[S3D_TAB_SQRT_RECIP * a.T + t], srm1 = a.tables[S3D_TAB_SQRT_RECIPM1 * a.T + t];
-        const float xt = a.x[i];
-        float x0 = a.model_out[i];
-        if (a.mean_type == S3D_MEAN_EPSILON) x0 = sr * xt - srm1 * x0;
-        if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-        const float nz = t != 0 ? 1.f : 0.f;
-        if (a.mode == S3D_STEP_DDIM) {
-            if (a.y0 && a.mask) {
-                const float m = a.mask[i], mixed = m * a.y0[i] + (1.f - m) * x0;
-                x0 = a.is_mask_t0 ? mixed : mixed * nz + x0 * (1.f - nz);
-            }
-            const float eps = (sr * xt - x0) / srm1;
-            const float ab = a.tables[S3D_TAB_ACP * a.T + t], abp = a.tables[S3D_TAB_ACP_PREV * a.T + t];
-            const float sigma = a.eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
-            const float mean_pred = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * eps;
-            const float nv = a.noise ? a.noise[i] : 0.f;
-            a.sample[i] = mean_pred + nz * sigma * nv;
-            a.pred_xstart[i] = x0;
-        } else {
-            const float mean = a.tables[S3D_TAB_COEF1 * a.T + t] * x0 + a.tables[S3D_TAB_COEF2 * a.T + t] * xt;
-            if (a.mean) a.mean[i] = mean;
-            a.pred_xstart[i] = x0;
-            if (a.mode == S3D_STEP_DDPM) {
-                const float lv = a.tables[S3D_TAB_LOGVAR * a.T + t];
-                a.sample[i] = mean + nz * expf(0.5f * lv) * a.noise[i];
-            }
-        }
+        const SamplerCoef c = sampler_coef(a, int(a.t[b]));
+        sampler_element(a, c, i, a.model_out[i]);
     }
 }
 int launch_sampler(const s3d_sampler_args& a, hipStream_t st) {

@@ -64,7 +64,7 @@ struct ConvWT {
     size_t rcol_T[3] = {0, 0, 0};
 };
 struct ResBlockWT { ConvWT c1, c2, skip; };
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD, PK_WINO24S_T };
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD, PK_WINO24S_T };
 struct PackDesc {                     // one device-side repacking job: flat reference-layout parameter -> packed image
     int kind, cout, ctot, cin, slot, taps, col_varying, to_tbuf;
     long long src, dst, n;
@@ -80,7 +80,6 @@ struct s3d_unet {
     std::vector<ParamSpec> specs;
     std::map<std::string, std::vector<float>> host;     // as handed to set_param (PyTorch layouts)
     bool packed = false;
-    bool wino44_current = false;                         // the F(4x4) weight images match the parameters (host pack only)
 
     // packed parameters, one device allocation, offsets in floats
     DevBuf wbuf;
@@ -111,19 +110,6 @@ struct s3d_unet {
     Tape tape;
     const float* tdev(size_t off) const { return static_cast<const float*>(tbuf.p) + off; }
 
-    // counters of the in-launch producer hand-off (s3d_rank1.h): zeroed once, targets are cumulative (host mirror: sync_expect)
-    DevBuf sync_ws;
-    unsigned sync_expect[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int sync_counters(hipStream_t st, unsigned** out) {
-        if (!sync_ws.p) {
-            S3D_TRY(sync_ws.reserve(kSyncWordsBytes));
-            S3D_HIP(hipMemsetAsync(sync_ws.p, 0, kSyncWordsBytes, st));
-            memset(sync_expect, 0, sizeof sync_expect);
-        }
-        *out = static_cast<unsigned*>(sync_ws.p);
-        return 0;
-    }
-
     // optional live timing of the convolution launches (s3d_unet_profile)
     struct ProfRec { int cls; hipEvent_t e0, e1; double flops, mfma_flops; };
     int prof_every = 0;
@@ -139,8 +125,8 @@ struct s3d_unet {
         else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
         return e;
     }
-    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st, R1Inline* r1 = nullptr) {
-        if (!prof_now) return launch_conv(kind, ca, st, r1, sync_expect);
+    int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
+        if (!prof_now) return launch_conv(kind, ca, st);
         // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
         int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : (kind == CONV_1x3_ROLL ? 9 : 25)));
         double pix = 0;
@@ -148,7 +134,7 @@ struct s3d_unet {
         ProfRec r{cls, prof_event(), prof_event(), 2.0 * taps * ca.cin * ca.cout * pix * ca.B, 0.0};
         r.mfma_flops = r.flops * conv_exec_fraction(kind, ca);
         if (r.e0) (void)hipEventRecord(r.e0, st);
-        int rc = launch_conv(kind, ca, st, r1, sync_expect);
+        int rc = launch_conv(kind, ca, st);
         if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
         if (r.e1) (void)hipEventRecord(r.e1, st);
         prof_recs.push_back(r);
@@ -178,8 +164,10 @@ namespace s3d {
 int pack_all(s3d_unet* m);
 int launch_repack_generic(const PackDesc* descs_dev, int ndesc, int blocks, const float* flat, float* wbuf, float* tbuf, hipStream_t st);
 // ext_film != null: the FiLM table [B or 1][film_total] is given (s3d_unet_film), t is not read
+// fuse != null: one denoising step — the sampler update is applied to the model output by the output head; `out` may then be
+// null (the model output is not stored)
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape, const float* ext_film = nullptr, int ext_film_stride = 0);
+                Tape* tape, const float* ext_film = nullptr, int ext_film_stride = 0, const s3d_sampler_args* fuse = nullptr);
 
 struct Fwd {
     s3d_unet* m;
@@ -234,24 +222,19 @@ struct Fwd {
     }
 
     // K slices of the rank-1 tables of the rollout convolution `cw` over the activated tensor y (s3d_rank1.h): 2 when that launch
-    // goes to k_conv_wino24s (the only reader that adds slices), from 256 own channels on; 1 otherwise
+    // goes to the mixed Winograd kernels (the only readers that add slices), from 256 own channels on; 1 otherwise
     int r1_slices_for(const Tri& y, const ConvW& cw) const {
-        if (cw.k != 3 || !cw.rollout || conv_use_naive() || conv_rank1_inline_enabled() || conv_rank1_fused_enabled()) return 1;
-        if (cw.wino24[0] == 0 || conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) != 1) return 1;
-        if (!tape && cw.wino44[0] != 0 && m->wino44_current && conv_wino44_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B)) return 1;
-        if (conv_wino24_persistent_enabled()) return 1;
+        if (cw.k != 3 || !cw.rollout || conv_use_naive()) return 1;
+        if (cw.wino24s[0] == 0 || !conv_wino24_channels(cw.cin, cw.cout)) return 1;
         return conv_rank1_slices(y.C);
     }
     // workspace of a rollout convolution's rank-1 terms for the activated tensor y: axis-sum partials, mean vectors, tables
     int roll_buffers(const Tri& y, const ConvW& cw, bool roll, MeanPartials& mp, MeanVecs& mv, const float* rrow[3], const float* rcol[3]) {
         for (int p = 0; p < 3; ++p) { rrow[p] = rcol[p] = nullptr; }
         if (!roll) return 0;
-        // the six mean vectors are ONE allocation: the in-launch producers store them through one buffer descriptor
         size_t mtot = 0;
         for (int p = 0; p < 3; ++p) mtot += size_t(B) * (y.g.h[p] + y.g.w[p]) * y.C;
-        S3D_CHECK(mtot * 4 < (size_t(1) << 31), S3D_ERR_INVALID, "rollout mean vectors exceed 2 GiB");
-        float* means = ar().alloc<float>(mtot);
-        mv.base = means; mv.bytes = mtot * 4;
+        float* means = ar().alloc<float>(mtot);            // (one allocation, as in round 3: the arena layout is unchanged)
         for (int p = 0; p < 3; ++p) {
             const int h = y.g.h[p], w = y.g.w[p];
             const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
@@ -265,49 +248,8 @@ struct Fwd {
         }
         return 0;
     }
-    // The rollout's means + tables of an activated tensor, not yet enqueued: the 3x3 convolution that consumes the tables
-    // takes them into its own launch as producer blocks (s3d_rank1.h); anything else flushes them as two stand-alone launches.
-    struct PendingR1 {
-        bool active = false;
-        Tri y; const ConvW* cw = nullptr; MeanPartials mp; MeanVecs mv;
-        const float* rrow[3]; const float* rcol[3];
-    } pend;
-    int defer_rank1(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
-        S3D_TRY(flush_rank1());
-        if (!conv_rank1_inline_enabled() || conv_use_naive()) return rank1_tables(y, cw, mp, mv, rrow, rcol);
-        pend.active = true; pend.y = y; pend.cw = &cw; pend.mp = mp; pend.mv = mv;
-        for (int p = 0; p < 3; ++p) { pend.rrow[p] = rrow[p]; pend.rcol[p] = rcol[p]; }
-        return 0;
-    }
-    int flush_rank1() {
-        if (!pend.active) return 0;
-        pend.active = false;
-        return rank1_tables(pend.y, *pend.cw, pend.mp, pend.mv, pend.rrow, pend.rcol);
-    }
-    void fill_r1(R1Inline& r1, const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
-        r1.nprod = 1;                                   // (the launcher fills in the layout)
-        r1.cin = y.C;
-        r1.mf = means_finalize_args(y.g, y.C, B, mp, mv);
-        // row-varying / column-varying vector of each plane
-        const float* rowvec[3] = {mv.rowmean[1], mv.rowmean[0], mv.colmean[0]};   // xy<-mean_d xz ; xz<-mean_w xy ; yz<-mean_h xy
-        const float* colvec[3] = {mv.rowmean[2], mv.colmean[2], mv.colmean[1]};   // xy<-mean_d yz ; xz<-mean_w yz ; yz<-mean_h xz
-        for (int p = 0; p < 3; ++p) {
-            r1.job[2 * p] = R1Job{rowvec[p], m->dev(cw.rrow[p]), const_cast<float*>(rrow[p]), y.g.h[p], 0, 0};
-            r1.job[2 * p + 1] = R1Job{colvec[p], m->dev(cw.rcol[p]), const_cast<float*>(rcol[p]), y.g.w[p], 0, 0};
-        }
-    }
     // th.mean over the axes + the six 1-D convolutions of the mean vectors (one launch each)
     int rank1_tables(const Tri& y, const ConvW& cw, const MeanPartials& mp, const MeanVecs& mv, const float* const rrow[3], const float* const rcol[3]) {
-        if (conv_rank1_fused_enabled() && !conv_use_naive() && mv.base && cw.cout % 4 == 0) {
-            // one launch: A blocks finalize the means, B blocks wait for them in-launch and build the tables (s3d_rank1.h)
-            R1Inline r1; memset(&r1, 0, sizeof r1);
-            fill_r1(r1, y, cw, mp, mv, rrow, rcol);
-            S3D_TRY(m->sync_counters(st, &r1.sync));
-            double pos = 0;
-            for (int p = 0; p < 3; ++p) pos += y.g.h[p] + y.g.w[p];
-            const double fl = 2.0 * 9 * y.C * cw.cout * pos * B;
-            return m->timed_launch(2, fl, fl, st, [&]() { return launch_rank1_fused(r1, cw.cout, B, m->sync_expect, st); });
-        }
         S3D_TRY(launch_means_finalize(y.g, y.C, B, mp, mv, st));
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = y.C; ca.cout = cw.cout; ca.njobs = 6;
@@ -347,7 +289,7 @@ struct Fwd {
         if (measuring) return 0;
         S3D_TRY(launch_gn_act(x, B, stats, aa, y, roll ? &mp : nullptr, st, add_parts ? &x.part : nullptr));
         if (!roll) return 0;
-        return defer_rank1(y, *cw, mp, mv, rrow, rcol);
+        return rank1_tables(y, *cw, mp, mv, rrow, rcol);
     }
 
     // want_stats (3x3 MFMA paths only): 1 = reduce the GroupNorm statistics of the output (partials in the epilogue +
@@ -357,13 +299,9 @@ struct Fwd {
         hipStream_t st = on ? on : this->st;
         out = alloc_tri(cw.cout, y.g);
         if (!(cw.k == 3 && !conv_use_naive())) want_stats = 0;
-        // the mixed Winograd kernel serves every forward (the tape keeps activations, not conv internals) and, on the transposed
+        // the mixed Winograd kernels serve every forward (the tape keeps activations, not conv internals) and, on the transposed
         // image, the backward's dgrad (s3d_train.hip:conv_bwd)
-        // F(4x4) for inference launches with many tiles (the choice includes the batch; never under a training tape, whose
-        // backward pass has the mixed kernel's transposed operators)
-        const bool w44 = !tape && cw.k == 3 && cw.wino44[0] != 0 && m->wino44_current && !conv_use_naive() &&
-                         conv_wino44_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B);
-        const int w24 = w44 ? 3 : (cw.k == 3 && cw.wino24[0] != 0 ? conv_wino24_geo(y.g.h, y.g.w, 3, cw.cin, cw.cout, B) : 0);
+        const bool w24 = cw.k == 3 && cw.wino24s[0] != 0 && conv_wino24_channels(cw.cin, cw.cout);
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);
@@ -374,19 +312,6 @@ struct Fwd {
             else out.part = part;
         }
         if (ar().measuring) return 0;
-        // this convolution's own rollout tables still pending: its launch produces them itself when it is the mixed Winograd
-        // kernel on this stream; every other case gets the two stand-alone launches first
-        R1Inline r1; r1.nprod = 0;
-        if (pend.active) {
-            const bool mine = rrow && rcol && rrow[0] == pend.rrow[0] && w24 == 1 && !on && cw.cout % 8 == 0 && pend.cw == &cw;   // (w24 == 3: F(4x4) -> flushed)
-            if (!mine) S3D_TRY(flush_rank1());
-            else {
-                pend.active = false;
-                memset(&r1, 0, sizeof r1);
-                fill_r1(r1, pend.y, cw, pend.mp, pend.mv, rrow, rcol);
-                S3D_TRY(m->sync_counters(st, &r1.sync));
-            }
-        }
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = B; ca.cin = cw.cin; ca.cout = cw.cout; ca.njobs = 3;
         if (want_stats) { ca.gn_sg = gn_subgroup(cw.cout); ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; }
@@ -395,15 +320,13 @@ struct Fwd {
             ConvJob& J = ca.job[p];
             J.in = y.p[p]; J.wgt = m->dev(cw.dense[p]); J.bias = no_bias ? nullptr : m->dev(cw.bias[p]);
             J.wgt_wino = cw.k == 3 && !w24 ? m->dev(cw.wino[p]) : nullptr;     // (the repack plan keeps only the image in use current)
-            J.wgt_wino24 = w24 ? m->dev(cw.wino24[p]) : nullptr;
             J.wgt_wino24s = w24 ? m->dev(cw.wino24s[p]) : nullptr;
-            J.wgt_wino44 = w44 ? m->dev(cw.wino44[p]) : nullptr;
             J.bbias = bbias; J.bbias_stride = fstride();
             J.rrow = rrow ? rrow[p] : nullptr; J.rcol = rcol ? rcol[p] : nullptr;
             J.res = res ? res->p[p] : nullptr; J.res_up = res && res_up ? 1 : 0; J.out = out.p[p]; J.h = y.g.h[p]; J.w = y.g.w[p];
             J.gn_part = want_stats ? part.p + size_t(p) * part.maxparts * part.nsub * 2 : nullptr;
         }
-        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st, r1.nprod ? &r1 : nullptr));
+        S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
         if (want_stats == 1) S3D_TRY(launch_gn_finalize(part, y.g, cw.cout, B, gs, st));
         return 0;
     }
@@ -444,7 +367,7 @@ struct Fwd {
             S3D_TRY(roll_buffers(y1, rb.c1, roll, mp, mv, rr, rc));
             if (!measuring) {
                 S3D_TRY(launch_gn_act_cat(u, sk, B, stats, aa, y1, roll ? &mp : nullptr, st));
-                if (roll) S3D_TRY(defer_rank1(y1, rb.c1, mp, mv, rr, rc));
+                if (roll) S3D_TRY(rank1_tables(y1, rb.c1, mp, mv, rr, rc));
             }
         }
         S3D_TRY(conv(y1, rb.c1, ssn ? nullptr : film_ptr, rr, rc, nullptr, h1, 2));   // partials only (norm_act adds them)

@@ -98,7 +98,6 @@ int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, i
         ConvJob& J = ca.job[p];
         J.in = x.p[p]; J.wgt = wdev + cw.dense[p]; J.bias = wdev + cw.bias[p];
         J.wgt_wino = ksize == 3 ? wdev + cw.wino[p] : nullptr;
-        J.wgt_wino24 = ksize == 3 && cw.wino24[p] ? wdev + cw.wino24[p] : nullptr;
         J.wgt_wino24s = ksize == 3 && cw.wino24s[p] ? wdev + cw.wino24s[p] : nullptr;
         J.rrow = tab_row[p]; J.rcol = tab_col[p]; J.out = o.p[p]; J.h = g.h[p]; J.w = g.w[p];
     }

@@ -90,8 +90,7 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             break;
         }
         case PK_WINO24S_T:
-        case PK_WINO24S:
-        case PK_WINO24: {                        // item = one (n, k) filter: G2 g G4^T, fragment order [n32][k8][24][64][4] / [n32][k16][24][2][64][4]
+        case PK_WINO24S: {                       // item = one (n, k) filter: G2 g G4^T, fragment order [n32][k16][24][2][64][4]
             // operator dims as in PK_WINO: forward N = cout, K = cin; transposed (dgrad) N = cin, K = cout, taps flipped
             const bool tr = d.kind == PK_WINO24S_T;
             const int K = tr ? cout : cin;
@@ -108,15 +107,13 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) t[u][q] = G2[u][0] * g[0 * 3 + q] + G2[u][1] * g[1 * 3 + q] + G2[u][2] * g[2 * 3 + q];
-            const int k8t = K / 8;
-            const int nt = n >> 5, jn = n & 31, k8 = k >> 3, hf = (k >> 2) & 1, e = k & 3;
+            const int nt = n >> 5, e = k & 3;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int v = 0; v < 6; ++v) {
-                    const double uv = fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2]));       // as pack_wino24_weights
-                    if (d.kind == PK_WINO24) dst[((((size_t)nt * k8t + k8) * 24 + (u * 6 + v)) * 64 + (hf * 32 + jn)) * 4 + e] = float(uv);
-                    else dst[(((((size_t)nt * (K / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
+                    const double uv = fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2]));       // as pack_wino24s_weights
+                    dst[(((((size_t)nt * (K / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
                 }
             break;
         }
@@ -176,11 +173,10 @@ struct Plan {
             add(PK_DENSE_T, w, wt.dense_T[p], (long long)taps * cout * cin, cout, ctot, cin, taps, 0, 0, 1);
             if (k == 3) {
                 // the per-step repack writes only the images this process's kernels read (S3D_WINO is fixed per process): with
-                // the mixed kernel active the F(2x2) images and the 16x16-pixel variant's would be rewritten for nobody
+                // the mixed kernel active the F(2x2) images would be rewritten for nobody
                 const bool fwd24 = cw.wino24s[p] && conv_wino24_channels(cin, cout);
                 const bool bwd24 = cw.wino24s[p] && cout % 32 == 0 && conv_wino24_channels(cout, cin);
                 if (!fwd24) add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
-                if (cw.wino24[p] && (conv_wino24_big_enabled() || !fwd24)) add(PK_WINO24, w, cw.wino24[p], (long long)cout * cin, cout, ctot, cin, 9);
                 if (cw.wino24s[p]) add(PK_WINO24S, w, cw.wino24s[p], (long long)cout * cin, cout, ctot, cin, 9);
                 if (!bwd24) {      // transposed operator: cin outputs (padded to 32) x cout inputs
                     wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);

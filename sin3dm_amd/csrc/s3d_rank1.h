@@ -1,23 +1,11 @@
-// s3d_rank1.h — device bodies of the rollout's small dependent stages, shared by their stand-alone kernels
-// (k_means_finalize in s3d_kernels.hip, k_rank1 in s3d_conv.hip) and by the 3x3 convolution launch that runs them as
-// producer blocks ahead of its own tiles (k_conv_wino24s, s3d_wino24.hip):
+// s3d_rank1.h — device bodies of the rollout's small dependent stages (k_means_finalize in s3d_kernels.hip, k_rank1 in
+// s3d_conv.hip):
 //
 //   gn_act --(tile partial sums)--> means  --(six mean vectors)--> rank-1 tables --> convolution EPILOGUE
 //
-// The convolution's k-loop needs none of this, so with S3D_RANK1_INLINE=1 the three stages are ONE launch (built in round 3
-// on VERDICT r2's item 1, bit-identical, measured SLOWER and therefore off by default — profiles/r03_rank1_inline.txt):
-// blocks [0, na) finalize the means ("A"), blocks [na, na+nb) build the tables ("B"), the rest are convolution tiles ("C").
-// Hand-off inside the launch (MI355X: per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores):
-//   * payloads are written with 16-byte write-through (sc1) stores and read with sc1 loads — no agent-scope fence anywhere
-//     (a release would write back the XCD's dirty lines, i.e. the activation the C blocks are producing);
-//   * every writing wave drains its stores (s_waitcnt vmcnt(0)), the block meets at a barrier, ONE lane bumps a counter
-//     with a relaxed agent-scope atomic; A counters are sharded by block id & 7, B counters by plane;
-//   * consumers poll with relaxed agent-scope loads (one lane per counter), bounded: after ~20 ms a block raises the error
-//     word and goes on, so a scheduling surprise fails a test instead of hanging the GPU;
-//   * counters are never reset: the host hands every launch the cumulative value each counter must reach (launches on a
-//     handle are stream-ordered), compared wrap-safe.
-// Dead-lock freedom rests on block ids being dispatched in order (A before B before C; A waits for nothing).
-// Same arithmetic in the same order as the stand-alone kernels: results are bit-identical with the switch on or off.
+// Each stage is its own launch; stream order is the hand-off.  (Round 3 also ran the two stages as producer blocks inside the
+// 3x3 convolution launch and as one fused launch — bit-identical, measured slower, removed in round 4: DESIGN.md §12.1,
+// profiles/r03_rank1_inline.txt, commits c0b16ff / 6acaefc hold the code.)
 #pragma once
 #include "s3d_common.h"
 
@@ -25,41 +13,15 @@ namespace s3d {
 
 typedef float r1_f32x16 __attribute__((ext_vector_type(16)));
 typedef float r1_f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned r1_u32x4 __attribute__((ext_vector_type(4)));
 typedef const r1_f32x4 __attribute__((address_space(1)))* r1_gf4ptr;
-constexpr int kAuxSc1 = 16;                               // buffer-instruction aux bit 4 = sc1 (write-through / L1-bypass)
 
 constexpr int kR1Chunk = 128, kR1Ld = kR1Chunk + 4;
 constexpr int kR1LdsFloats = (34 + 2 * 32) * kR1Ld;       // A tile (34 rows) + two B tiles: 51 744 bytes
-constexpr int kSyncStride = 32;                           // counters 128 bytes apart
-constexpr int kSyncA = 0, kSyncB = 8, kSyncErr = 11, kSyncWords = 12 * kSyncStride;
-constexpr int kSpinLimit = 1 << 14;
-static_assert(size_t(kSyncWords) * 4 == kSyncWordsBytes, "s3d_common.h sizes the handle's counter buffer");
-
-__device__ __forceinline__ unsigned sync_load(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void sync_arrive(unsigned* p) { __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// the block has issued its payload stores: drain them, meet, one lane publishes
-__device__ __forceinline__ void sync_publish(unsigned* counter) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) sync_arrive(counter);
-}
-// spin until *p has reached target (wrap-safe); returns false after kSpinLimit polls
-__device__ __forceinline__ bool sync_wait(const unsigned* p, unsigned target, unsigned first) {
-    unsigned v = first;
-    for (int spin = 0; int(v - target) < 0; ++spin) {
-        if (spin >= kSpinLimit) return false;
-        __builtin_amdgcn_s_sleep(8);
-        v = sync_load(p);
-    }
-    return true;
-}
 
 // ------------------------------------------------------------------ stage A: th.mean over one axis of the activated planes
 // (src/diffusion/unet_triplane.py:38-46): add the tile partials in index order and divide by the axis length.
 // item = (vector, position, channel quad); four adjacent lanes share an item: lane k takes partials k, k+4, ... and the four
 // sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch).  gthread = global thread index.
-template <bool SC1>
 __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long long gthread) {
     const long long i = gthread >> 2;
     const int part0 = int(gthread & 3);
@@ -89,13 +51,7 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
     const float inv = 1.0f / float(is_col ? h : w);
     s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
     float* dst = (is_col ? a.colmean[p] : a.rowmean[p]) + (size_t(b) * len + pos) * a.C + q * 4;
-    if (SC1) {       // one descriptor for the launch: the six vectors are one allocation (Fwd::roll_buffers)
-        const r1_f32x4 v4 = {s.x, s.y, s.z, s.w};
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.mean_base, 0, int(a.mean_bytes), 0x00020000);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v4), rs, unsigned(reinterpret_cast<const char*>(dst) - reinterpret_cast<const char*>(a.mean_base)), 0, kAuxSc1);
-    } else {
-        *reinterpret_cast<float4*>(dst) = s;
-    }
+    *reinterpret_cast<float4*>(dst) = s;
 }
 
 // ------------------------------------------------------------------ stage B: rank-1 rollout tables (skinny GEMMs)
@@ -108,8 +64,6 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
 // three taps o of the SUMMED-OUT axis (interior o0+o1+o2, first o1+o2, last o0+o1, single o1), so only the three per-tap
 // products U_o are contracted — weights [tap][n][cin] with n = (co / 8) * 24 + o * 8 + co % 8, a block owns 32 positions x
 // 8 output channels = 24 weight rows — and the variants are formed while the four waves' partials are added.
-// SC1: the vector `vin` was written earlier in THIS launch (stage A): it is read with sc1 loads after `wait()` returns.
-// SC1_OUT: the table is consumed later in THIS launch: it leaves with 16-byte sc1 stores (requires cout % 4 == 0).
 // lds: kR1LdsFloats floats.
 // chunk0 / nch: the 128-channel K chunks this block contracts (0 / 0 = all).  A table may be cut into K SLICES, one per
 // chunk, written by different blocks to out + slice * slice_stride and added by the consuming convolution's epilogue in slice
@@ -119,9 +73,8 @@ __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long
 // same order as with NS = 1.  lds: kR1LdsFloats + (NS - 1) * 34 * kR1Ld floats.
 struct R1Block { const float* vin; const float* wgt; float* out; int L, cin, cout4, n_tiles_n, b, mtile, ntile; int chunk0 = 0, nch = 0; int bcount = 1; };
 
-template <bool ROLL3, bool SC1, bool SC1_OUT, int NS = 1, class Wait>
-__device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait wait) {
-    static_assert(NS == 1 || (!SC1 && !SC1_OUT), "the in-launch producers take one sample per block");
+template <bool ROLL3, int NS = 1>
+__device__ __forceinline__ void rank1_block(const R1Block& J, float* lds) {
     constexpr int kATile = 34 * kR1Ld;
     float* sA = lds;
     float* sB0 = lds + NS * kATile;
@@ -130,7 +83,6 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
     const int nchunks = (cin + kR1Chunk - 1) / kR1Chunk;   // the last chunk is narrower when cin % 128 != 0
     constexpr int q4 = kR1Chunk / 4;                        // float4 slots per staged row
     const float* vb = J.vin + size_t(b) * L * cin;
-    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vb), 0, L * cin * 4, 0x00020000);
     const size_t tapStride = ROLL3 ? size_t(J.n_tiles_n) * 24 * cin : size_t(cout4) * cin;
     const r1_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     r1_f32x16 acc[NS];
@@ -151,12 +103,8 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
             const int idx = it * 256 + tid, row = idx / q4, q = idx - row * q4;
             const int pos = mtile * 32 - 1 + row;
             const bool ok = row < 34 && pos >= 0 && pos < L && q < wq && n < J.bcount;
-            if (SC1) {                                      // out-of-range offset: the hardware returns zeros
-                ra[n][it] = __builtin_bit_cast(r1_f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, ok ? unsigned((pos * cin + c0 + q * 4) * 4) : 0x80000000u, 0, kAuxSc1));
-            } else {
-                ra[n][it] = ((r1_gf4ptr)(uintptr_t)(vb + (size_t(ok ? n : 0) * L + (ok ? pos : 0)) * cin + c0 + (ok ? q : 0) * 4))[0];
-                if (!ok) ra[n][it] = zero4;
-            }
+            ra[n][it] = ((r1_gf4ptr)(uintptr_t)(vb + (size_t(ok ? n : 0) * L + (ok ? pos : 0)) * cin + c0 + (ok ? q : 0) * 4))[0];
+            if (!ok) ra[n][it] = zero4;
         }
     };
     auto loadB = [&](int tap, int chunk) {
@@ -189,8 +137,7 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
 
     const int ch0 = J.nch > 0 ? J.chunk0 : 0;
     const int nstages = (J.nch > 0 ? J.nch : nchunks) * 3; // stage s -> chunk = ch0 + s / 3, tap = s % 3
-    loadB(0, ch0);                                         // the weights do not depend on stage A: requested before the wait
-    wait();
+    loadB(0, ch0);
     loadA(ch0);
     storeA(); storeB(0);
     __syncthreads();
@@ -240,21 +187,6 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
                 const int r = (p & 3) + 4 * (p >> 3), l = ((p >> 2) & 1) * 32 + o * 8 + c8;
                 return red[(0 * 16 + r) * 64 + l] + red[(1 * 16 + r) * 64 + l] + red[(2 * 16 + r) * 64 + l] + red[(3 * 16 + r) * 64 + l];
             };
-            if (SC1_OUT) {
-                // thread = (position, variant, channel quad of the block's eight): one 16-byte write-through store each
-                const int p = tid >> 3, var = (tid >> 1) & 3, c4 = (tid & 1) * 4;
-                const int row = mtile * 32 + p, co = ntile * 8 + c4;
-                r1_f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float u0 = usum(p, c4 + e, 0), u1 = usum(p, c4 + e, 1), u2 = usum(p, c4 + e, 2);
-                    v[e] = var == 0 ? (u0 + u1) + u2 : (var == 1 ? u1 + u2 : (var == 2 ? u0 + u1 : u1));
-                }
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(J.out + size_t(bs) * L * 4 * cout4, 0, L * 4 * cout4 * 4, 0x00020000);
-                if (row < L && co < cout4)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(r1_u32x4, v), rs, unsigned(((row * 4 + var) * cout4 + co) * 4), 0, kAuxSc1);
-                continue;
-            }
             const int p = tid >> 3, c8 = tid & 7;
             const float u0 = usum(p, c8, 0), u1 = usum(p, c8, 1), u2 = usum(p, c8, 2);
             const int row = mtile * 32 + p, co = ntile * 8 + c8;
@@ -271,39 +203,6 @@ __device__ __forceinline__ void rank1_block(const R1Block& J, float* lds, Wait w
             if (row < L && col < cout4) J.out[(size_t(bs) * L + row) * cout4 + col] = v;
         }
     }
-}
-
-// ------------------------------------------------------------------ the producer roles of a launch with r1.nprod > 0
-// block ids [0, na) finalize the mean vectors (A), [na, na + nb) build the rank-1 tables from them (B), [na + nb, nprod) are
-// padding.  TABLES_IN_LAUNCH: the tables' consumers are blocks of the same launch (the 3x3 convolution's tiles): write-through
-// stores + a per-plane counter; otherwise the next launch reads them (stream order is the hand-off).
-template <bool TABLES_IN_LAUNCH>
-__device__ __forceinline__ void r1_producer_role(const R1Inline& r1, int bid, float* lds) {
-    const int tid = threadIdx.x;
-    if (bid < r1.na) {
-        for (int it = 0; it < r1.a_iters; ++it) means_finalize_thread<true>(r1.mf, ((long long)bid * r1.a_iters + it) * 256 + tid);
-        sync_publish(r1.sync + (kSyncA + (bid & 7)) * kSyncStride);
-        return;
-    }
-    const int lb = bid - r1.na;
-    if (lb >= r1.nb) return;
-    int j = 0;
-#pragma unroll
-    for (int k = 1; k < 6; ++k) j += lb >= r1.job[k].block_begin ? 1 : 0;
-    const R1Job& J = r1.job[j];
-    int local = lb - J.block_begin;
-    R1Block blk;
-    blk.ntile = local % r1.n_tiles_n; local /= r1.n_tiles_n;
-    blk.b = local / J.tiles; blk.mtile = local % J.tiles;
-    blk.vin = J.vin; blk.wgt = J.wgt; blk.out = J.out; blk.L = J.L; blk.cin = r1.cin; blk.cout4 = r1.cout; blk.n_tiles_n = r1.n_tiles_n;
-    rank1_block<true, true, TABLES_IN_LAUNCH>(blk, lds, [&]() {
-        if (tid < 8) {                                       // one lane per A counter
-            const unsigned* c = r1.sync + (kSyncA + tid) * kSyncStride;
-            if (!sync_wait(c, r1.a_target[tid], sync_load(c))) __hip_atomic_store(r1.sync + kSyncErr * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    });
-    if (TABLES_IN_LAUNCH) sync_publish(r1.sync + (kSyncB + (j >> 1)) * kSyncStride);
 }
 
 }  // namespace s3d

@@ -329,7 +329,6 @@ int s3d_unet_train_attach(s3d_unet* m, float* params, int64_t numel) {
 }
 
 int s3d_unet_repack(s3d_unet* m, void* stream) {
-    if (m) m->wino44_current = false;                 // F(4x4) images are host-packed only: inference falls back to the mixed kernel until the next load_state_dict
     S3D_CHECK(m && m->flat, S3D_ERR_INVALID, "repack: call s3d_unet_train_attach first");
     return launch_repack(m, static_cast<hipStream_t>(stream));
 }

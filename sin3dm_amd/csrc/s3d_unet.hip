@@ -103,9 +103,7 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
                 for (int c = 0; c < cin; ++c) d[(size_t(t) * cout + co) * cin + c] = W[(size_t(co) * ctot + c) * taps + t];
         if (k == 3) cw.wino[p] = pack_wino_weights(stage, W, cout, ctot, cin);
         if (k == 3 && cin % 32 == 0) {
-            cw.wino24[p] = pack_wino24_weights(stage, W, cout, ctot, cin);
             cw.wino24s[p] = pack_wino24s_weights(stage, W, cout, ctot, cin);
-            if (conv_wino44_enabled() && cout % 4 == 0) cw.wino44[p] = pack_wino44_weights(stage, W, cout, ctot, cin);
         }
         if (!roll) continue;
         const bool a_is_col = (p == 0);          // slot A column-varying only for xy; slot B is the other kind
@@ -215,14 +213,13 @@ int pack_all(s3d_unet* m) {
     S3D_TRY(upload(m->wbuf, m->stage.data(), m->stage.size() * sizeof(float)));
     m->stage.clear(); m->stage.shrink_to_fit();
     m->packed = true;
-    m->wino44_current = true;                         // (the device-side repack of the training tier does not rebuild the F(4x4) images)
     return 0;
 }
 
 // ------------------------------------------------------------------ forward
 
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape, const float* ext_film, int ext_film_stride) {
+                Tape* tape, const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse) {
     const s3d_unet_cfg& c = m->cfg;
     const int mc = c.model_channels, ted = 4 * mc;
     Fwd f{m, B, st, nullptr};
@@ -331,16 +328,17 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         h = o;
         (void)level;
     }
-    S3D_TRY(f.flush_rank1());                       // (every rollout convolution takes its tables into its own launch: nothing is left)
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
     GnStats stats;
     S3D_TRY(f.stats_of(h, stats));
     if (tape) { tape->head_in = h; tape->head_stats = stats; tape->arena_off = ar.off; tape->valid = !meas; }
+    // a fused step on a width the pixel-chunk head does not take: the model output goes through a workspace buffer
+    if (fuse && !out && !out_head_fuses_sampler(h.C, c.out_channels)) out = ar.alloc<float>(size_t(B) * c.out_channels * (H + D) * (W + D));
     if (!meas) {
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
         aa.film = nullptr; aa.film_stride = 0;
-        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st));
+        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st, fuse));
     }
     return 0;
 }
@@ -394,7 +392,7 @@ int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data, const i
 }
 
 static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
-                        const float* ext_film, int ext_film_stride);
+                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse = nullptr);
 
 int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream) {
     S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "unet_forward: null argument");
@@ -425,23 +423,35 @@ int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film, int fi
     return forward_impl(m, x, nullptr, B, H, W, D, out, stream, film, film_stride);
 }
 
+int s3d_unet_step_film(s3d_unet* m, const float* film, int film_stride, int B, int H, int W, int D, const s3d_sampler_args* step,
+                       float* model_out, void* stream) {
+    S3D_CHECK(m && film && step, S3D_ERR_INVALID, "unet_step_film: null argument");
+    S3D_CHECK(film_stride == 0 || film_stride == m->film_total, S3D_ERR_INVALID, "unet_step_film: film_stride must be 0 or %d", m->film_total);
+    S3D_CHECK(step->x && step->t && step->tables && step->pred_xstart && (step->mode == S3D_STEP_MEAN_ONLY || step->sample) &&
+                  (step->mode != S3D_STEP_DDPM || step->noise),
+              S3D_ERR_INVALID, "unet_step_film: incomplete sampler arguments");
+    S3D_CHECK(step->batch == B && step->per_sample == (long long)m->cfg.out_channels * (H + D) * (W + D) && m->cfg.in_channels == m->cfg.out_channels,
+              S3D_ERR_INVALID, "unet_step_film: the step's shape is not the model's");
+    return forward_impl(m, step->x, nullptr, B, H, W, D, model_out, stream, film, film_stride, step);
+}
+
 }  // extern "C"
 
 static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
-                        const float* ext_film, int ext_film_stride) {
+                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse) {
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "unet_forward: B,H,W,D must be >= 1");
     if (!m->packed) S3D_TRY(pack_all(m));
     m->tape.valid = false;                    // the workspace is shared with the training tape
     hipStream_t st = static_cast<hipStream_t>(stream);
     // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows).  The walk is pure host
     // work and depends only on the shapes: skipped when they repeat (every step of a sampling loop).
-    const long long key[4] = {B, H, W, D};
+    const long long key[4] = {B, H, W, D | (fuse && !out ? 1LL << 40 : 0)};      // (a fused step without a caller buffer may need one from the workspace)
     const bool same = m->inf_key[0] == key[0] && m->inf_key[1] == key[1] && m->inf_key[2] == key[2] && m->inf_key[3] == key[3];
     int rc = 0;
     if (!same || m->inf_high > m->arena.buf.cap) {
         m->arena.measuring = true;
         m->arena.high = 0;
-        rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride);
+        rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride, fuse);
         m->arena.measuring = false;
         if (rc) return rc;
         m->inf_high = m->arena.high;
@@ -454,7 +464,7 @@ static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int 
     m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
     ++m->fwd_count;
     if (m->prof_now) ++m->prof_forwards;
-    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride);
+    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride, fuse);
     m->prof_now = false;
     return rc;
 }
@@ -486,17 +496,6 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
     m->prof_recs.clear();
     out->forwards += m->prof_forwards;
     m->prof_forwards = 0;
-    return 0;
-}
-
-int s3d_unet_sync_errors(s3d_unet* m, int* err) {
-    S3D_CHECK(m && err, S3D_ERR_INVALID, "unet_sync_errors: null argument");
-    *err = 0;
-    if (!m->sync_ws.p) return 0;
-    S3D_HIP(hipDeviceSynchronize());
-    unsigned v = 0;
-    S3D_HIP(hipMemcpy(&v, static_cast<const unsigned*>(m->sync_ws.p) + 11 * 32, sizeof v, hipMemcpyDeviceToHost));
-    *err = int(v);
     return 0;
 }
 

@@ -179,25 +179,35 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ one fused update
     def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta=0.0, y0=None, mask=None,
-              is_mask_t0=False, want_mean=False):
+              is_mask_t0=False, want_mean=False, fuse=False, noise=None):
+        """fuse (the sampling loops): when the denoiser offers `denoise_step` and the timestep values are known on the host,
+        the UNet's output head applies the update itself — one launch instead of head + sampler kernel, and the model output
+        never reaches memory (SURVEY.md section 2b, K8 + K9).  noise: this step's eps when the caller drew it ahead."""
         _lib.require_gpu(x)
         if model_kwargs is None:
             model_kwargs = {}
         B, Cc = x.shape[:2]
         assert t.shape == (B,)
         x = x.contiguous().float()
-        model_output = model(x, self._scale_timesteps(t), **model_kwargs)
-        assert model_output.shape == x.shape, "learned-variance outputs are not supported on this path"
-        if denoised_fn is not None:
-            if self.model_mean_type != ModelMeanType.START_X:
-                raise NotImplementedError("denoised_fn with epsilon prediction")
-            model_output = denoised_fn(model_output)
-        model_output = model_output.contiguous()
+        step_fn = getattr(model, "denoise_step", None) if fuse else None
+        ts = self._scale_timesteps(t)
+        fused = (step_fn is not None and denoised_fn is None and host_values_of(ts) is not None
+                 and mode in (_lib.STEP_DDPM, _lib.STEP_DDIM) and not want_mean and set(model_kwargs) == {"H", "W", "D"})
+        model_output = None
+        if not fused:
+            model_output = model(x, ts, **model_kwargs)
+            assert model_output.shape == x.shape, "learned-variance outputs are not supported on this path"
+            if denoised_fn is not None:
+                if self.model_mean_type != ModelMeanType.START_X:
+                    raise NotImplementedError("denoised_fn with epsilon prediction")
+                model_output = denoised_fn(model_output)
+            model_output = model_output.contiguous()
         sample = th.empty_like(x) if mode != _lib.STEP_MEAN_ONLY else None
         pred = th.empty_like(x)
         mean = th.empty_like(x) if want_mean else None
-        noise = None
-        if mode == _lib.STEP_DDPM or (mode == _lib.STEP_DDIM):
+        if noise is not None:
+            assert noise.shape == x.shape and noise.is_contiguous()
+        elif mode == _lib.STEP_DDPM or (mode == _lib.STEP_DDIM):
             # the reference draws randn_like on every step, t == 0 and eta == 0 included (:431, :591):
             # keep the generator stream identical
             noise = self._noise(x).contiguous()
@@ -210,12 +220,16 @@ class GaussianDiffusion:
         t64 = t.to(device=x.device, dtype=th.int64).contiguous()
         a = _lib.SamplerArgs(mode=mode, mean_type=self._mean_type_code(), clip_denoised=int(bool(clip_denoised)),
                              is_mask_t0=int(bool(is_mask_t0)), eta=float(eta), T=self.num_timesteps, batch=B,
-                             per_sample=x[0].numel(), model_out=model_output.data_ptr(), x=x.data_ptr(),
+                             per_sample=x[0].numel(), model_out=model_output.data_ptr() if model_output is not None else None,
+                             x=x.data_ptr(),
                              noise=noise.data_ptr() if noise is not None else None, t=t64.data_ptr(),
                              tables=tab.data_ptr(), y0=y0.data_ptr() if y0 is not None else None,
                              mask=mask.data_ptr() if mask is not None else None,
                              sample=sample.data_ptr() if sample is not None else None, pred_xstart=pred.data_ptr(),
                              mean=mean.data_ptr() if mean is not None else None)
+        if fused:
+            step_fn(x, ts, a, **model_kwargs)
+            return sample, pred, mean
         with th.cuda.device(x.device):
             _lib.check(_lib.load().s3d_sampler_step(a, _lib.stream_ptr()))
         return sample, pred, mean
@@ -247,7 +261,16 @@ class GaussianDiffusion:
         return {"sample": sample, "pred_xstart": pred}
 
     # ------------------------------------------------------------------ loops
-    def _loop(self, step_fn, model, shape, noise, device, progress, **kw):
+    _NOISE_AHEAD_BYTES = 256 << 20      # eps of this many bytes' worth of steps is drawn by ONE randn launch
+
+    def _loop(self, mode, model, shape, noise, device, progress, clip_denoised=True, denoised_fn=None, cond_fn=None,
+              model_kwargs=None, **kw):
+        """Shared body of p_sample_loop_progressive / ddim_sample_loop_progressive (:488-536, 687-734).  Every step is ONE call
+        into the library when the denoiser is the HIP UNet (`_step(fuse=True)`); the per-step eps comes from the device
+        generator like the reference's randn_like on a GPU, drawn for many steps at a time (`noise_fn`, if set, is asked every
+        step instead).  The single-step API (p_sample / ddim_sample) keeps the forward + sampler-kernel pair."""
+        if cond_fn is not None:
+            raise NotImplementedError("cond_fn guidance is out of scope (no caller in the reference)")
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
@@ -261,17 +284,31 @@ class GaussianDiffusion:
         prepare = getattr(self, "_prepare_loop", None)
         if prepare is not None:
             prepare(model, shape[0], device)         # per-schedule caches (timestep map, FiLM tables) in one go
-        for i in indices:
+        ahead, ahead_k = None, 0
+        per_step = 4
+        for d in shape:
+            per_step *= int(d)
+        chunk = max(1, min(self.num_timesteps, self._NOISE_AHEAD_BYTES // max(per_step, 1)))
+        for n, i in enumerate(indices):
             t = HostTimesteps(all_t[i], (i,) * shape[0])
+            eps = None
+            if self.noise_fn is None:
+                if ahead is None or ahead_k == ahead.shape[0]:
+                    ahead = th.randn((min(chunk, self.num_timesteps - n),) + tuple(shape), device=device)
+                    ahead_k = 0
+                eps = ahead[ahead_k]
+                ahead_k += 1
             with th.no_grad():
-                out = step_fn(model, img, t, **kw)
+                sample, pred, _ = self._step(mode, model, img, t, clip_denoised, denoised_fn, model_kwargs, fuse=True,
+                                             noise=eps, **kw)
+                out = {"sample": sample, "pred_xstart": pred}
                 yield out
                 img = out["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False):
         """Generator over the per-step dicts of p_sample (:488-536)."""
-        yield from self._loop(self.p_sample, model, shape, noise, device, progress, clip_denoised=clip_denoised,
+        yield from self._loop(_lib.STEP_DDPM, model, shape, noise, device, progress, clip_denoised=clip_denoised,
                               denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs)
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
@@ -288,7 +325,7 @@ class GaussianDiffusion:
                                      cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0, y0=None,
                                      mask=None, is_mask_t0=False):
         """Generator over the per-step dicts of ddim_sample (:687-734)."""
-        yield from self._loop(self.ddim_sample, model, shape, noise, device, progress, clip_denoised=clip_denoised,
+        yield from self._loop(_lib.STEP_DDIM, model, shape, noise, device, progress, clip_denoised=clip_denoised,
                               denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta, y0=y0,
                               mask=mask, is_mask_t0=is_mask_t0)
 

@@ -134,6 +134,24 @@ class _WrappedModel:
     def __getattr__(self, name):          # forward_train / backward_flat / flat_parameters of the wrapped denoiser
         return getattr(self.__dict__["model"], name)
 
+    def _mapped_host(self, ts):
+        """HostTimesteps of the ORIGINAL step values for host-known respaced indices (one cached device tensor per batch of values)."""
+        mapped = tuple(self._mapped(v) for v in host_values_of(ts))
+        ck = (str(ts.device), mapped)
+        new_ts = self._maps.get(ck)
+        if new_ts is None:
+            new_ts = self._maps[ck] = HostTimesteps(th.tensor(mapped, device=ts.device, dtype=th.float32), mapped)
+        return new_ts
+
+    @property
+    def denoise_step(self):
+        """The denoiser's fused step (UNet + sampler update in the output head), with the same timestep mapping as __call__;
+        None when the denoiser has none (GaussianDiffusion._step then runs the two-kernel path)."""
+        inner = getattr(self.model, "denoise_step", None)
+        if inner is None:
+            return None
+        return lambda x, ts, step, **kw: inner(x, self._mapped_host(ts), step, **kw)
+
     def __call__(self, x, ts, **kwargs):
         # the map is kept in float32: the denoiser embeds float timesteps anyway (nn.py:113), so one gather replaces the
         # reference's integer gather + cast (exact: indices < 2^24)
@@ -141,12 +159,7 @@ class _WrappedModel:
         hv = host_values_of(ts)
         if hv is not None:
             # the loop told us the values: map them on the host, one cached device tensor per distinct batch of values
-            mapped = tuple(self._mapped(v) for v in hv)
-            ck = (key, mapped)
-            new_ts = self._maps.get(ck)
-            if new_ts is None:
-                new_ts = self._maps[ck] = HostTimesteps(th.tensor(mapped, device=ts.device, dtype=th.float32), mapped)
-            return self.model(x, new_ts, **kwargs)
+            return self.model(x, self._mapped_host(ts), **kwargs)
         m = self._maps.get(key)
         if m is None:
             m = self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=th.float32)

@@ -271,12 +271,6 @@ class _TriplaneUNetBase(nn.Module):
         """Name of the kernel the most recent timed launch of class cls (0: 3x3, 1: 1x1, 2: rank-1) dispatched."""
         return (_lib.load().s3d_unet_profile_kernel(self._handle, int(cls)) or b"").decode()
 
-    def sync_errors(self):
-        """0 unless an in-launch hand-off of the rollout tables ever timed out (then results are invalid); synchronises."""
-        err = C.c_int(0)
-        _lib.check(_lib.load().s3d_unet_sync_errors(self._ensure_handle() and self._handle, C.byref(err)))
-        return int(err.value)
-
     def convert_to_fp16(self):
         raise NotImplementedError("fp16 is not runnable in the reference (see __init__)")
 
@@ -312,6 +306,25 @@ class _TriplaneUNetBase(nn.Module):
                                                 _lib.ptr(out), _lib.stream_ptr()))
         assert out.shape == x.shape or y is not None
         return out
+
+    def denoise_step(self, x, timesteps, step, H=None, W=None, D=None):
+        """One step of a sampling loop in one library call: this forward (host-known `timesteps`) with the sampler update
+        `step` (_lib.SamplerArgs with x / noise / tables / outputs set; its model_out is ignored) applied by the output
+        head's launch — src/diffusion/unet_triplane.py:465-510 + gaussian_diffusion.py:396-440 / 538-600.  The model output
+        is not materialised.  Results equal forward() followed by s3d_sampler_step bit for bit."""
+        assert H is not None and W is not None and D is not None
+        _lib.require_gpu(x)
+        hv = getattr(timesteps, "host_values", None)
+        B = x.shape[0]
+        assert hv is not None and len(hv) == B, "denoise_step needs host-known timesteps (HostTimesteps)"
+        assert x.is_contiguous() and x.dtype == th.float32 and x.data_ptr() == step.x
+        assert x.shape[1] == self.in_channels == self.out_channels and x.shape[2] == H + D and x.shape[3] == W + D
+        lib = self._ensure_handle()
+        t = timesteps.to(device=x.device, dtype=th.float32).contiguous()
+        with th.cuda.device(x.device):
+            film, stride = self._film_for(lib, hv, t)
+            _lib.check(lib.s3d_unet_step_film(self._handle, _lib.ptr(film), stride, B, int(H), int(W), int(D), C.byref(step),
+                                              None, _lib.stream_ptr()))
 
     def prepare_timesteps(self, values, t_dev):
         """The FiLM tables of a whole schedule (host values + the same values on the device) in one batched launch (three

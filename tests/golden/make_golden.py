@@ -258,6 +258,104 @@ def gen_sampler():
     save("trajectories", **tr)
 
 
+def gen_sampler_branches():
+    """Reachable sampler / training branches the default fixtures do not touch:
+    clip_denoised=False (the reference's own trainer samples that way, train_util.py:181), predict_xstart=False
+    (ModelMeanType.EPSILON: p_mean_variance :306-315 through _predict_xstart_from_eps, and the training target
+    :829-835 with gradients), sigma_small=True (ModelVarType.FIXED_SMALL :286-289); each at t in {T-1, 1, 0}."""
+    import diffusion.gaussian_diffusion as gd
+    from diffusion.script_util import create_gaussian_diffusion
+    out = {}
+    model = make_unet(32)
+    H, W, D = 10, 14, 6
+    kw = dict(H=H, W=W, D=D)
+    B = 1
+    shape = (B, 12, H + D, W + D)
+    cfgs = (("noclip", dict(predict_xstart=True), "", False),
+            ("eps", dict(predict_xstart=False), "", True),
+            ("eps_noclip", dict(predict_xstart=False), "", False),
+            ("eps_r20", dict(predict_xstart=False), "20", True),
+            ("small", dict(predict_xstart=True, sigma_small=True), "", True),
+            ("small_r20_noclip", dict(predict_xstart=True, sigma_small=True), "20", False),
+            ("eps_small", dict(predict_xstart=False, sigma_small=True), "", True))
+    for tag, dkw, resp, clip in cfgs:
+        diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", timestep_respacing=resp, **dkw)
+        Tn = diff.num_timesteps
+        for ti in (Tn - 1, 1, 0):
+            x = rnd(shape, 1500 + ti)
+            if "eps" in tag:
+                x = x * 0.5           # keeps the eps-derived x0 = (x - sqrt(1-ab) eps) / sqrt(ab) partly inside [-1, 1] at small t
+            eps = rnd(shape, 1600 + ti)
+            t = torch.tensor([ti] * B)
+            orig = gd.th.randn_like
+            gd.th.randn_like = lambda z: eps.clone()
+            try:
+                o1 = diff.p_sample(model, x, t, clip_denoised=clip, model_kwargs=kw)
+                o2 = diff.ddim_sample(model, x, t, clip_denoised=clip, model_kwargs=kw)
+                o3 = diff.ddim_sample(model, x, t, clip_denoised=clip, model_kwargs=kw, eta=0.7)
+                pm = diff.p_mean_variance(model, x, t, clip_denoised=clip, model_kwargs=kw)
+                mo = model(x, diff._scale_timesteps(torch.tensor([diff.timestep_map[ti]] * B)), **kw)
+            finally:
+                gd.th.randn_like = orig
+            pre = f"{tag}.t{ti}"
+            out[pre + ".x"], out[pre + ".eps"] = x, eps
+            out[pre + ".model_out"] = mo                     # the update arithmetic can be pinned without the UNet's round-off (EPSILON amplifies it by sqrt(1/ac - 1), 157 at t = 999)
+            assert torch.equal(o1["pred_xstart"], o2["pred_xstart"])
+            out[pre + ".p_sample"], out[pre + ".p_xstart"] = o1["sample"], o1["pred_xstart"]
+            out[pre + ".ddim_sample"] = o2["sample"]
+            out[pre + ".ddim_eta_sample"] = o3["sample"]
+            out[pre + ".mean"] = pm["mean"]
+            out[pre + ".variance"], out[pre + ".log_variance"] = pm["variance"][:, 0, 0, 0], pm["log_variance"][:, 0, 0, 0]
+        out[f"{tag}.cfg"] = np.asarray([int(dkw.get("predict_xstart", False)), int(dkw.get("sigma_small", False)),
+                                        int(resp or 0), int(clip)])
+    out["hwd"] = np.asarray([H, W, D])
+    save("sampler_branches", **out)
+
+    # a short unclipped ancestral trajectory, as TrainLoop._sample_and_visualize runs it (train_util.py:181)
+    tr = {}
+    for tag, dkw, resp in (("noclip_ddpm20", dict(predict_xstart=True), "20"), ("eps_ddim10", dict(predict_xstart=False), "10")):
+        diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", timestep_respacing=resp, **dkw)
+        Tn = diff.num_timesteps
+        xT = rnd(shape, 1700)
+        epss = [rnd(shape, 1710 + i) for i in range(Tn)]
+        it = iter(epss)
+        orig = gd.th.randn_like
+        gd.th.randn_like = lambda z: next(it).clone()
+        try:
+            if "ddim" in tag:
+                final = diff.ddim_sample_loop(model, shape, noise=xT.clone(), clip_denoised=True, model_kwargs=kw)
+            else:
+                final = diff.p_sample_loop(model, shape, noise=xT.clone(), clip_denoised=False, model_kwargs=kw)
+        finally:
+            gd.th.randn_like = orig
+        tr[f"{tag}.xT"], tr[f"{tag}.eps"], tr[f"{tag}.final"] = xT, torch.stack(epss), final
+    tr["hwd"] = np.asarray([H, W, D])
+    save("trajectories_branches", **tr)
+
+    # training_losses with the EPSILON target (:829-835): loss terms and every parameter gradient
+    torch.set_grad_enabled(True)
+    out = {}
+    diffusion = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=False)
+    for tag, mc, raw, (B, H, W, D), ssn, cm in (("mc32_a", 32, False, (2, 10, 14, 6), True, "1,2"),
+                                                ("mc32_add", 32, False, (1, 10, 14, 6), False, "1,2")):
+        model = make_unet(mc, raw, ssn, cm)
+        model.train()
+        x0 = rnd((B, 12, H + D, W + D), 400).clamp(-1, 1)
+        noise = rnd((B, 12, H + D, W + D), 401)
+        t = torch.tensor([700, 3][:B], dtype=torch.int64)
+        terms = diffusion.training_losses(model, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+        model.zero_grad()
+        (terms["loss"] * torch.ones(B)).mean().backward()
+        out[f"{tag}.t"] = t
+        out[f"{tag}.hwd"] = np.asarray([H, W, D])
+        for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+            out[f"{tag}.{k}"] = terms[k].detach()
+        grad_digest({k: p.grad for k, p in model.named_parameters()}, f"{tag}.grad", out,
+                    full_names=TRAIN_FULL if tag == "mc32_a" else ())
+    save("train_eps", **out)
+    torch.set_grad_enabled(False)
+
+
 def gen_decoder():
     from encoding.networks import AutoEncoderGroupSkip
     from encoding.blocks import TriplaneGroupResnetBlock
@@ -627,7 +725,7 @@ def gen_ae_ckpt():
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name, fn in (("schedules", gen_schedules), ("temb", gen_temb), ("leaves", gen_leaves),
-                     ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler),
+                     ("resblock", gen_resblock), ("unet", gen_unet), ("sampler", gen_sampler), ("sampler_branches", gen_sampler_branches),
                      ("decoder", gen_decoder), ("compose", gen_compose), ("train", gen_train), ("ae_train", gen_ae_train), ("respaced", gen_respaced_train),
                      ("formats", gen_formats), ("ae_ckpt", gen_ae_ckpt)):
         if not only or name in only:

@@ -114,6 +114,44 @@ def test_sampler_updates(oracle):
             assert relerr(s, g[pre + ".ddim_eta_sample"]) < 5e-5
 
 
+BRANCH_TAGS = ["noclip", "eps", "eps_noclip", "eps_r20", "small", "small_r20_noclip", "eps_small"]
+
+
+@pytest.mark.parametrize("tag", BRANCH_TAGS)
+def test_sampler_update_branches(oracle, tag):
+    """clip_denoised=False, ModelMeanType.EPSILON and ModelVarType.FIXED_SMALL (gaussian_diffusion.py:286-289, 294-315) at
+    t in {T-1, 1, 0}: p_sample, ddim_sample (eta 0 and 0.7) and the model mean / (log-)variance of p_mean_variance."""
+    g = golden("sampler_branches")
+    from sin3dm_amd.diffusion.respace import space_timesteps
+    H, W, D = (int(v) for v in g["hwd"])
+    px, small, resp, clip = (int(v) for v in g[f"{tag}.cfg"])
+    sd = oracle.Params(T.synthetic_state_dict(T.unet_param_shapes(model_channels=32), 0, as_torch=False))
+    tab, tmap = oracle.schedule_tables(space_timesteps(1000, str(resp)) if resp else None)
+    Tn = tab.shape[1]
+    kw = dict(clip=bool(clip), mean_eps=not px)
+    for ti in (Tn - 1, 1, 0):
+        pre = f"{tag}.t{ti}"
+        x, eps = g[pre + ".x"], g[pre + ".eps"]
+        # (1) the update arithmetic alone, on the reference's own model output: fp32 round-off only
+        mo = g[pre + ".model_out"]
+        s, p, m = oracle.p_sample_update(mo, x, eps, tab, ti, var_small=bool(small), want_mean=True, **kw)
+        assert relerr(s, g[pre + ".p_sample"]) < 2e-6 and relerr(p, g[pre + ".p_xstart"]) < 2e-6 and relerr(m, g[pre + ".mean"]) < 2e-6
+        s, p = oracle.ddim_update(mo, x, eps, tab, ti, **kw)
+        assert relerr(s, g[pre + ".ddim_sample"]) < 2e-6 and relerr(p, g[pre + ".p_xstart"]) < 2e-6
+        s, _ = oracle.ddim_update(mo, x, eps, tab, ti, eta=0.7, **kw)
+        assert relerr(s, g[pre + ".ddim_eta_sample"]) < 2e-6
+        # (2) end to end through the oracle's UNet.  An eps-derived x0 multiplies the UNet's round-off by
+        # sqrt(1 / alphas_cumprod - 1) (157 at t = 999): the bound is the forward gate times that factor
+        mo2 = oracle.unet_forward(sd, x, [tmap[ti]] * x.shape[0], H, W, D, 32)
+        assert relerr(mo2, mo) < 5e-5
+        amp = 1.0 if px else max(1.0, float(tab[4][ti]) * float(np.abs(mo).max()) / float(np.abs(g[pre + ".p_xstart"]).max()))
+        s, p = oracle.p_sample_update(mo2, x, eps, tab, ti, var_small=bool(small), **kw)
+        assert relerr(s, g[pre + ".p_sample"]) < 5e-5 * amp and relerr(p, g[pre + ".p_xstart"]) < 5e-5 * amp
+        var = tab[5][max(ti, 1)] if small else (tab[5][1] if ti == 0 else tab[0][ti])
+        assert abs(float(g[pre + ".log_variance"][0]) - np.log(var)) < 1e-5 * abs(np.log(var))
+        assert abs(float(g[pre + ".variance"][0]) - (tab[5][ti] if small else var)) <= 1e-6 * var
+
+
 @pytest.mark.parametrize("tag,resp,ddim", [("ddim10", "10", True), ("ddpm20", "20", False)])
 def test_trajectories(oracle, tag, resp, ddim):
     g = golden("trajectories")
@@ -201,6 +239,26 @@ def test_torch_port_training_losses_and_grads(oracle, tag, mc, raw, ssn, cm, B):
     terms, x_t = tp.training_losses(sd, x0, t, noise, tabs, H, W, D, model_channels=mc, channel_mult=cm,
                                     use_scale_shift_norm=ssn, rollout=not raw)
     assert relerr(x_t.detach().numpy(), g[f"{tag}.x_t"]) < 1e-6
+    for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+        assert relerr(terms[k].detach().numpy(), g[f"{tag}.{k}"]) < 1e-5
+    terms["loss"].mean().backward()
+    w = digest_errors({k: v.grad.numpy() for k, v in sd.items()}, g, f"{tag}.grad")
+    assert w["norm"] < 1e-4 and w["proj"] < 1e-4 and w["head"] < 1e-3 and w["full"] < 1e-4, w
+
+
+@pytest.mark.parametrize("tag,ssn,B", [("mc32_a", True, 2), ("mc32_add", False, 1)])
+def test_torch_port_training_epsilon_target(oracle, tag, ssn, B):
+    """predict_xstart=False: the MSE target is the noise (gaussian_diffusion.py:829-835); loss terms and every parameter
+    gradient against the reference's autograd."""
+    import torch
+    import torch_port as tp
+    g = golden("train_eps")
+    shapes = T.unet_param_shapes(model_channels=32, use_scale_shift_norm=ssn)
+    sd = {k: v.requires_grad_(True) for k, v in T.synthetic_state_dict(shapes, 0).items()}
+    H, W, D, x0, noise, t = _train_inputs(g, tag, B)
+    tabs = oracle.schedule_tables_named(1000)
+    terms, _ = tp.training_losses(sd, x0, t, noise, tabs, H, W, D, predict_xstart=False, model_channels=32,
+                                  use_scale_shift_norm=ssn)
     for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
         assert relerr(terms[k].detach().numpy(), g[f"{tag}.{k}"]) < 1e-5
     terms["loss"].mean().backward()

@@ -1,14 +1,16 @@
-// Stand-alone timing of the three 3x3 kernels on the network's layer shapes (tuning / profiles/r02_wino_ubench.txt):
-//   k_conv_wino4 (F(2x2), s3d_wino.hip), k_conv_wino24s and k_conv_wino24 (F(2x4), s3d_wino24.hip), random data, three square planes.
+// Stand-alone timing of the 3x3 kernels on the network's layer shapes (tuning / profiles/r04_wino_ubench.txt):
+//   k_conv_wino4 (F(2x2), s3d_wino.hip), k_conv_wino24s and k_conv_wino24w (F(2x4), s3d_wino24.hip), random data, three square planes.
+//   -DW24_TIMING: per-block phase stamps; -DW24W_RING=N: weight-fragment ring depth of the wide kernel
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino24_ubench.hip -o tools/ub_wino24
 #include "../sin3dm_amd/csrc/s3d_common.h"
-namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; } struct R1Inline; void r1_layout(R1Inline&, int, int) {} void r1_targets(R1Inline&, int, unsigned*, bool) {}
+namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; }
   size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
 #include "../sin3dm_amd/csrc/s3d_wino.hip"
 #include "../sin3dm_amd/csrc/s3d_wino24.hip"
-#include "../sin3dm_amd/csrc/s3d_wino44.hip"
+#include <chrono>
 #include <cstdlib>
 using namespace s3d;
+static double g_warm_s = 0.3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 #ifdef W24_TIMING
 static unsigned long long* g_tb = nullptr;
@@ -16,7 +18,7 @@ static unsigned long long* g_tb = nullptr;
 static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     const size_t npix = size_t(3) * hw * hw * B;
     float *in, *wgt, *out, *res, *tab;
-    const size_t wsz = wino44_packed_floats(cout, cin);          // >= the F(2x4) and F(2x2) images
+    const size_t wsz = std::max(wino24_packed_floats(cout, cin), size_t((cout + 31) / 32) * (cin / 8) * 16 * 256);   // the F(2x4) and F(2x2) images
     CK(hipMalloc(&in, npix * cin * 4)); CK(hipMalloc(&wgt, 3 * wsz * 4)); CK(hipMalloc(&out, npix * cout * 4)); CK(hipMalloc(&res, npix * cout * 4));
     CK(hipMalloc(&tab, size_t(B) * hw * 4 * cout * 4));
     std::vector<float> h(npix * cin); for (auto& v : h) v = float(rand()) / RAND_MAX - 0.5f;
@@ -25,10 +27,11 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
     { std::vector<float> r(npix * cout); for (auto& v : r) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(res, r.data(), r.size() * 4, hipMemcpyHostToDevice));
       std::vector<float> t(size_t(B) * hw * 4 * cout); for (auto& v : t) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice)); }
-    const char* names[5] = {"wino4  F(2x2)  8x16 px", "wino24s F(2x4) 8x16 px", "wino24 F(2x4) 16x16 px", "wino24p F(2x4) persistent", "wino44 F(4x4) 16x16 px "};
-    const double frac[5] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3, 1.0 / 4};
+    const char* names[3] = {"wino4   F(2x2) 8x16 px x 32", "wino24s F(2x4) 8x16 px x 32", "wino24w F(2x4) 8x16 px x 64"};
+    const double frac[3] = {4.0 / 9, 1.0 / 3, 1.0 / 3};
     std::vector<float> ref_out;
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < 3; ++k) {
+        if (k == 2 && cout % 64) continue;
         ConvArgs a; memset(&a, 0, sizeof a);
         a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
         for (int p = 0; p < 3; ++p) {
@@ -36,18 +39,20 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
             a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
             if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
         }
-        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24s(a, 0) : (k == 2 ? launch_conv_wino24(a, 0) : (k == 3 ? launch_conv_wino24p(a, 0) : launch_conv_wino44(a, 0)))); };
-        if (k == 1 || k == 3) {      // the persistent form must reproduce k_conv_wino24s bit for bit
+        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24_narrow(a, 0) : launch_conv_wino24_wide(a, 0)); };
+        if (k >= 1) {                // the wide form must reproduce k_conv_wino24s bit for bit
             CK(hipMemset(out, 0xFF, npix * cout * 4));
             launch(); CK(hipDeviceSynchronize());
             std::vector<float> o(npix * cout);
             CK(hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost));
             if (k == 1) ref_out.swap(o);
-            else printf("    persistent vs wino24s: %s\n", memcmp(o.data(), ref_out.data(), o.size() * 4) == 0 ? "bit-identical" : "MISMATCH");
+            else printf("    wino24w vs wino24s: %s\n", memcmp(o.data(), ref_out.data(), o.size() * 4) == 0 ? "bit-identical" : "MISMATCH");
         }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) launch();
-        CK(hipDeviceSynchronize());
+        {   // steady state: the chip is power-limited under this kernel (profiles/r04_clock.txt) — measure after ~0.3 s of it, not on a cold ramp
+            const auto w0 = std::chrono::steady_clock::now();
+            do { for (int i = 0; i < 10; ++i) launch(); CK(hipDeviceSynchronize()); } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < g_warm_s);
+        }
         CK(hipEventRecord(e0, 0));
         for (int i = 0; i < iters; ++i) launch();
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -55,7 +60,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * npix;
         int blocks = 0; for (int p = 0; p < 3; ++p) blocks += a.job[p].tiles_per_img * a.job[p].n_tiles_n * B;
 #ifdef W24_TIMING
-        if (k == 1 || k == 3 || k == 4) {   // per-block phase times of one launch of k_conv_wino24s (wall_clock64 ticks of 10 ns)
+        if (k >= 1) {   // per-block phase times of one launch (wall_clock64 ticks of 10 ns)
             unsigned long long* tb = g_tb;
             launch(); CK(hipDeviceSynchronize());
             std::vector<unsigned long long> t(size_t(blocks) * 8);
@@ -68,11 +73,26 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
                 for (int q = 0; q < 5; ++q) ph[late][q] += (t[i * 8 + q + 1] - t[i * 8 + q]) * 0.01;
                 ++n[late];
             }
-            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : (k == 4 ? "wino44" : "wino24p (per tile; first-wave = each block's first tile)"), (t5 - t0) * 0.01);
+            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : "wino24w", (t5 - t0) * 0.01);
             for (int l = 0; l < 2; ++l)
                 if (n[l]) printf("  [%s %d blocks] halo->LDS %.1f | first operands %.1f | k-loop %.1f | barrier + share images + operand loads %.1f | finish + stores %.1f us",
                                  l ? "later" : "first-wave", n[l], ph[l][0] / n[l], ph[l][1] / n[l], ph[l][2] / n[l], ph[l][3] / n[l], ph[l][4] / n[l]);
             printf("\n");
+            // a grid of ONE block per CU (and, wide form, exactly two): what a block's phases take when it has the CU's matrix pipe to itself
+            for (int per_cu = 1; per_cu <= (k == 2 ? 2 : 3); ++per_cu) {
+                const int nb = 256 * per_cu;
+                if (nb > blocks) break;
+                CK(hipMemset(tb, 0, size_t(blocks) * 64));
+                for (int rep = 0; rep < 3; ++rep) {
+                    if (k == 1) hipLaunchKernelGGL(k_conv_wino24s, dim3(nb), dim3(256), 0, 0, a); else hipLaunchKernelGGL(k_conv_wino24w, dim3(nb), dim3(256), 0, 0, a);
+                }
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(t.data(), tb, size_t(nb) * 64, hipMemcpyDeviceToHost));
+                double q[5] = {0, 0, 0, 0, 0}, cs = 0, ws = 0;
+                for (int i = 0; i < nb; ++i) { for (int z = 0; z < 5; ++z) q[z] += (t[i * 8 + z + 1] - t[i * 8 + z]) * 0.01; cs += double(t[i * 8 + 7] - t[i * 8 + 6]); ws += double(t[i * 8 + 3] - t[i * 8 + 2]); }
+                printf("      %d block(s) per CU (%d blocks): halo->LDS %.1f | first operands %.1f | k-loop %.1f (%.0f MHz in it; MFMA time of one block at that clock %.1f us) | images %.1f | finish %.1f us\n",
+                       per_cu, nb, q[0] / nb, q[1] / nb, q[2] / nb, cs / ws * 100.0, double(cin / 16) * (k == 2 ? 96 : 48) * 32 / (cs / ws * 100.0), q[3] / nb, q[4] / nb);
+            }
         }
 #endif
         printf("%s cin=%4d cout=%4d hw=%3d B=%d extras=%d blocks=%5d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
@@ -80,16 +100,27 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     }
     CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
-int main() {
+int main(int argc, char** argv) {          // arguments: indices of the cases to run (default: all)
 #ifdef W24_TIMING
     CK(hipMalloc(&g_tb, size_t(1 << 16) * 64)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_w24time), &g_tb, sizeof g_tb));
 #endif
-    run(128, 128, 128, 1, 20, true);      // input_blocks.0 / output_blocks.1.0.out_layers.2
-    run(128, 256, 64, 1, 20, true);       // input_blocks.1.1.in_layers.2
-    run(256, 256, 64, 1, 20, true);       // the three half-resolution 256 -> 256 layers
-    run(384, 128, 128, 1, 20, true);      // output_blocks.1.0.in_layers.2
-    run(128, 128, 128, 8, 5, true);       // batch 8 (BASELINE config 3)
-    run(256, 256, 64, 8, 5, true);
-    run(384, 128, 256, 1, 5, true);       // (256,256,128)-sized planes (config 5), square stand-in
+    if (getenv("UB_WARM_S")) g_warm_s = atof(getenv("UB_WARM_S"));
+    const int NC = 19;
+    const int cases[NC][5] = {{128, 128, 128, 1, 20},     // 0 input_blocks.0 / output_blocks.1.0.out_layers.2
+                              {128, 256, 64, 1, 20},      // 1 input_blocks.1.1.in_layers.2
+                              {256, 256, 64, 1, 20},      // 2 the three half-resolution 256 -> 256 layers
+                              {384, 128, 128, 1, 20},     // 3 output_blocks.1.0.in_layers.2
+                              {128, 128, 128, 8, 5},      // 4 batch 8 (BASELINE config 3)
+                              {256, 256, 64, 8, 5},       // 5
+                              {384, 128, 256, 1, 5},      // 6 (256,256,128)-sized planes (config 5), square stand-in
+                              {128, 128, 128, 2, 10}, {128, 256, 64, 2, 10}, {256, 256, 64, 2, 10}, {384, 128, 128, 2, 10},     // 7-10 batch 2
+                              {128, 128, 128, 4, 10}, {128, 256, 64, 4, 10}, {256, 256, 64, 4, 10}, {384, 128, 128, 4, 10},     // 11-14 batch 4
+                              {128, 256, 64, 8, 5}, {384, 128, 128, 8, 5},                                                      // 15-16 the other two shapes at batch 8
+                              {64, 64, 96, 4, 10}, {64, 128, 48, 4, 10}};                                                      // 17-18 the training tier's widths (64-channel UNet, batch 4)
+    for (int c = 0; c < NC; ++c) {
+        bool on = argc < 2;
+        for (int i = 1; i < argc; ++i) on |= atoi(argv[i]) == c;
+        if (on) run(cases[c][0], cases[c][1], cases[c][2], cases[c][3], cases[c][4], true);
+    }
     return 0;
 }
