@@ -2,8 +2,11 @@
 """Headline benchmark: DDPM-1000 triplane samples/sec at a 128^2 latent (BASELINE.json configs[1]:
 128-ch UNet, (H,W,D)=(128,128,128), batch 1 per GPU), through the public sampling API.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+--config selects the BASELINE.json workload (default c2 = configs[1], the one the metric is quoted on; c3 = configs[2]'s per-GPU
+share: DDIM-100, batch 8 per GPU; c5 = configs[4]: the (256,256,128) retarget, DDPM-1000) — each line carries its own roofline.
 
 A "step" is one iteration of GaussianDiffusion.p_sample_loop_progressive (the loop src/sample.py drives) for one sample per
 GPU: UNet forward + fused sampler update + the step's noise draw (device generator, as the reference does on a GPU).  value = samples/s over all ranks
@@ -30,8 +33,22 @@ MC = 128
 HWD = (128, 128, 128)
 T_STEPS = 1000
 PREWARM = 60
-PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak
-TRAFFIC_PROFILE = "profiles/r03_pmc_traffic.json"
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak (at the 2400 MHz data-sheet clock)
+PEAK_CLOCK_MHZ = 2400.0
+TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
+# BASELINE.json workloads a single GPU can run (per-GPU share of the multi-GPU ones): name -> (hwd, batch per GPU, sampler,
+# timestep_respacing, steps per sample, metric, workload text)
+CONFIGS = {
+    "c2": ((128, 128, 128), 1, "ddpm", "", 1000, "DDPM-1000 triplane samples/sec @128^2 latent",
+           "BASELINE configs[1]: 128^2 triplane (H,W,D)=(128,128,128), 128-ch TriplaneUNetModelSmall, DDPM-1000, batch 1 per GPU; "
+           "a step = 1 denoising step"),
+    "c3": ((128, 128, 128), 8, "ddim", "ddim100", 100, "DDIM-100 triplane samples/sec @128^2 latent, batch 8 per GPU",
+           "BASELINE configs[2] per-GPU share: 128^2 triplane, 128-ch UNet, DDIM-100, batch 64 over 8 GPUs = 8 per GPU; "
+           "a step = 1 denoising step of the batch"),
+    "c5": ((256, 256, 128), 1, "ddpm", "", 1000, "DDPM-1000 triplane samples/sec @(256,256,128) retarget",
+           "BASELINE configs[4] (diffusion side): retargeted (H,W,D)=(256,256,128) triplane (--resize 2 2 1), 128-ch UNet, "
+           "DDPM-1000, batch 1; a step = 1 denoising step"),
+}
 
 
 def f_dense_per_step(mc, H, W, D, mult=(1, 2)):
@@ -161,6 +178,111 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+class ClockSampler:
+    """gfx clock / socket power of this rank's GPU through amdsmi's gpu_metrics, sampled by a thread while the benchmark's own
+    untimed steps run (the same load as the timed region; never during it — a 1-ms driver call inside an 18-ms timed region is
+    noise nobody needs).  Everything is optional: no amdsmi / no permission -> no figures, never a failure."""
+
+    def __init__(self, bdf):
+        self.samples, self._stop, self._thread, self._h = [], False, None, None
+        try:
+            import amdsmi
+            self._smi = amdsmi
+            amdsmi.amdsmi_init()
+            handles = amdsmi.amdsmi_get_processor_handles()
+            want = (bdf or "").lower()
+            for h in handles:
+                try:
+                    if want and want in str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower():
+                        self._h = h
+                except Exception:
+                    pass
+            if self._h is None and len(handles) == 1:
+                self._h = handles[0]
+        except Exception:
+            self._h = None
+
+    def _run(self):
+        while not self._stop:
+            try:
+                m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
+                clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+                if not clk and isinstance(m.get("current_gfxclk"), (int, float)):
+                    clk = [m["current_gfxclk"]]
+                pw = m.get("current_socket_power")
+                if not isinstance(pw, (int, float)) or pw >= 60000:
+                    pw = m.get("average_socket_power")
+                if clk:
+                    self.samples.append((sum(clk) / len(clk), pw if isinstance(pw, (int, float)) and pw < 60000 else None))
+            except Exception:
+                return
+            time.sleep(0.02)
+
+    def start(self):
+        if self._h is not None:
+            import threading
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        s = self.samples[len(self.samples) // 3:]                 # the clocks settle during the first steps
+        if not s:
+            return None
+        pw = [p for _, p in s if p is not None]
+        return {"gfxclk_mhz_mean": round(sum(c for c, _ in s) / len(s), 0), "gfxclk_mhz_min": round(min(c for c, _ in s), 0),
+                "socket_power_w_mean": round(sum(pw) / len(pw), 0) if pw else None, "samples": len(s),
+                "how": "amdsmi gpu_metrics (mean over the XCDs) every 20 ms during the untimed pre-warm steps of this run"}
+
+
+def measure_traffic_in_run(config):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two fresh children of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, --kernel-trace only, the program directly after `--`),
+    started before this process touches the GPU.  Returns (bytes per launch, source string) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this process is itself being profiled"
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="s3d_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--profile-every", "0",
+                   "--prewarm", "4", "--traffic", "off", "--config", config]
+            env = dict(os.environ, TMPDIR=tmp)
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]!r}"
+            agg = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] != counter or "k_conv_wino" not in row["Kernel_Name"]:
+                    continue
+                a = agg.setdefault("dom", [0.0, 0])
+                a[0] += float(row["Counter_Value"]); a[1] += 1
+            if "dom" not in agg:
+                return None, f"no k_conv_wino launches in the {counter} pass"
+            tot[counter] = agg["dom"][0] / agg["dom"][1]
+    except Exception as e:                                      # a profiler hiccup must not cost the benchmark line
+        return None, f"in-run PMC passes failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM section): x2; WRITE_SIZE KB as is
+    bytes_per_launch = int(2 * tot["FETCH_SIZE"] * 1024 + tot["WRITE_SIZE"] * 1024)
+    return bytes_per_launch, ("measured_in_run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this command (separate passes, "
+                              "--kernel-trace only, 6 steps each), per-launch mean over the k_conv_wino24* launches, read side x2 "
+                              "(gfx950 FETCH_SIZE correction)")
+
+
 # ------------------------------------------------------------------------------------------------ worker
 def worker(args):
     import torch
@@ -171,7 +293,8 @@ def worker(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    H, W, D = HWD
+    (H, W, D), BATCH, sampler_kind, respacing, steps_per_sample, metric, workload = CONFIGS[args.config]
+    clock = None
 
     ident = {"device_index": None, "pci_bus_id": None, "uuid": None, "name": "cpu (dry run)"}
     if args.dry_run:
@@ -205,14 +328,16 @@ def worker(args):
         model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
         model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0))
         model.to(dev).eval()
-        diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True)
+        diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True, timestep_respacing=respacing)
+        assert diffusion.num_timesteps == steps_per_sample
         kw = dict(H=H, W=W, D=D)
         torch.manual_seed(1000 + rank)
         state = {"x": None}
+        loop = diffusion.ddim_sample_loop_progressive if sampler_kind == "ddim" else diffusion.p_sample_loop_progressive
 
         def sampler():          # the public sampling loop, sample after sample (src/sample.py:38 calls p_sample_loop)
             while True:
-                for out in diffusion.p_sample_loop_progressive(model, (1, 12, H + D, W + D), model_kwargs=kw):
+                for out in loop(model, (BATCH, 12, H + D, W + D), model_kwargs=kw):
                     state["x"] = out["sample"]
                     yield
         gen = sampler()
@@ -224,9 +349,13 @@ def worker(args):
             dist.barrier()
 
     with torch.no_grad():
-        for _ in range(PREWARM + args.warmup):
+        if not args.dry_run and rank == 0:
+            clock = ClockSampler(ident.get("pci_bus_id"))
+            clock.start()
+        for _ in range(args.prewarm + args.warmup):
             step()
         sync()
+        clock = clock.stop() if clock is not None else None
         if not args.dry_run:
             model.profile(args.profile_every)
         barrier()
@@ -257,13 +386,16 @@ def worker(args):
         dist.destroy_process_group()
     if rank != 0:
         return 0
-    distinct = {(r["pci_bus_id"], r["uuid"], r["device_index"]) for r in ranks}
-    if not args.dry_run and len(distinct) != world:
-        raise SystemExit(f"bench.py: {world} ranks but only {len(distinct)} distinct devices: {ranks}")
+    # N ranks must be N physical devices: keyed on what identifies the hardware (the device INDEX is LOCAL_RANK by construction
+    # and proves nothing); a build that reports neither bus id nor uuid cannot be verified and says so in the line
+    keys = [(r["pci_bus_id"], r["uuid"]) for r in ranks]
+    verifiable = all(k != (None, None) for k in keys)
+    if not args.dry_run and verifiable and len(set(keys)) != world:
+        raise SystemExit(f"bench.py: {world} ranks but only {len(set(keys))} distinct devices: {ranks}")
 
     ms_step = dt / args.steps * 1e3
-    value = world * args.steps / T_STEPS / dt
-    fd = f_dense_per_step(MC, H, W, D)
+    value = world * BATCH * args.steps / steps_per_sample / dt
+    fd = f_dense_per_step(MC, H, W, D) * BATCH
     switches = s3d_switches()
     roof = None
     if prof is not None and prof.launches[0] > 0:
@@ -271,22 +403,28 @@ def worker(args):
         avg_s = sec / prof.launches[0]
         executed = prof.mfma_flops[0] / sec / 1e12                 # what the matrix cores multiply: the hardware rate
         algorithmic = prof.flops[0] / sec / 1e12
-        traffic, traffic_src = None, None
-        if not switches:     # the committed PMC passes were taken with the default kernels ...
+        traffic, traffic_src = getattr(args, "traffic_measured", (None, None))
+        if traffic is None and not switches and args.config == "c2":     # the committed PMC passes: default kernels, the headline config ...
+            why_not = traffic_src
             try:
                 tp = json.load(open(os.path.join(REPO, TRAFFIC_PROFILE)))
                 if tp.get("csrc_sha256") == csrc_sha256():            # ... of exactly this tree's kernel sources
                     traffic = tp["dominant_traffic_bytes_per_launch"]
                     traffic_src = (f"from_committed_profile {TRAFFIC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command "
                                    "(separate passes, gfx950 2x read correction), kernel sources unchanged since (sha256 match); "
-                                   "not re-measured in this run")
+                                   f"not re-measured in this run ({why_not})")
                 else:
                     traffic_src = (f"dropped: {TRAFFIC_PROFILE} was measured on other kernel sources "
                                    f"(csrc sha256 {str(tp.get('csrc_sha256'))[:12]} != {csrc_sha256()[:12]}); re-run tools/refresh_profiles.sh")
             except (OSError, KeyError, ValueError):
                 pass
+        peak_at_clock = round(PEAK_FP32_MFMA_TFLOPS * clock["gfxclk_mhz_mean"] / PEAK_CLOCK_MHZ, 1) if clock else None
         roof = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(executed / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                # the part is power-limited under this kernel (profiles/r04_clock.txt): the peak the matrix pipe has at the clock
+                # the run really held (157.3 TF is the 2400-MHz data-sheet figure and stays `peak`)
+                "peak_at_measured_clock": peak_at_clock, "frac_at_measured_clock": round(executed / peak_at_clock, 4) if peak_at_clock else None,
+                "clock": clock,
                 "algorithmic_tflops": round(algorithmic, 2),
                 "hbm_gbs": round(traffic / avg_s / 1e9, 1) if traffic else None,
                 "hbm_frac_of_8TBs": round(traffic / avg_s / 8e12, 4) if traffic else None,
@@ -304,23 +442,23 @@ def worker(args):
                         "direct count) / HIP-event time on the launch stream inside the timed region / 157.3 TF; "
                         "algorithmic_tflops = 2*9*C*Cout per output pixel (own channels only: rank-1 rollout exploited) over the "
                         "same time; the rate on the reference-executed F_dense is effective_dense_tflops"}
-    line = {"metric": "DDPM-1000 triplane samples/sec @128^2 latent", "value": value, "unit": "samples/s",
+    line = {"metric": metric, "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)",
-            "config": {"workload": "BASELINE configs[1]: 128^2 triplane (H,W,D)=(128,128,128), 128-ch "
-                                   "TriplaneUNetModelSmall, DDPM-1000, batch 1 per GPU; a step = 1 denoising step",
-                       "steps_per_sample": T_STEPS, "batch_per_gpu": 1, "parallelism": f"{world} independent samples",
-                       "prewarm_steps": PREWARM},
+            "config": {"workload": workload, "name": args.config,
+                       "steps_per_sample": steps_per_sample, "batch_per_gpu": BATCH,
+                       "parallelism": f"{world} independent samples" if BATCH == 1 else f"{world} x {BATCH} independent samples",
+                       "prewarm_steps": args.prewarm},
             "f_dense_gflop_per_step": round(fd / 1e9, 2),
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
             "roofline": roof, "s3d_switches": switches,
-            "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks],
+            "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks], "devices_verified_distinct": bool(verifiable) if world > 1 else None,
             "rccl_world_size": backend_world if world > 1 else None, "dist_backend": backend if world > 1 else None}
     if args.dry_run:
         line["data"] = "DRY RUN (no GPU work: launcher / rendezvous plumbing check only)"
         line["value"] = 0.0
-    elif not args.no_cpu_baseline:
+    elif not args.no_cpu_baseline and args.config == "c2" and world == 1:      # (the CPU legs time the headline workload, on rank 0 at N = 1 only)
         line["cpu_baseline"] = cpu_baseline()
         line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         try:
@@ -338,12 +476,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-every", type=int, default=8, help="instrument every n-th step with HIP events (0=off)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json workload (default: configs[1], the scored one)")
+    ap.add_argument("--prewarm", type=int, default=PREWARM, help="untimed steps before --warmup (a fresh box needs them to reach steady clocks)")
+    ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
+                    help="auto: measure roofline.traffic in this run with two rocprofv3 --pmc child passes (N = 1 only)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-early", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_workers(args, sys.argv[1:])
+    if args.traffic == "auto" and args.gpus == 1 and not args.dry_run and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not s3d_switches():
+        args.traffic_measured = measure_traffic_in_run(args.config)       # BEFORE this process touches the GPU
     return worker(args)
 
 

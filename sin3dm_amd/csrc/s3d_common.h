@@ -280,8 +280,10 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
 // `out` may be null and the model output is never stored)
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
                     const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st,
-                    const s3d_sampler_args* fuse = nullptr);
+                    const s3d_sampler_args* fuse = nullptr, const GnPartials* part = nullptr);
 bool out_head_fuses_sampler(int C, int Cout);
+// part (with stats.mr == null): the head adds its input's GroupNorm partials itself — no k_gn_finalize launch before it
+bool out_head_adds_parts(const GnPartials& part, int C, int Cout);
 
 // small dense layers for the timestep path: y[b][o] = act_out( sum_i f(in[b][i]) * W[o][i] + bias[o] )
 // in_mode 0: plain, 1: SiLU(in), 2: in is t[b] -> sinusoidal embedding of width I (cos | sin)

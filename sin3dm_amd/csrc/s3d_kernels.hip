@@ -476,6 +476,57 @@ int launch_gn_finalize_cat(const GnPartials& pu, const GnPartials& ps, const Geo
 // h*(1+scale)+shift of TriplaneResBlock._forward (:285-297) applied between them, and the axis sums the
 // next TriplaneConv's rollout needs (:37-46) accumulated on the way out.
 // y = x*(rstd*gamma) + (beta - mean*rstd*gamma) is the form ATen's CPU group_norm kernel evaluates.
+// GroupNorm statistics from a producer's partial sums, added by the CONSUMING block itself (k_gn_act, k_out_head_px): L =
+// blockDim / 32 lanes per group, lane j adds entries j, j + L, ... of the group's [sub][part] list (16 loads in flight per
+// trip, added in index order), the lanes meet in lane order (double) — the formula of k_gn_finalize.  sd: 2 * blockDim doubles
+// of LDS; returns the block's {mean[32], rstd[32]} as floats right behind them (valid after the caller's next barrier).
+struct GnPartSrc { const double* part; int nparts[3], maxparts, nsub, spg; double count[3]; };
+__device__ __forceinline__ float* gn_stats_from_parts(const GnPartSrc& a, int b, int p, double* sd, float* mr_out) {
+    const int L = int(blockDim.x) >> 5, tid = threadIdx.x;
+    if (tid < 32 * L) {
+        const int g = tid / L, j = tid - g * L;
+        const int n = a.nparts[p], tot = a.spg * n;
+        const double2* base = reinterpret_cast<const double2*>(a.part) + ((size_t(b) * 3 + p) * a.nsub + size_t(g) * a.spg) * a.maxparts;
+        double S = 0, SS = 0;
+        constexpr int NB = 16;                          // loads in flight per trip (added in index order afterwards)
+        for (int k0 = j; k0 < tot; k0 += NB * L) {
+            double2 v[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int k = k0 + u * L, kc = k < tot ? k : j;
+                const int sub = kc / n, part = kc - sub * n;
+                v[u] = base[size_t(sub) * a.maxparts + part];
+                if (k >= tot) v[u] = make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) { S += v[u].x; SS += v[u].y; }
+        }
+        sd[tid * 2] = S; sd[tid * 2 + 1] = SS;
+    }
+    __syncthreads();
+    float* stf = reinterpret_cast<float*>(sd + 2 * blockDim.x);     // behind the lanes' sums: no second barrier
+    if (tid < 32) {
+        double S = 0, SS = 0;
+        for (int j = 0; j < L; ++j) { S += sd[(tid * L + j) * 2]; SS += sd[(tid * L + j) * 2 + 1]; }
+        const double m = S / a.count[p];
+        double var = SS / a.count[p] - m * m;
+        if (var < 0) var = 0;
+        stf[tid] = float(m); stf[32 + tid] = float(1.0 / sqrt(var + 1e-5));
+        if (mr_out) {
+            float* o = mr_out + ((size_t(b) * 3 + p) * 32 + tid) * 2;
+            o[0] = stf[tid]; o[1] = stf[32 + tid];
+        }
+    }
+    return stf;
+}
+
+static GnPartSrc gn_part_src(const GnPartials& part, const Geo& g, int C) {
+    GnPartSrc s;
+    s.part = part.p; s.maxparts = part.maxparts; s.nsub = part.nsub; s.spg = part.nsub / 32;
+    for (int p = 0; p < 3; ++p) { s.nparts[p] = part.nparts[p]; s.count[p] = double(C / 32) * g.h[p] * g.w[p]; }
+    return s;
+}
+
 struct GnActArgs {
     const float* x[3]; float* y[3];
     const float* gamma[3]; const float* beta[3];
@@ -486,7 +537,7 @@ struct GnActArgs {
     int C, cq, pl, with_means;
     // mr == null && part != null: the statistics come from the producer's partial sums, added here (every block adds the
     // parts of its plane's 32 groups itself: 64 KB from L2 at 128^2 x 128 channels, instead of a k_gn_finalize launch)
-    const double* part; int nparts[3], maxparts, nsub, spg; double count[3];
+    GnPartSrc ps;
     float* mr_out;            // ... and block 0 of each (plane, sample) also leaves {mean, rstd} [B][3][32][2] (the training tape)
 };
 __global__ void k_gn_act(GnActArgs a) {
@@ -497,52 +548,14 @@ __global__ void k_gn_act(GnActArgs a) {
     const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
     if (int(blockIdx.x) >= ntc * ntr) return;
     const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
-    const bool ident = a.mr == nullptr && a.part == nullptr;
+    const bool ident = a.mr == nullptr && a.ps.part == nullptr;
     if (a.mr) {
         if (threadIdx.x < 32) {
             const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
             sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
         }
-    } else if (a.part) {
-        // L = blockDim/32 lanes per group: lane j adds entries j, j+L, ... of the group's [sub][part] list, the lanes meet in
-        // lane order (double) — the formula of k_gn_finalize
-        double* sd = reinterpret_cast<double*>(smem_raw);
-        const int L = int(blockDim.x) >> 5, tid = threadIdx.x;
-        if (tid < 32 * L) {
-            const int g = tid / L, j = tid - g * L;
-            const int n = a.nparts[p], tot = a.spg * n;
-            const double2* base = reinterpret_cast<const double2*>(a.part) + ((size_t(b) * 3 + p) * a.nsub + size_t(g) * a.spg) * a.maxparts;
-            double S = 0, SS = 0;
-            constexpr int NB = 16;                          // loads in flight per trip (added in index order afterwards)
-            for (int k0 = j; k0 < tot; k0 += NB * L) {
-                double2 v[NB];
-#pragma unroll
-                for (int u = 0; u < NB; ++u) {
-                    const int k = k0 + u * L, kc = k < tot ? k : j;
-                    const int sub = kc / n, part = kc - sub * n;
-                    v[u] = base[size_t(sub) * a.maxparts + part];
-                    if (k >= tot) v[u] = make_double2(0.0, 0.0);
-                }
-#pragma unroll
-                for (int u = 0; u < NB; ++u) { S += v[u].x; SS += v[u].y; }
-            }
-            sd[tid * 2] = S; sd[tid * 2 + 1] = SS;
-        }
-        __syncthreads();
-        if (tid < 32) {
-            double S = 0, SS = 0;
-            for (int j = 0; j < L; ++j) { S += sd[(tid * L + j) * 2]; SS += sd[(tid * L + j) * 2 + 1]; }
-            const double m = S / a.count[p];
-            double var = SS / a.count[p] - m * m;
-            if (var < 0) var = 0;
-            float* stf = reinterpret_cast<float*>(sd + 2 * blockDim.x);     // behind the lanes' sums: no second barrier
-            stf[tid] = float(m); stf[32 + tid] = float(1.0 / sqrt(var + 1e-5));
-            if (a.mr_out && blockIdx.x == 0) {
-                float* o = a.mr_out + ((size_t(b) * 3 + p) * 32 + tid) * 2;
-                o[0] = stf[tid]; o[1] = stf[32 + tid];
-            }
-        }
-        sm = reinterpret_cast<float*>(sd + 2 * blockDim.x);
+    } else if (a.ps.part) {
+        sm = gn_stats_from_parts(a.ps, b, p, reinterpret_cast<double*>(smem_raw), a.mr_out && blockIdx.x == 0 ? a.mr_out : nullptr);
     }
     __syncthreads();
     const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
@@ -618,12 +631,11 @@ bool gn_act_can_add_parts(const GnPartials& part, int C) {
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
                   hipStream_t st, const GnPartials* stats_part) {
     GnActArgs a;
-    a.part = nullptr; a.mr_out = nullptr;
+    a.ps.part = nullptr; a.mr_out = nullptr;
     if (stats_part) {                                     // stats.mr (optional) then receives the statistics instead of providing them
         S3D_CHECK(gn_act_can_add_parts(*stats_part, x.C), S3D_ERR_INVALID, "gn_act: partial-sum statistics layout");
         a.mr_out = stats.mr; stats.mr = nullptr;
-        a.part = stats_part->p; a.maxparts = stats_part->maxparts; a.nsub = stats_part->nsub; a.spg = stats_part->nsub / 32;
-        for (int p = 0; p < 3; ++p) { a.nparts[p] = stats_part->nparts[p]; a.count[p] = double(x.C / 32) * x.g.h[p] * x.g.w[p]; }
+        a.ps = gn_part_src(*stats_part, x.g, x.C);
     }
     int maxtiles = 0;
     for (int p = 0; p < 3; ++p) {
@@ -639,7 +651,7 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y,
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
-    if (a.part) shm = std::max(shm, size_t(a.cq) * a.pl * 2 * sizeof(double) + 64 * sizeof(float));
+    if (a.ps.part) shm = std::max(shm, size_t(a.cq) * a.pl * 2 * sizeof(double) + 64 * sizeof(float));
     hipLaunchKernelGGL(k_gn_act, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -1048,6 +1060,7 @@ struct OutHeadArgs {
     const float* mr; const float* w; const float* bias; float* out;
     int h[3], wd[3];
     int C, cq, ppb, Cout, H, W, D;
+    GnPartSrc ps;             // mr == null (k_out_head_px only): the block adds the producing convolution's partial sums itself
 };
 constexpr int kOutCo = 16;     // output channels handled per pass
 // One thread = one pixel x one float4 of channels: the activation is evaluated once per element, each thread
@@ -1136,22 +1149,66 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
     if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; if (blk >= segs2) { blk -= segs2; p = 3; } } }
     if (p == 3) {                                           // the D x D corner of compose_featmaps: zeros
         const long long n = (long long)a.Cout * a.D * a.D;
+        // FUSED: the corner takes the sampler update too (a quarter of the composed map at D = H = W): four independent
+        // elements per thread with their loads issued together — a one-element grid-stride loop is a chain of dependent
+        // load -> store round trips, 12 deep on 64 blocks: it made this launch 31 us instead of 15 + 7
+        constexpr int U = 4;
         SamplerCoef sc;
         if (FUSED) sc = sampler_coef(sa, int(sa.t[b]));
-        for (long long i = (long long)blk * 256 + tid; i < n; i += 256LL * (gridDim.x - segs0 - segs1 - segs2)) {
-            const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
-            const size_t o = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
-            if (!FUSED || a.out) a.out[o] = 0.f;
-            if (FUSED) sampler_element(sa, sc, (long long)o, 0.f);
+        const long long stride = 256LL * U * (gridDim.x - segs0 - segs1 - segs2);
+        for (long long base = (long long)blk * 256 * U + tid; base < n; base += stride) {
+            size_t o[U]; float xv[U], nv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long i = base + 256LL * u;
+                xv[u] = nv[u] = 0.f; o[u] = 0;
+                if (i < n) {
+                    const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
+                    o[u] = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
+                    if (FUSED) { xv[u] = sa.x[o[u]]; if (sa.noise) nv[u] = sa.noise[o[u]]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + 256LL * u >= n) continue;
+                if (!FUSED || a.out) a.out[o[u]] = 0.f;
+                if (FUSED) sampler_element(sa, sc, (long long)o[u], 0.f, xv[u], nv[u]);
+            }
         }
         return;
     }
     const int h = a.h[p], w = a.wd[p];
     const int len = p == 2 ? h : w, nseg = (len + kOhPx - 1) / kOhPx;
     const int line = blk / nseg, s0 = (blk % nseg) * kOhPx;
-    if (tid < 32) {
-        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + tid) * 2;
-        sst[tid] = mr[0]; sst[32 + tid] = mr[1];
+    // FUSED: x_t and the step's eps of this thread's output positions are requested NOW — as the tail of the block (behind the
+    // last barrier) their latency was the block's critical path: 31 us per launch instead of 15 + 7 for head + sampler kernel
+    constexpr int kOutIts = 16 * kOhPx / 256;                 // Cout <= 16
+    float pre_x[kOutIts], pre_n[kOutIts];
+    SamplerCoef sc;
+    if (FUSED) {
+#pragma unroll
+        for (int k = 0; k < kOutIts; ++k) {
+            const int it = tid + 256 * k, co = it >> 6, e = it & 63;
+            pre_x[k] = pre_n[k] = 0.f;
+            if (co < a.Cout && s0 + e < len) {
+                const int sy = p == 2 ? a.H + line : line, sx0 = p == 1 ? a.W + s0 : s0;
+                const size_t o = ((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx0 + e;
+                pre_x[k] = sa.x[o];
+                if (sa.noise) pre_n[k] = sa.noise[o];
+            }
+        }
+        sc = sampler_coef(sa, int(sa.t[b]));                  // (t, then the seven table entries it selects: two dependent round trips, behind the requests above)
+    }
+    const float* st = sst;
+    if (a.mr) {
+        if (tid < 32) {
+            const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + tid) * 2;
+            sst[tid] = mr[0]; sst[32 + tid] = mr[1];
+        }
+    } else {
+        // the statistics of the head's input from its producer's partial sums, as k_gn_act does it: one k_gn_finalize launch less
+        // on the step's dependent chain (the L2-hot reads run beside the x_t / eps requests above)
+        st = gn_stats_from_parts(a.ps, b, p, reinterpret_cast<double*>(sx), nullptr);
     }
     __syncthreads();
     {
@@ -1161,9 +1218,10 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c = 4 * q + k, g = c / cg;
-            A[k] = sst[32 + g] * a.gamma[p][c];
-            Bc[k] = a.beta[p][c] - A[k] * sst[g];
+            A[k] = st[32 + g] * a.gamma[p][c];
+            Bc[k] = a.beta[p][c] - A[k] * st[g];
         }
+        if (!a.mr) __syncthreads();                         // the added statistics live in sx, which the staging below overwrites
         const float* xb = a.x[p] + size_t(b) * h * w * C;
 #pragma unroll
         for (int k = 0; k < kOhPx / LANES; ++k) {
@@ -1196,17 +1254,16 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
             sp[wv][co][e] = s0a + s1a;
         }
     }
-    SamplerCoef sc;
-    if (FUSED) sc = sampler_coef(sa, int(sa.t[b]));          // (requested before the barrier: scalar table loads)
     __syncthreads();
-    for (int it = tid; it < a.Cout * kOhPx; it += 256) {
-        const int co = it >> 6, e = it & 63;
-        if (s0 + e >= len) continue;
+#pragma unroll
+    for (int k = 0; k < kOutIts; ++k) {
+        const int it = tid + 256 * k, co = it >> 6, e = it & 63;
+        if (co >= a.Cout || s0 + e >= len) continue;
         const float v = ((sp[0][co][e] + sp[1][co][e]) + (sp[2][co][e] + sp[3][co][e])) + a.bias[p * a.Cout + co];
         const int sy = p == 2 ? a.H + line : line, sx0 = p == 1 ? a.W + s0 : s0;
         const size_t o = ((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx0 + e;
         if (!FUSED || a.out) a.out[o] = v;
-        if (FUSED) sampler_element(sa, sc, (long long)o, v);
+        if (FUSED) sampler_element(sa, sc, (long long)o, v, pre_x[k], pre_n[k]);
     }
 }
 static bool out_head_px_form(int C, int Cout) {
@@ -1217,8 +1274,10 @@ bool out_head_fuses_sampler(int C, int Cout) { return out_head_px_form(C, Cout);
 // fuse != null: the sampler update of one denoising step is applied to the model output (fuse->model_out is ignored).  When
 // the pixel-chunk form takes the launch it happens in the same kernel and `out` may be null (the model output is then never
 // stored); otherwise `out` is required and the stand-alone k_sampler follows.
+// part != null (stats.mr == null; only when out_head_adds_parts() says so): the kernel adds the producer's GroupNorm partials itself.
+bool out_head_adds_parts(const GnPartials& part, int C, int Cout) { return out_head_px_form(C, Cout) && gn_act_can_add_parts(part, C); }
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const float* w, const float* bias,
-                    int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse) {
+                    int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse, const GnPartials* part) {
     OutHeadArgs a;
     int maxpix = D * D ? 1 : 0;
     for (int p = 0; p < 3; ++p) {
@@ -1227,6 +1286,11 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
         maxpix = std::max(maxpix, a.h[p] * a.wd[p]);
     }
     a.mr = stats.mr; a.w = w; a.bias = bias; a.out = out; a.C = x.C; a.Cout = Cout; a.H = H; a.W = W; a.D = D;
+    memset(&a.ps, 0, sizeof a.ps);
+    if (part) {
+        S3D_CHECK(!stats.mr && out_head_adds_parts(*part, x.C, Cout), S3D_ERR_INVALID, "out head: partial-sum statistics layout");
+        a.ps = gn_part_src(*part, x.g, x.C);
+    } else S3D_CHECK(stats.mr, S3D_ERR_INVALID, "out head: no GroupNorm statistics");
     thread_shape(x.C, a.cq, a.ppb);
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "out head: C=%d unsupported", x.C);
     if (!maxpix || !B) return 0;
@@ -1234,7 +1298,7 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
     if (out_head_px_form(x.C, Cout)) {
         int segs[3];
         for (int p = 0; p < 3; ++p) { const int len = p == 2 ? a.h[p] : a.wd[p], lines = p == 2 ? a.wd[p] : a.h[p]; segs[p] = lines * cdiv(len, kOhPx); }
-        const int corner = D * D ? std::min(64, cdiv(Cout * D * D, 256)) : 0;
+        const int corner = D * D ? std::min(fuse ? 256 : 64, cdiv(Cout * D * D, 256 * 4)) : 0;
         const dim3 grid(segs[0] + segs[1] + segs[2] + corner, B);
         s3d_sampler_args sa;
         memset(&sa, 0, sizeof sa);

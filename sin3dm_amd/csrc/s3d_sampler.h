@@ -12,48 +12,64 @@
 
 namespace s3d {
 
+// (HIP's __fmul_rn / __fadd_rn are plain `*` / `+` unless OCML_BASIC_ROUNDED_OPERATIONS is defined, i.e. still contractable:
+// the functions below switch contraction off with `#pragma clang fp contract(off)`, which travels with the operations when they
+// are inlined into a kernel.)
 struct SamplerCoef {          // per-sample scalars of one step (gathered once per thread / block)
     float sr, srm1, c1, c2, sig_ddpm, nz;
     float sigma, ca, cb;      // ddim: sigma_t, sqrt(alpha_bar_prev), sqrt(1 - alpha_bar_prev - sigma^2)
 };
 
 __device__ __forceinline__ SamplerCoef sampler_coef(const s3d_sampler_args& a, int t) {
+#pragma clang fp contract(off)
     SamplerCoef c;
     c.sr = a.tables[S3D_TAB_SQRT_RECIP * a.T + t]; c.srm1 = a.tables[S3D_TAB_SQRT_RECIPM1 * a.T + t];
     c.c1 = a.tables[S3D_TAB_COEF1 * a.T + t]; c.c2 = a.tables[S3D_TAB_COEF2 * a.T + t];
     c.nz = t != 0 ? 1.f : 0.f;
-    c.sig_ddpm = __fmul_rn(c.nz, expf(__fmul_rn(0.5f, a.tables[S3D_TAB_LOGVAR * a.T + t])));      // nonzero_mask * exp(0.5 * log_variance)
+    c.sig_ddpm = c.nz * expf(0.5f * a.tables[S3D_TAB_LOGVAR * a.T + t]);      // nonzero_mask * exp(0.5 * log_variance)
     const float ab = a.tables[S3D_TAB_ACP * a.T + t], abp = a.tables[S3D_TAB_ACP_PREV * a.T + t];
     // eta * sqrt((1 - abp) / (1 - ab)) * sqrt(1 - ab / abp)      (:579-583)
-    c.sigma = __fmul_rn(__fmul_rn(a.eta, __fsqrt_rn(__fdiv_rn(__fsub_rn(1.f, abp), __fsub_rn(1.f, ab)))), __fsqrt_rn(__fsub_rn(1.f, __fdiv_rn(ab, abp))));
-    c.ca = __fsqrt_rn(abp);
-    c.cb = __fsqrt_rn(__fsub_rn(__fsub_rn(1.f, abp), __fmul_rn(c.sigma, c.sigma)));
+    c.sigma = (a.eta * sqrtf((1.f - abp) / (1.f - ab))) * sqrtf(1.f - ab / abp);
+    c.ca = sqrtf(abp);
+    c.cb = sqrtf((1.f - abp) - c.sigma * c.sigma);
     return c;
 }
 
-// element i of the step: mo = the model's output there.  Writes sample / pred_xstart / mean as the mode asks.
-__device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo) {
-    const float xt = a.x[i];
+// element i of the step: mo = the model's output there, xt = x_t[i], nv = the step's eps there (0 when the step has none).
+// Writes sample / pred_xstart / mean as the mode asks.
+__device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo, float xt, float nv) {
+#pragma clang fp contract(off)
     float x0 = mo;
-    if (a.mean_type == S3D_MEAN_EPSILON) x0 = __fsub_rn(__fmul_rn(c.sr, xt), __fmul_rn(c.srm1, mo));      // _predict_xstart_from_eps (:329-335)
+    if (a.mean_type == S3D_MEAN_EPSILON) {                                                                  // _predict_xstart_from_eps (:329-335)
+        const float p1 = c.sr * xt, p2 = c.srm1 * mo;
+        x0 = p1 - p2;
+    }
     if (a.clip_denoised) x0 = fminf(fmaxf(x0, -1.f), 1.f);
     if (a.mode == S3D_STEP_DDIM) {
         if (a.y0 && a.mask) {                                                                               // in-painting (:568-577)
             const float m = a.mask[i];
-            const float mixed = __fadd_rn(__fmul_rn(m, a.y0[i]), __fmul_rn(__fsub_rn(1.f, m), x0));
-            x0 = a.is_mask_t0 ? mixed : __fadd_rn(__fmul_rn(mixed, c.nz), __fmul_rn(x0, __fsub_rn(1.f, c.nz)));
+            const float q1 = m * a.y0[i], q2 = (1.f - m) * x0;
+            const float mixed = q1 + q2;
+            if (a.is_mask_t0) x0 = mixed;
+            else { const float r1 = mixed * c.nz, r2 = x0 * (1.f - c.nz); x0 = r1 + r2; }
         }
-        const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c.sr, xt), x0), c.srm1);                            // _predict_eps_from_xstart (:346-350)
-        const float mean_pred = __fadd_rn(__fmul_rn(x0, c.ca), __fmul_rn(c.cb, eps));
-        const float nv = a.noise ? a.noise[i] : 0.f;
-        a.sample[i] = __fadd_rn(mean_pred, __fmul_rn(__fmul_rn(c.nz, c.sigma), nv));
+        const float p1 = c.sr * xt;
+        const float eps = (p1 - x0) / c.srm1;                                                               // _predict_eps_from_xstart (:346-350)
+        const float m1 = x0 * c.ca, m2 = c.cb * eps;
+        const float mean_pred = m1 + m2;
+        const float nzs = (c.nz * c.sigma) * nv;
+        a.sample[i] = mean_pred + nzs;
         a.pred_xstart[i] = x0;
     } else {
-        const float mean = __fadd_rn(__fmul_rn(c.c1, x0), __fmul_rn(c.c2, xt));                             // q_posterior_mean_variance (:218-221)
+        const float m1 = c.c1 * x0, m2 = c.c2 * xt;                                                         // q_posterior_mean_variance (:218-221)
+        const float mean = m1 + m2;
         if (a.mean) a.mean[i] = mean;
         a.pred_xstart[i] = x0;
-        if (a.mode == S3D_STEP_DDPM) a.sample[i] = __fadd_rn(mean, __fmul_rn(c.sig_ddpm, a.noise[i]));
+        if (a.mode == S3D_STEP_DDPM) { const float nzs = c.sig_ddpm * nv; a.sample[i] = mean + nzs; }
     }
+}
+__device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo) {
+    sampler_element(a, c, i, mo, a.x[i], a.noise ? a.noise[i] : 0.f);
 }
 
 }  // namespace s3d

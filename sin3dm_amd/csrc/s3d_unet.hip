@@ -292,7 +292,8 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
                 if (vcat_on && !tape && up == sk.g && sk.part.p && rb.has_skip && rb.c_up == h.C && rb.skip_a.dense[0] &&
                     gn_subgroup(Cc) == gn_subgroup(sk.C) && sk.part.nsub == sk.C / gn_subgroup(Cc) && h.C % gn_subgroup(Cc) == 0) {
                     Tri o;
-                    S3D_TRY(f.resblock_cat(rb, h, sk, o, oi == c.n_levels - 1 ? 1 : 0));
+                    // the last block feeds the output head, which adds the partial sums itself when it can (else: k_gn_finalize)
+                    S3D_TRY(f.resblock_cat(rb, h, sk, o, oi == c.n_levels - 1 ? (out_head_fuses_sampler(rb.Cout, c.out_channels) ? 2 : 1) : 0));
                     h = o;
                     continue;
                 }
@@ -323,14 +324,18 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             }
         }
         Tri o;
-        S3D_TRY(f.resblock(m->out_blocks[oi], inp, o, oi == c.n_levels - 1));       // ... and so does the last one (out head)
+        // ... and so does the last one (out head) — which adds the partials itself when it can (inference): partials only
+        const bool last = oi == c.n_levels - 1;
+        const int head_parts = last && !tape && out_head_fuses_sampler(m->out_blocks[oi].Cout, c.out_channels) ? 2 : -1;
+        S3D_TRY(f.resblock(m->out_blocks[oi], inp, o, last, head_parts));
         if (tape) { f.last_rb.index = oi; f.last_rb.is_out = true; tape->out_rb.push_back(f.last_rb); tape->cat_in.push_back(inp); }
         h = o;
         (void)level;
     }
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
-    GnStats stats;
-    S3D_TRY(f.stats_of(h, stats));
+    GnStats stats{nullptr};
+    const bool head_adds = !tape && !h.gn && h.part.p && out_head_adds_parts(h.part, h.C, c.out_channels);
+    if (!head_adds) S3D_TRY(f.stats_of(h, stats));
     if (tape) { tape->head_in = h; tape->head_stats = stats; tape->arena_off = ar.off; tape->valid = !meas; }
     // a fused step on a width the pixel-chunk head does not take: the model output goes through a workspace buffer
     if (fuse && !out && !out_head_fuses_sampler(h.C, c.out_channels)) out = ar.alloc<float>(size_t(B) * c.out_channels * (H + D) * (W + D));
@@ -338,7 +343,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
         aa.film = nullptr; aa.film_stride = 0;
-        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st, fuse));
+        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st, fuse, head_adds ? &h.part : nullptr));
     }
     return 0;
 }

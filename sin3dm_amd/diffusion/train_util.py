@@ -81,7 +81,9 @@ class FlatAdamW:
 class TrainLoop:
     def __init__(self, *, model, diffusion, data, batch_size, microbatch, lr, ema_rate, log_interval, save_interval,
                  resume_checkpoint, use_fp16=False, fp16_scale_growth=1e-3, schedule_sampler=None, weight_decay=0.0,
-                 lr_anneal_steps=0, log_dir=None):
+                 lr_anneal_steps=0, log_dir=None, optimizer=None):
+        """optimizer: an object with .step(flat_grad) and .lr working on model.flat_parameters (default: FlatAdamW, the fused
+        AdamW + EMA kernel; the CPU tests of the multi-rank control flow hand in a plain one)."""
         if use_fp16:
             raise NotImplementedError("use_fp16 is not runnable in the reference (see TriplaneUNetModelSmall) and not implemented")
         self.model, self.diffusion, self.data = model, diffusion, data
@@ -109,12 +111,16 @@ class TrainLoop:
         if self.world > 1:                           # identical start on every rank (the role of sync_params)
             parallel.broadcast_flat_(self.model.flat_parameters, src=0)
             self.model.mark_parameters_changed()
-        self.opt = FlatAdamW(model, lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
+        self.opt = optimizer if optimizer is not None else FlatAdamW(model, lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
         if self.resume_step:
             self._load_optimizer_and_ema()
         self._grad = th.empty_like(self.model.flat_parameters)
-        self.overlap_allreduce = os.environ.get("S3D_OVERLAP_ALLREDUCE", "1") != "0"
-        self._marks = self._comm = self._groups = None
+        # Gradient exchange overlapped with the backward pass: OFF by default.  The communication-stream / event ordering has
+        # never run on more than one GPU (no multi-GPU node was available to this build), and from three ranks on the cut
+        # vector is reduced in a different order than the whole one (parallel.average_flat_groups_): S3D_OVERLAP_ALLREDUCE=1
+        # opts in until a multi-GPU RCCL run has compared both.
+        self.overlap_allreduce = os.environ.get("S3D_OVERLAP_ALLREDUCE", "0") == "1"
+        self._marks = self._comm = self._groups = self._staging = None
 
     # ------------------------------------------------------------------ resume
     def _load_optimizer_and_ema(self):
@@ -158,14 +164,16 @@ class TrainLoop:
             # loss = mean over the GLOBAL batch.  The backward pass fills the flat gradient from the output blocks towards
             # the input; the groups that are final early are all-reduced on a communication stream while the rest of it
             # runs (RCCL over xGMI on GPUs), joined before the optimizer step.  Bit-identical to the single all-reduce at
-            # world size 2 (tests/test_parallel.py); unmeasured on hardware until an 8-GPU node is available.
-            if self._marks is None:
-                self._marks = [th.cuda.Event(), th.cuda.Event()]
-                self._comm = th.cuda.Stream(device=dev)
+            # world size 2 (tests/test_parallel.py); unmeasured on hardware until a multi-GPU node is available.
+            if self._groups is None:
                 self._groups = self.model.grad_ready_groups()
+                self._staging = parallel.GroupStaging(self._grad, self._groups)       # allocated once, not per step
+                if self._grad.is_cuda:
+                    self._marks = [th.cuda.Event(), th.cuda.Event()]
+                    self._comm = th.cuda.Stream(device=dev)
             losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad,
                                                                     grad_marks=self._marks)
-            parallel.average_flat_groups_(grad, self._groups, self._marks, self._comm)
+            parallel.average_flat_groups_(grad, self._groups, self._marks, self._comm, staging=self._staging)
         else:
             losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
             parallel.average_flat_(grad)                  # one all-reduce of the whole flat vector per step

@@ -6,6 +6,9 @@ children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1
     fails within seconds — a rank that dies before the RCCL rendezvous must not leave its peers inside
     `init_process_group` / a barrier until the store or collective timeout (minutes);
   * an overall deadline (S3D_LAUNCH_TIMEOUT seconds, default 3600) bounds a hung collective the same way;
+  * the children never outlive the parent's watch: they run in their own sessions (process groups), the poll loop sits in a
+    try/finally that stops every group, and SIGTERM / SIGINT / SIGHUP to the parent (a harness `timeout`, a cancelled gpurun
+    call, Ctrl-C) are turned into that same clean-up instead of leaving N ranks inside an RCCL collective with their GPUs held;
   * rank 0's stdout is drained by a thread (no pipe dead-lock) and its last JSON line is relayed.
 
 The reference is single-process (src/utils/dist_util.py:29-42 is commented out); this is the launch side of SURVEY.md §8e.
@@ -29,23 +32,43 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def _signal_group(p, sig):
+    """Signal the child's whole process group (it leads its own session: helpers it started go with it)."""
+    try:
+        os.killpg(p.pid, sig)
+    except (OSError, ProcessLookupError):
+        try:
+            p.send_signal(sig)
+        except OSError:
+            pass
+
+
 def _stop(procs, grace=5.0):
     live = [p for p in procs if p.poll() is None]
     for p in live:
-        try:
-            p.send_signal(signal.SIGTERM)
-        except OSError:
-            pass
+        _signal_group(p, signal.SIGTERM)
     t_end = time.time() + grace
     for p in live:
         try:
             p.wait(timeout=max(0.05, t_end - time.time()))
         except subprocess.TimeoutExpired:
-            try:
-                p.kill()
-            except OSError:
-                pass
+            _signal_group(p, signal.SIGKILL)
             p.wait()
+    for p in procs:                       # anything a finished rank left behind in its group
+        if p not in live and _group_alive(p):
+            _signal_group(p, signal.SIGKILL)
+
+
+def _group_alive(p):
+    try:
+        os.killpg(p.pid, 0)
+        return True
+    except (OSError, ProcessLookupError):
+        return False
+
+
+class _Interrupted(Exception):
+    pass
 
 
 def spawn_ranks(script, argv, n, timeout=None, poll_s=0.1, out=sys.stdout, err=sys.stderr, module=False, relay_json=True) -> int:
@@ -57,30 +80,49 @@ def spawn_ranks(script, argv, n, timeout=None, poll_s=0.1, out=sys.stdout, err=s
     base = {k: v for k, v in os.environ.items() if k not in _RDZV_KEYS}
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        cmd = [sys.executable] + (["-m", script] if module else [os.path.abspath(script)]) + list(argv)
-        stdout = None if not relay_json else (subprocess.PIPE if r == 0 else subprocess.DEVNULL)
-        procs.append(subprocess.Popen(cmd, env=env, stdout=stdout, text=True))
     chunks = []
-    reader = threading.Thread(target=lambda: chunks.extend(procs[0].stdout) if relay_json else None, daemon=True)
-    reader.start()
-    t0 = time.time()
     failed, why = None, None
-    while True:
-        rcs = [p.poll() for p in procs]
-        bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
-        if bad:
-            failed, why = bad, f"rank(s) {bad} exited with {[rcs[i] for i in bad]}"
-            break
-        if all(rc == 0 for rc in rcs):
-            break
-        if time.time() - t0 > timeout:
-            failed, why = [i for i, rc in enumerate(rcs) if rc is None], f"no result after {timeout:.0f} s"
-            break
-        time.sleep(poll_s)
-    if failed is not None:
-        _stop(procs)
+    t0 = time.time()
+
+    def on_signal(signum, frame):
+        raise _Interrupted(signal.Signals(signum).name)
+
+    handled = [sg for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP) if threading.current_thread() is threading.main_thread()]
+    previous = {sg: signal.signal(sg, on_signal) for sg in handled}
+    reader = None
+    try:
+        for r in range(n):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            cmd = [sys.executable] + (["-m", script] if module else [os.path.abspath(script)]) + list(argv)
+            stdout = None if not relay_json else (subprocess.PIPE if r == 0 else subprocess.DEVNULL)
+            procs.append(subprocess.Popen(cmd, env=env, stdout=stdout, text=True, start_new_session=True))
+        reader = threading.Thread(target=lambda: chunks.extend(procs[0].stdout) if relay_json else None, daemon=True)
+        reader.start()
+        while True:
+            rcs = [p.poll() for p in procs]
+            bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
+            if bad:
+                failed, why = bad, f"rank(s) {bad} exited with {[rcs[i] for i in bad]}"
+                break
+            if all(rc == 0 for rc in rcs):
+                break
+            if time.time() - t0 > timeout:
+                failed, why = [i for i, rc in enumerate(rcs) if rc is None], f"no result after {timeout:.0f} s"
+                break
+            time.sleep(poll_s)
+    except _Interrupted as e:
+        failed, why = list(range(len(procs))), f"the launcher received {e}"
+    except KeyboardInterrupt:
+        failed, why = list(range(len(procs))), "the launcher was interrupted"
+    finally:
+        # whatever ended the watch — a failed rank, the deadline, a signal, an exception in this function — no rank survives it
+        if any(p.poll() is None for p in procs) or failed is not None:
+            _stop(procs)
+        for sg, h in previous.items():
+            signal.signal(sg, h)
+    if reader is None:
+        err.write(f"{os.path.basename(script)}: launch of {n} ranks failed: {why}\n")
+        return 1
     reader.join(timeout=5.0)
     text = "".join(chunks)
     line = next((l for l in reversed(text.splitlines()) if l.startswith("{")), None)

@@ -20,14 +20,43 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None):
+def init(backend=None, device=None, timeout_s=None):
     """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
     rank, local, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend, **kw)
     return rank, local, world
+
+
+def launch_token():
+    """A string every rank of ONE launch derives identically and two launches do not share: the rendezvous port plus the
+    launcher's pid (torchrun's run id when it provides one)."""
+    return "%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+
+
+def wait_for_file(path, poll_s=0.5, log_every_s=60.0, what="a file"):
+    """Block until `path` exists — the hand-off for work ONE rank does for minutes before the process group is created (the
+    auto-encoder stage of train.py).  No collective and no timeout: a rank parked in an RCCL barrier for the length of stage 1
+    would be aborted by the collective watchdog whenever the stage outlasts it.  Ends early (SystemExit) only when the
+    launcher is gone (the parent pid changed: nobody is left to stop this rank), otherwise the launcher ends the wait by
+    terminating the rank when rank 0 fails."""
+    import sys
+    import time
+    parent = os.getppid()
+    t0 = last = time.time()
+    while not os.path.exists(path):
+        if os.getppid() != parent:
+            raise SystemExit(f"waiting for {what}: the launcher is gone, giving up")
+        time.sleep(poll_s)
+        now = time.time()
+        if now - last >= log_every_s:
+            print(f"[rank {os.environ.get('RANK', '?')}] still waiting for {what} ({now - t0:.0f} s)", file=sys.stderr, flush=True)
+            last = now
 
 
 def shard_indices(n_samples, rank, world):
@@ -119,23 +148,50 @@ def _bucketed(flat, ranges, min_elems=1 << 16):
     return big, small
 
 
-def average_flat_groups_(flat, groups, marks=None, comm_stream=None):
-    """Mean over ranks of `flat`, group by group: bit-identical to average_flat_ at world size 2 (a two-term sum does not
-    depend on how the vector is cut).  On a GPU, with `marks` (the events the backward pass recorded) and `comm_stream`: each
-    group's all-reduces are enqueued on comm_stream behind its event, so they run while the main stream is still in the
-    backward pass; the caller's stream waits for comm_stream at the end.  Without them (CPU / gloo): sequential."""
+class GroupStaging:
+    """The packed buffers of the small ranges of each group, allocated ONCE (per flat vector and grouping) and reused by every
+    step: a per-step torch.cat on the communication stream would allocate there every step (and its block would be recycled
+    across streams by the caching allocator)."""
+
+    def __init__(self, flat, groups):
+        self.key = (flat.data_ptr(), flat.numel(), tuple(tuple(g) for g in groups))
+        self.bufs = []
+        for ranges in groups:
+            _, small = _bucketed(flat, ranges)
+            n = sum(e - b for b, e in small)
+            self.bufs.append(torch.empty(n, dtype=flat.dtype, device=flat.device) if n else None)
+
+    def matches(self, flat, groups):
+        return self.key == (flat.data_ptr(), flat.numel(), tuple(tuple(g) for g in groups))
+
+
+def average_flat_groups_(flat, groups, marks=None, comm_stream=None, staging=None):
+    """Mean over ranks of `flat`, group by group.  At world size 2 this is bit-identical to average_flat_ (a two-term sum does
+    not depend on how the vector is cut); from three ranks on the ring / tree reduction order of an element depends on where its
+    chunk boundaries fall, so the cut vector and the whole vector agree only to fp32 round-off — S3D_OVERLAP_ALLREDUCE=0 and =1
+    are then two different (equally valid) training trajectories.
+    On a GPU, with `marks` (the events the backward pass recorded) and `comm_stream`: each group's all-reduces are enqueued on
+    comm_stream behind its event, so they run while the main stream is still in the backward pass; the caller's stream waits for
+    comm_stream at the end.  Without them (CPU / gloo): sequential.  staging: a GroupStaging kept by the caller across steps
+    (None: buffers are allocated for this call)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return flat
     world = dist.get_world_size()
     on_gpu = flat.is_cuda and comm_stream is not None
     main = torch.cuda.current_stream(flat.device) if on_gpu else None
+    if staging is None or not staging.matches(flat, groups):
+        staging = GroupStaging(flat, groups)
 
-    def reduce_group(ranges):
+    def reduce_group(k, ranges):
         big, small = _bucketed(flat, ranges)
         for b, e in big:
             dist.all_reduce(flat[b:e])
         if small:
-            stage = torch.cat([flat[b:e] for b, e in small])
+            stage = staging.bufs[k]
+            o = 0
+            for b, e in small:
+                stage[o:o + e - b].copy_(flat[b:e])
+                o += e - b
             dist.all_reduce(stage)
             o = 0
             for b, e in small:
@@ -151,9 +207,9 @@ def average_flat_groups_(flat, groups, marks=None, comm_stream=None):
             else:
                 comm_stream.wait_stream(main)             # the last group: everything the main stream has been given so far
             with torch.cuda.stream(comm_stream):
-                reduce_group(ranges)
+                reduce_group(k, ranges)
         else:
-            reduce_group(ranges)
+            reduce_group(k, ranges)
     if on_gpu:
         main.wait_stream(comm_stream)
     flat.mul_(1.0 / world)

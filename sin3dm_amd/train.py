@@ -6,7 +6,9 @@
     S3D_GPUS=8 python -m sin3dm_amd.train --tag EXP --data_path ... --diff_batch_size 4     # the same, self-launched (sin3dm_amd/launcher.py)
 
 Stage 1 (src/train.py:8-29): ShapeAutoEncoder.train on the preprocessed shape, then EXP/encoding/{args.json, feat.npz,
-ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it, the others wait.
+ckpt_final.pth, eval_stat.json}.  It is a single-shape fit of a few minutes: rank 0 runs it BEFORE the process group exists and
+the other ranks wait on a marker file (no collective is open while it runs, so neither --enc_n_iters nor a slow box can trip
+the RCCL watchdog); torch.distributed is initialised after it, for stage 2 only.
 Stage 2 (:32-75): the triplane diffusion UNet (sin3dm_amd/diffusion/train_util.py) -> EXP/diffusion/{args.json,
 ema_<rate>_<step>.pt, opt<step>.pt, progress.jsonl} — the files sample.py of either implementation reads.
 Multi-GPU: --diff_batch_size is PER GPU (the reference's 32 = 8 x 4); gradients are averaged with one all-reduce per
@@ -63,19 +65,32 @@ def train_diffusion(args, rank=0):
               weight_decay=args.weight_decay, lr_anneal_steps=args.diff_n_iters, log_dir=log_dir).run_loop()
 
 
+def stage1_marker(tag):
+    """Written by rank 0 once the experiment directory and the encoding are in place (one name per launch)."""
+    return os.path.join(tag, ".stage1_done_" + parallel.launch_token())
+
+
 def main(argv=None, confirm=input):
     rank, local, world = parallel.env_rank_world()
     args = train_args(argv, confirm=confirm, write=rank == 0)        # rank 0 alone creates directories / symlink / args.json
     seed_all(0 + rank)                               # per-rank timestep / noise streams; weights are broadcast from rank 0
     dist_util.setup_dist(local if world > 1 else args.gpu_id)
-    parallel.init(device=dist_util.dev())
-    parallel.barrier()                               # the experiment directory exists before anyone reads it
-    if args.enc_log is None:
-        if rank == 0:
+    # stage 1 belongs to one process and takes minutes: no process group yet, the other ranks wait for its marker file
+    marker = stage1_marker(args.tag)
+    if rank == 0:
+        if args.enc_log is None:
             train_ae(args)
-        parallel.barrier()
-    if not args.only_enc:
-        train_diffusion(args, rank)
+        if world > 1:
+            open(marker, "w").close()                # the experiment directory + encoding exist: everyone may read them
+    else:
+        parallel.wait_for_file(marker, what="rank 0's auto-encoder stage")
+    if args.only_enc:
+        return
+    parallel.init(device=dist_util.dev())
+    parallel.barrier()
+    if rank == 0 and world > 1:
+        os.remove(marker)                            # every rank is past its wait
+    train_diffusion(args, rank)
     parallel.barrier()
 
 

@@ -80,3 +80,50 @@ def test_launch_deadline(tmp_path):
     t0 = time.time()
     rc = spawn_ranks(str(script), [], 2, timeout=2.0, err=err)
     assert rc == 1 and time.time() - t0 < 30 and "no result after" in err.getvalue()
+
+
+def test_config_c3_line_over_two_ranks():
+    """`bench.py --config c3 --gpus 2` (BASELINE configs[2]'s per-GPU share: DDIM-100, batch 8 per GPU) goes through the same
+    self-spawning launch; the line names the workload, counts batch x ranks samples and keeps the contract's keys."""
+    r = _run("--gpus", "2", "--config", "c3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["name"] == "c3" and line["config"]["batch_per_gpu"] == 8 and line["config"]["steps_per_sample"] == 100
+    assert "DDIM-100" in line["metric"] and "configs[2]" in line["config"]["workload"]
+    assert line["config"]["parallelism"] == "2 x 8 independent samples" and line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["devices_verified_distinct"] is False        # the CPU dry run has no bus id / uuid to verify: said, not assumed
+    r = _run("--gpus", "1", "--config", "c5")
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["name"] == "c5" and "(256,256,128)" in line["metric"]
+
+
+def test_launcher_stops_its_ranks_when_it_is_terminated(tmp_path):
+    """SIGTERM to the launcher (a harness `timeout`, a cancelled gpurun call): the ranks — each leading its own session — are
+    stopped with it instead of staying behind inside a collective with their GPUs held."""
+    import signal
+    import time
+    child = tmp_path / "rank.py"
+    child.write_text("import os, sys, time\nopen(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "from sin3dm_amd.launcher import spawn_ranks\n"
+        f"sys.exit(spawn_ranks({str(child)!r}, [{str(tmp_path / 'pid')!r}], 2, timeout=500))\n")
+    p = subprocess.Popen([sys.executable, str(parent)], stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not all(os.path.exists(f"{tmp_path}/pid.{r}") and open(f"{tmp_path}/pid.{r}").read() for r in (0, 1)):
+        assert time.time() - t0 < 60 and p.poll() is None
+        time.sleep(0.1)
+    pids = [int(open(f"{tmp_path}/pid.{r}").read()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode == 1 and "SIGTERM" in err
+    time.sleep(0.5)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except ProcessLookupError:
+            alive = False
+        assert not alive, f"rank process {pid} outlived its launcher"

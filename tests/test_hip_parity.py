@@ -263,6 +263,122 @@ def test_sampler_steps_golden():
             assert pm["mean"].shape == pm["variance"].shape == pm["log_variance"].shape == x.shape
 
 
+BRANCH_TAGS = ["noclip", "eps", "eps_noclip", "eps_r20", "small", "small_r20_noclip", "eps_small"]
+
+
+@pytest.mark.parametrize("tag", BRANCH_TAGS)
+def test_sampler_branches_golden(tag):
+    """Reachable branches without a default-path fixture: clip_denoised=False (train_util.py:181), ModelMeanType.EPSILON
+    (gaussian_diffusion.py:306-315, 329-335) and ModelVarType.FIXED_SMALL (:286-289), at t in {T-1, 1, 0}.
+    (1) s3d_sampler_step on the reference's own model output: the update arithmetic alone, 2e-6.  (2) p_sample / ddim_sample /
+    p_mean_variance through the model at TOL_FWD — times sqrt(1/alphas_cumprod - 1) (157 at t = 999) where an eps-derived x0
+    multiplies the UNet's round-off."""
+    from sin3dm_amd import _lib
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    g = golden("sampler_branches")
+    H, W, D = (int(v) for v in g["hwd"])
+    kw = dict(H=H, W=W, D=D)
+    px, small, resp, clip = (int(v) for v in g[f"{tag}.cfg"])
+    diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=bool(px), sigma_small=bool(small),
+                                     timestep_respacing=str(resp) if resp else "")
+    model = make_model(32)
+    Tn = diff.num_timesteps
+    for ti in (Tn - 1, 1, 0):
+        pre = f"{tag}.t{ti}"
+        x, eps, mo = cu(g[pre + ".x"]), cu(g[pre + ".eps"]), cu(g[pre + ".model_out"])
+        t = torch.full((x.shape[0],), ti, device=dev(), dtype=torch.int64)
+        # (1) the kernel on the reference's model output
+        for mode, eta, want in ((_lib.STEP_DDPM, 0.0, "p_sample"), (_lib.STEP_DDIM, 0.0, "ddim_sample"), (_lib.STEP_DDIM, 0.7, "ddim_eta_sample")):
+            sample, pred, mean = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            a = _lib.SamplerArgs(mode=mode, mean_type=diff._mean_type_code(), clip_denoised=clip, is_mask_t0=0, eta=eta, T=Tn,
+                                 batch=x.shape[0], per_sample=x[0].numel(), model_out=mo.data_ptr(), x=x.data_ptr(),
+                                 noise=eps.data_ptr(), t=t.data_ptr(), tables=diff._tables(x.device).data_ptr(), y0=None, mask=None,
+                                 sample=sample.data_ptr(), pred_xstart=pred.data_ptr(), mean=mean.data_ptr() if mode == _lib.STEP_DDPM else None)
+            _lib.check(_lib.load().s3d_sampler_step(a, _lib.stream_ptr()))
+            assert relerr(sample.cpu().numpy(), g[pre + "." + want]) < 2e-6, (ti, want)
+            assert relerr(pred.cpu().numpy(), g[pre + ".p_xstart"]) < 2e-6, (ti, want)
+            if mode == _lib.STEP_DDPM:
+                assert relerr(mean.cpu().numpy(), g[pre + ".mean"]) < 2e-6
+        # (2) through the public API
+        srm1 = float(diff.sqrt_recipm1_alphas_cumprod[ti])
+        amp = 1.0 if px else max(1.0, srm1 * float(np.abs(g[pre + ".model_out"]).max()) / float(np.abs(g[pre + ".p_xstart"]).max()))
+        diff.noise_fn = lambda z: eps.clone()
+        with torch.no_grad():
+            o1 = diff.p_sample(model, x, t, clip_denoised=bool(clip), model_kwargs=kw)
+            o2 = diff.ddim_sample(model, x, t, clip_denoised=bool(clip), model_kwargs=kw)
+            o3 = diff.ddim_sample(model, x, t, clip_denoised=bool(clip), model_kwargs=kw, eta=0.7)
+            pm = diff.p_mean_variance(model, x, t, clip_denoised=bool(clip), model_kwargs=kw)
+        tol = TOL_FWD * amp
+        assert relerr(o1["sample"].cpu().numpy(), g[pre + ".p_sample"]) < tol and relerr(o1["pred_xstart"].cpu().numpy(), g[pre + ".p_xstart"]) < tol
+        assert relerr(o2["sample"].cpu().numpy(), g[pre + ".ddim_sample"]) < tol and relerr(o3["sample"].cpu().numpy(), g[pre + ".ddim_eta_sample"]) < tol
+        assert relerr(pm["mean"].cpu().numpy(), g[pre + ".mean"]) < tol and relerr(pm["pred_xstart"].cpu().numpy(), g[pre + ".p_xstart"]) < tol
+        assert abs(float(pm["variance"].flatten()[0]) - float(g[pre + ".variance"][0])) <= 1e-6 * abs(float(g[pre + ".variance"][0]))
+        assert abs(float(pm["log_variance"].flatten()[0]) - float(g[pre + ".log_variance"][0])) <= 1e-6 * abs(float(g[pre + ".log_variance"][0]))
+
+
+@pytest.mark.parametrize("tag,px,resp,ddim,clip", [("noclip_ddpm20", True, "20", False, False), ("eps_ddim10", False, "10", True, True)])
+def test_trajectories_branches_golden(tag, px, resp, ddim, clip):
+    """An unclipped ancestral run as TrainLoop._sample_and_visualize does it (train_util.py:181) and an epsilon-prediction DDIM
+    run, whole loops against the reference with its eps stream."""
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    g = golden("trajectories_branches")
+    H, W, D = (int(v) for v in g["hwd"])
+    model = make_model(32)
+    diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=px, timestep_respacing=resp)
+    eps = iter(cu(g[f"{tag}.eps"]))
+    diff.noise_fn = lambda z: next(eps).clone()
+    xT = cu(g[f"{tag}.xT"])
+    fn = diff.ddim_sample_loop if ddim else diff.p_sample_loop
+    final = fn(model, tuple(xT.shape), noise=xT.clone(), clip_denoised=clip, model_kwargs=dict(H=H, W=W, D=D)).cpu().numpy()
+    assert relerr(final, g[f"{tag}.final"]) < 2e-4
+    # the D x D corner: the model's output is zero there.  As an x0 prediction that ends the corner at exactly 0; as an eps
+    # prediction x0 = x_t / sqrt(alphas_cumprod) there, clamped — the reference's corner is +-1, and so is ours
+    corner, ref_corner = final[..., H:, W:], g[f"{tag}.final"][..., H:, W:]
+    assert np.all(corner == 0) if px else (np.all(np.abs(ref_corner) == 1) and np.array_equal(corner, ref_corner))
+
+
+@pytest.mark.parametrize("mc", [32, 64])
+def test_fused_denoise_step_equals_forward_plus_sampler_kernel(mc):
+    """The sampling loops' step (s3d_unet_step_film: the output head applies the sampler update, SURVEY section 2b K8 + K9) against
+    the single-step API (forward, then s3d_sampler_step), bit for bit: DDPM, DDIM with eta, the in-painting branch, EPSILON and
+    unclipped, t = 0 included; mc = 64 takes the pixel-chunk head (one launch), mc = 32 the generic head followed by the sampler
+    kernel.  And the loops draw their eps ahead from the device generator without changing the single-step API's stream use."""
+    from sin3dm_amd import _lib
+    from sin3dm_amd.diffusion.gaussian_diffusion import HostTimesteps
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    H, W, D = 12, 9, 7
+    kw = dict(H=H, W=W, D=D)
+    model = make_model(mc)
+    B = 2
+    shape = (B, 12, H + D, W + D)
+    x, eps = cu(T.synthetic_noise(shape, 91)), cu(T.synthetic_noise(shape, 92))
+    y0 = cu(T.synthetic_noise(shape, 93))
+    mask = (cu(T.synthetic_noise(shape, 94)) > 0).float()
+    for px, resp in ((True, "10"), (False, "")):
+        diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=px, timestep_respacing=resp)
+        for ti in (diff.num_timesteps - 1, 0):
+            t = torch.full((B,), ti, device=dev(), dtype=torch.int64)
+            ht = HostTimesteps(t, (ti,) * B)
+            for mode, extra in ((_lib.STEP_DDPM, {}), (_lib.STEP_DDIM, dict(eta=0.7)), (_lib.STEP_DDIM, dict(y0=y0, mask=mask)),
+                                (_lib.STEP_DDIM, dict(y0=y0, mask=mask, is_mask_t0=True))):
+                for clip in (True, False):
+                    with torch.no_grad():
+                        a = diff._step(mode, model, x, ht, clip, None, kw, fuse=False, noise=eps, **extra)
+                        b = diff._step(mode, model, x, ht, clip, None, kw, fuse=True, noise=eps, **extra)
+                    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (mc, px, ti, mode, extra.keys(), clip)
+    # device-generator loops: reproducible under a seed, finite, corner at zero
+    diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True, timestep_respacing="10")
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        outs.append(diff.p_sample_loop(model, shape, model_kwargs=kw))
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all() and float(outs[0][..., H:, W:].abs().max()) == 0.0
+    diff._NOISE_AHEAD_BYTES = 3 * 4 * outs[0].numel()            # three steps per randn launch: the chunk boundary inside a loop
+    torch.manual_seed(5)
+    z = diff.p_sample_loop(model, shape, model_kwargs=kw)
+    assert torch.isfinite(z).all() and float(z[..., H:, W:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("tag,resp,ddim", [("ddim10", "10", True), ("ddpm20", "20", False)])
 def test_trajectories_golden(tag, resp, ddim):
     g = golden("trajectories")

@@ -88,6 +88,33 @@ def test_training_losses_and_grads(tag, mc, raw, ssn, cm, B):
     assert w["norm"] < 2e-4 and w["proj"] < 2e-4 and w["head"] < 2e-3 and w["full"] < 2e-4, (w, _offenders(grads, g, f"{tag}.grad"))
 
 
+@pytest.mark.parametrize("tag,ssn,B", [("mc32_a", True, 2), ("mc32_add", False, 1)])
+def test_training_losses_and_grads_epsilon_target(tag, ssn, B):
+    """predict_xstart=False (ModelMeanType.EPSILON, script_util.py:29,47): the MSE target is the noise
+    (gaussian_diffusion.py:829-835); loss terms and every parameter gradient against the reference's autograd."""
+    import torch
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    g = golden("train_eps")
+    m = _model(32, ssn=ssn)
+    diffusion = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=False)
+    H, W, D, x0, noise = _inputs(g, tag, B)
+    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    terms = diffusion.training_losses(m, x0, t, model_kwargs=dict(H=H, W=W, D=D), noise=noise)
+    for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+        assert relerr(terms[k].detach().cpu().numpy(), g[f"{tag}.{k}"]) < 2e-5, k
+    (terms["loss"] * torch.ones(B, device="cuda")).mean().backward()
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in m.named_parameters()}
+    w = digest_errors(grads, g, f"{tag}.grad")
+    assert w["norm"] < 2e-4 and w["proj"] < 2e-4 and w["head"] < 2e-3 and w["full"] < 2e-4, (w, _offenders(grads, g, f"{tag}.grad"))
+    # the graph-free path (TrainLoop) takes the same target
+    m2 = _model(32, ssn=ssn)
+    terms2, flat = diffusion.training_losses_and_grads(m2, x0, t, torch.ones(B, device="cuda"), dict(H=H, W=W, D=D), noise=noise)
+    assert relerr(terms2["loss"].cpu().numpy(), g[f"{tag}.loss"]) < 2e-5
+    g2 = {k: v.cpu().numpy() for k, v in m2.split_flat(flat).items()}
+    w2 = digest_errors(g2, g, f"{tag}.grad")
+    assert w2["norm"] < 2e-4 and w2["proj"] < 2e-4, w2
+
+
 def test_grads_with_the_direct_weight_gradient_kernel():
     """S3D_WGRAD_WINO=0 (the direct 3x3 weight gradient, default for 1x1 / 5x5) against the same golden gradients; the
     switch is read once per process, hence the subprocess."""

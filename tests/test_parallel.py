@@ -191,3 +191,141 @@ def test_two_rank_gloo_chunked_allreduce_equals_whole_vector(tmp_path):
     for r in res:
         assert r["equal"] and r["covered_once"], r
     assert res[0]["sum"] == res[1]["sum"]
+
+
+LOOP_WORKER = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["S3D_REPO"])
+import numpy as np, torch
+from sin3dm_amd import parallel, testing as T
+from sin3dm_amd.diffusion.train_util import TrainLoop
+rank, local, world = parallel.init(backend="gloo")
+
+# a stand-in denoiser with the REAL flat-vector layout (state-dict order of a 32-channel UNet) and a deterministic gradient,
+# so that TrainLoop's multi-rank control flow (broadcast, exchange, optimizer step, annealing) runs without a GPU
+layout, off = [], 0
+for name, shp in T.unet_param_shapes(model_channels=32).items():
+    n = int(np.prod(shp)); layout.append((name, off, n)); off += n
+
+class Toy:
+    def __init__(self, seed):
+        self.flat_parameters = torch.randn(off, generator=torch.Generator().manual_seed(seed))
+    def mark_parameters_changed(self): pass
+    def grad_ready_groups(self): return parallel.grad_ready_groups(layout)
+    def named_parameters(self): return iter(())
+    def parameters(self): return iter([self.flat_parameters])
+
+class ToyDiffusion:
+    num_timesteps = 1000
+    def training_losses_and_grads(self, model, micro, t, weights, cond, grad_out=None, grad_marks=None):
+        assert grad_marks is None                        # CPU: no events
+        g = torch.tanh(model.flat_parameters * 3.0) * micro.mean() + torch.sin(model.flat_parameters * (1.0 + t.float().mean() / 1000))
+        g = g * torch.logspace(-4, 2, off)               # every magnitude
+        grad_out.copy_(g)
+        z = torch.zeros(micro.shape[0])
+        return {"loss": z, "mse_xy": z, "mse_xz": z, "mse_yz": z}, grad_out
+
+class Sgd:
+    def __init__(self, model, lr): self.model, self.lr = model, lr
+    def step(self, g): self.model.flat_parameters.add_(g, alpha=-self.lr)
+
+def data():
+    k = 0
+    while True:
+        yield torch.full((2, 12, 4, 4), float(rank + 1 + k)), {}
+        k += 1
+
+def run(overlap):
+    os.environ["S3D_OVERLAP_ALLREDUCE"] = "1" if overlap else "0"
+    torch.manual_seed(100 + rank)                        # the timestep sampler's stream: per rank, identical for both runs
+    np.random.seed(100 + rank)
+    model = Toy(seed=5 + rank)                           # ranks start DIFFERENT: the loop must broadcast rank 0's copy
+    loop = TrainLoop(model=model, diffusion=ToyDiffusion(), data=data(), batch_size=2, microbatch=-1, lr=1e-2, ema_rate="0.99",
+                     log_interval=1000, save_interval=10**9, resume_checkpoint=False, lr_anneal_steps=10, log_dir=None,
+                     optimizer=Sgd(model, 1e-2))
+    assert loop.overlap_allreduce == overlap and loop.world == 2
+    it = data()
+    for _ in range(2):
+        batch, cond = next(it)
+        loop.run_step(batch, cond)
+        loop.step += 1
+    return model.flat_parameters.clone(), loop
+
+a, la = run(False)
+b, lb = run(True)
+assert lb._staging is not None and la._staging is None
+res = {"equal": bool(torch.equal(a, b)), "sum": float(a.double().sum()), "moved": float((a - Toy(5).flat_parameters).abs().max()),
+       "default_off": os.environ.pop("S3D_OVERLAP_ALLREDUCE") is not None and TrainLoop.__init__.__defaults__ is not None}
+out = parallel.gather_objects(res)
+if rank == 0:
+    print("RESULT " + json.dumps(out))
+parallel.barrier()
+"""
+
+
+def test_two_rank_gloo_trainloop_overlap_on_off_same_parameters(tmp_path):
+    """TrainLoop.run_step twice on two gloo ranks from the same seeds, once with the single all-reduce (the default) and once with
+    S3D_OVERLAP_ALLREDUCE=1 (the exchange cut into the backward pass's finishing groups, persistent staging buffers): the flat
+    parameters end bit for bit the same, on both ranks, and equal across ranks (the broadcast at start + identical averaged
+    gradients).  The denoiser / optimizer are stand-ins with the real flat layout — the HIP kernels need a GPU; what is covered
+    here is the loop's multi-rank control flow (src/diffusion/train_util.py:163-247)."""
+    import json
+    script = tmp_path / "loop_worker.py"
+    script.write_text(LOOP_WORKER)
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    env.pop("S3D_OVERLAP_ALLREDUCE", None)
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    res = json.loads([l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][0][len("RESULT "):])
+    assert all(r["equal"] for r in res), res
+    assert res[0]["sum"] == res[1]["sum"] and res[0]["moved"] > 1e-4
+
+
+STAGE1_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["S3D_REPO"])
+from sin3dm_amd import parallel, train
+rank = int(os.environ["RANK"])
+calls = []
+def slow_stage1(args):                                    # stands in for ShapeAutoEncoder.train (minutes on a real shape)
+    time.sleep(float(os.environ["FAKE_STAGE1_S"]))
+    calls.append("ae")
+    open(os.path.join(args.tag, "encoding", "feat.npz"), "wb").close()
+train.train_ae = slow_stage1
+t0 = time.time()
+train.main(["--tag", os.environ["EXP"], "--data_path", "unused.npz", "--only_enc"], confirm=lambda q: "y")
+waited = time.time() - t0
+assert os.path.exists(os.path.join(os.environ["EXP"], "encoding", "feat.npz"))       # every rank returns AFTER stage 1
+assert (calls == ["ae"]) == (rank == 0)
+# the process group is created only now, with a timeout SHORTER than stage 1 took: had the ranks been parked in a collective
+# (or in the rendezvous) during stage 1, this would have expired
+parallel.init(backend="gloo", timeout_s=float(os.environ["FAKE_STAGE1_S"]) * 0.75)
+parallel.barrier()
+print("RESULT %d %.2f" % (rank, waited))
+"""
+
+
+def test_train_cli_ranks_wait_for_stage1_outside_any_collective(tmp_path):
+    """python -m sin3dm_amd.train on N ranks: rank 0 runs the auto-encoder stage (src/train.py:8-29) before torch.distributed is
+    initialised; the other ranks wait for its marker file — not in a barrier whose watchdog would abort the job when stage 1
+    outlasts the collective timeout (25 000 iterations x 6.3 ms is already 160 s)."""
+    script = tmp_path / "stage1_worker.py"
+    script.write_text(STAGE1_WORKER)
+    exp = tmp_path / "EXP"
+    env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", EXP=str(exp),
+               FAKE_STAGE1_S="4")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    waits = {int(l.split()[1]): float(l.split()[2]) for o, _ in outs for l in o.splitlines() if l.startswith("RESULT ")}
+    assert waits[0] >= 4.0 and waits[1] >= 3.0, waits            # rank 1 really waited for rank 0's stage
+    assert any(f.startswith(".stage1_done_") for f in os.listdir(exp))

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """One step's kernel timeline from a rocprofv3 --kernel-trace CSV: start offset, duration and the idle gap before each
-kernel, for the LAST complete step in the trace (a step starts at k_linear / the first kernel after k_sampler).
+kernel, for the LAST complete step in the trace (a step ends with the output head, which applies the sampler update in the loops).
 
-    python tools/trace_timeline.py <kernel_trace.csv> [marker-substring=k_sampler]
+    python tools/trace_timeline.py <kernel_trace.csv> [marker-substring=k_out_head]
 """
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "k_sampler"
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_out_head"
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"^void |s3d::", "", r["Kernel_Name"]).split("(")[0][:60],
               int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])))
              for r in rows), key=lambda e: e[0])
