@@ -18,7 +18,8 @@ Prints ONE JSON line on rank 0.  Multi-GPU = independent samples per rank (no da
 non-zero if any worker fails.
 
 Before the W warm-up steps the script always runs PREWARM untimed steps of its own: a fresh box needs more than a
-handful of steps to reach steady clocks and warm caches (round 1: 1.145 ms/step after 5 warm-up steps, 1.08 after 100).
+handful of steps to reach steady clocks and warm caches (round 1: 1.145 ms/step after 5 warm-up steps, 1.08 after 100; the
+part is power-limited under this workload, so the clock it settles at is part of the result — `roofline.clock`).
 """
 import argparse
 import json
@@ -32,7 +33,7 @@ sys.path.insert(0, REPO)
 MC = 128
 HWD = (128, 128, 128)
 T_STEPS = 1000
-PREWARM = 60
+PREWARM = 150
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak (at the 2400 MHz data-sheet clock)
 PEAK_CLOCK_MHZ = 2400.0
 TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
@@ -178,63 +179,89 @@ def csrc_sha256():
     return h.hexdigest()
 
 
+_SAMPLER_CODE = r"""
+import sys, time
+try:
+    import amdsmi
+    amdsmi.amdsmi_init()
+    hs = amdsmi.amdsmi_get_processor_handles()
+    want = sys.argv[1].lower()
+    h = None
+    for x in hs:
+        try:
+            if want and want in str(amdsmi.amdsmi_get_gpu_device_bdf(x)).lower():
+                h = x
+        except Exception:
+            pass
+    if h is None and len(hs) == 1:
+        h = hs[0]
+    if h is None:
+        raise SystemExit(0)
+    print("READY", flush=True)
+    while True:
+        m = amdsmi.amdsmi_get_gpu_metrics_info(h)
+        clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
+        if not clk and isinstance(m.get("current_gfxclk"), (int, float)):
+            clk = [m["current_gfxclk"]]
+        pw = m.get("current_socket_power")
+        if not isinstance(pw, (int, float)) or pw >= 60000:
+            pw = m.get("average_socket_power")
+        if clk:
+            print("%.4f %.1f %s" % (time.time(), sum(clk) / len(clk), pw if isinstance(pw, (int, float)) and pw < 60000 else "nan"), flush=True)
+        time.sleep(0.01)
+except Exception:
+    pass
+"""
+
+
 class ClockSampler:
-    """gfx clock / socket power of this rank's GPU through amdsmi's gpu_metrics, sampled by a thread while the benchmark's own
-    untimed steps run (the same load as the timed region; never during it — a 1-ms driver call inside an 18-ms timed region is
-    noise nobody needs).  Everything is optional: no amdsmi / no permission -> no figures, never a failure."""
+    """gfx clock / socket power of this rank's GPU (amdsmi gpu_metrics, every 10 ms) during the benchmark's own untimed pre-warm
+    steps — the same load as the timed region, never during it.  The sampling runs in a CHILD process that touches no GPU (a
+    thread in this process would contend for the interpreter lock with the launch loop: it starved the GPU and cost 7 % in a
+    first version); this process only notes the time window and reads the child's lines afterwards.  Everything is optional: no
+    amdsmi / no permission -> no figures, never a failure."""
 
     def __init__(self, bdf):
-        self.samples, self._stop, self._thread, self._h = [], False, None, None
+        import subprocess
+        self._p = None
         try:
-            import amdsmi
-            self._smi = amdsmi
-            amdsmi.amdsmi_init()
-            handles = amdsmi.amdsmi_get_processor_handles()
-            want = (bdf or "").lower()
-            for h in handles:
-                try:
-                    if want and want in str(amdsmi.amdsmi_get_gpu_device_bdf(h)).lower():
-                        self._h = h
-                except Exception:
-                    pass
-            if self._h is None and len(handles) == 1:
-                self._h = handles[0]
+            self._p = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, bdf or ""], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
         except Exception:
-            self._h = None
+            self._p = None
+        self._t0 = self._t1 = None
 
-    def _run(self):
-        while not self._stop:
-            try:
-                m = self._smi.amdsmi_get_gpu_metrics_info(self._h)
-                clk = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 60000]
-                if not clk and isinstance(m.get("current_gfxclk"), (int, float)):
-                    clk = [m["current_gfxclk"]]
-                pw = m.get("current_socket_power")
-                if not isinstance(pw, (int, float)) or pw >= 60000:
-                    pw = m.get("average_socket_power")
-                if clk:
-                    self.samples.append((sum(clk) / len(clk), pw if isinstance(pw, (int, float)) and pw < 60000 else None))
-            except Exception:
-                return
-            time.sleep(0.02)
+    def begin(self):
+        self._t0 = time.time()
 
-    def start(self):
-        if self._h is not None:
-            import threading
-            self._thread = threading.Thread(target=self._run, daemon=True)
-            self._thread.start()
+    def end(self):
+        self._t1 = time.time()
 
-    def stop(self):
-        self._stop = True
-        if self._thread is not None:
-            self._thread.join(timeout=2.0)
-        s = self.samples[len(self.samples) // 3:]                 # the clocks settle during the first steps
+    def result(self):
+        if self._p is None:
+            return None
+        try:
+            self._p.terminate()
+            out, _ = self._p.communicate(timeout=5)
+        except Exception:
+            return None
+        rows = []
+        for l in out.splitlines():
+            f = l.split()
+            if len(f) == 3:
+                try:
+                    rows.append((float(f[0]), float(f[1]), float(f[2])))
+                except ValueError:
+                    pass
+        if self._t0 is None or self._t1 is None:
+            return None
+        lo = self._t0 + 0.4 * (self._t1 - self._t0)                    # the clocks settle during the first steps
+        s = [(c, p) for t, c, p in rows if lo <= t <= self._t1]
         if not s:
             return None
-        pw = [p for _, p in s if p is not None]
+        pw = [p for _, p in s if p == p]
         return {"gfxclk_mhz_mean": round(sum(c for c, _ in s) / len(s), 0), "gfxclk_mhz_min": round(min(c for c, _ in s), 0),
                 "socket_power_w_mean": round(sum(pw) / len(pw), 0) if pw else None, "samples": len(s),
-                "how": "amdsmi gpu_metrics (mean over the XCDs) every 20 ms during the untimed pre-warm steps of this run"}
+                "how": "amdsmi gpu_metrics (mean over the XCDs) every 10 ms, read by a child process during the untimed pre-warm steps of this run"}
 
 
 def measure_traffic_in_run(config):
@@ -323,6 +350,8 @@ def worker(args):
         torch.cuda.set_device(local)
         dev = torch.device(f"cuda:{local}")
         ident = device_identity(local)
+        if rank == 0:
+            clock = ClockSampler(ident.get("pci_bus_id"))            # (a child process; it is sampling by the time the model is built)
         if world > 1:
             dist.init_process_group("nccl", device_id=dev)
         model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
@@ -349,13 +378,13 @@ def worker(args):
             dist.barrier()
 
     with torch.no_grad():
-        if not args.dry_run and rank == 0:
-            clock = ClockSampler(ident.get("pci_bus_id"))
-            clock.start()
+        if clock is not None:
+            clock.begin()
         for _ in range(args.prewarm + args.warmup):
             step()
         sync()
-        clock = clock.stop() if clock is not None else None
+        if clock is not None:
+            clock.end()
         if not args.dry_run:
             model.profile(args.profile_every)
         barrier()
@@ -386,6 +415,7 @@ def worker(args):
         dist.destroy_process_group()
     if rank != 0:
         return 0
+    clock = clock.result() if clock is not None else None
     # N ranks must be N physical devices: keyed on what identifies the hardware (the device INDEX is LOCAL_RANK by construction
     # and proves nothing); a build that reports neither bus id nor uuid cannot be verified and says so in the line
     keys = [(r["pci_bus_id"], r["uuid"]) for r in ranks]

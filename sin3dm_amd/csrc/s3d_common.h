@@ -281,7 +281,8 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
                     const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st,
                     const s3d_sampler_args* fuse = nullptr, const GnPartials* part = nullptr);
-bool out_head_fuses_sampler(int C, int Cout);
+bool out_head_fuses_sampler(int C, int Cout, int B);     // the update happens inside the head's launch (else: head, then k_sampler)
+bool out_head_px_takes(int C, int Cout);                 // the pixel-chunk head serves this width (it can add GroupNorm partials itself)
 // part (with stats.mr == null): the head adds its input's GroupNorm partials itself — no k_gn_finalize launch before it
 bool out_head_adds_parts(const GnPartials& part, int C, int Cout);
 

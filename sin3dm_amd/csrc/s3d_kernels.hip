@@ -1270,7 +1270,12 @@ static bool out_head_px_form(int C, int Cout) {
     static const bool px_form = !(getenv("S3D_OUT_HEAD") && strcmp(getenv("S3D_OUT_HEAD"), "0") == 0);
     return px_form && (C == 64 || C == 128 || C == 256) && Cout <= 16;
 }
-bool out_head_fuses_sampler(int C, int Cout) { return out_head_px_form(C, Cout); }
+// The in-head sampler update pays at batch 1, where the step is a chain of launch-bound kernels (head + sampler kernel + their
+// launch gap 23 -> 20 us at 128^3); from batch 2 on the launches are bandwidth-bound and the head's 256-byte row segments
+// (64 pixels of one channel) move the four extra tensors at half the rate of k_sampler's linear sweep (batch 8: 172 us fused
+// against 82 + 35) — there the head writes the model output to the workspace and the stand-alone kernel follows.
+bool out_head_fuses_sampler(int C, int Cout, int B) { return out_head_px_form(C, Cout) && B == 1; }
+bool out_head_px_takes(int C, int Cout) { return out_head_px_form(C, Cout); }
 // fuse != null: the sampler update of one denoising step is applied to the model output (fuse->model_out is ignored).  When
 // the pixel-chunk form takes the launch it happens in the same kernel and `out` may be null (the model output is then never
 // stored); otherwise `out` is required and the stand-alone k_sampler follows.
@@ -1295,14 +1300,16 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
     S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "out head: C=%d unsupported", x.C);
     if (!maxpix || !B) return 0;
     if (fuse) S3D_CHECK(fuse->batch == B && fuse->per_sample == (long long)Cout * (H + D) * (W + D), S3D_ERR_INVALID, "out head: the sampler step does not match the model output's shape");
+    const bool fuse_here = fuse && out_head_fuses_sampler(x.C, Cout, B);
+    if (fuse && !fuse_here) S3D_CHECK(out, S3D_ERR_INVALID, "out head: this step needs a model-output buffer");
     if (out_head_px_form(x.C, Cout)) {
         int segs[3];
         for (int p = 0; p < 3; ++p) { const int len = p == 2 ? a.h[p] : a.wd[p], lines = p == 2 ? a.wd[p] : a.h[p]; segs[p] = lines * cdiv(len, kOhPx); }
-        const int corner = D * D ? std::min(fuse ? 256 : 64, cdiv(Cout * D * D, 256 * 4)) : 0;
+        const int corner = D * D ? std::min(fuse_here ? 256 : 64, cdiv(Cout * D * D, 256 * 4)) : 0;
         const dim3 grid(segs[0] + segs[1] + segs[2] + corner, B);
         s3d_sampler_args sa;
         memset(&sa, 0, sizeof sa);
-        if (fuse) {
+        if (fuse_here) {
             sa = *fuse;
             if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
             else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
@@ -1313,6 +1320,7 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
             else hipLaunchKernelGGL((k_out_head_px<64, false>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
         }
         S3D_HIP(hipGetLastError());
+        if (fuse && !fuse_here) { s3d_sampler_args sb = *fuse; sb.model_out = out; return launch_sampler(sb, st); }
         return 0;
     }
     S3D_CHECK(out, S3D_ERR_INVALID, "out head: this width needs a model-output buffer");

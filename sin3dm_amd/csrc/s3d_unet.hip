@@ -293,7 +293,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
                     gn_subgroup(Cc) == gn_subgroup(sk.C) && sk.part.nsub == sk.C / gn_subgroup(Cc) && h.C % gn_subgroup(Cc) == 0) {
                     Tri o;
                     // the last block feeds the output head, which adds the partial sums itself when it can (else: k_gn_finalize)
-                    S3D_TRY(f.resblock_cat(rb, h, sk, o, oi == c.n_levels - 1 ? (out_head_fuses_sampler(rb.Cout, c.out_channels) ? 2 : 1) : 0));
+                    S3D_TRY(f.resblock_cat(rb, h, sk, o, oi == c.n_levels - 1 ? (out_head_px_takes(rb.Cout, c.out_channels) ? 2 : 1) : 0));
                     h = o;
                     continue;
                 }
@@ -326,7 +326,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         Tri o;
         // ... and so does the last one (out head) — which adds the partials itself when it can (inference): partials only
         const bool last = oi == c.n_levels - 1;
-        const int head_parts = last && !tape && out_head_fuses_sampler(m->out_blocks[oi].Cout, c.out_channels) ? 2 : -1;
+        const int head_parts = last && !tape && out_head_px_takes(m->out_blocks[oi].Cout, c.out_channels) ? 2 : -1;
         S3D_TRY(f.resblock(m->out_blocks[oi], inp, o, last, head_parts));
         if (tape) { f.last_rb.index = oi; f.last_rb.is_out = true; tape->out_rb.push_back(f.last_rb); tape->cat_in.push_back(inp); }
         h = o;
@@ -338,7 +338,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
     if (!head_adds) S3D_TRY(f.stats_of(h, stats));
     if (tape) { tape->head_in = h; tape->head_stats = stats; tape->arena_off = ar.off; tape->valid = !meas; }
     // a fused step on a width the pixel-chunk head does not take: the model output goes through a workspace buffer
-    if (fuse && !out && !out_head_fuses_sampler(h.C, c.out_channels)) out = ar.alloc<float>(size_t(B) * c.out_channels * (H + D) * (W + D));
+    if (fuse && !out && !out_head_fuses_sampler(h.C, c.out_channels, B)) out = ar.alloc<float>(size_t(B) * c.out_channels * (H + D) * (W + D));
     if (!meas) {
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }

@@ -332,24 +332,27 @@ def test_trajectories_branches_golden(tag, px, resp, ddim, clip):
     final = fn(model, tuple(xT.shape), noise=xT.clone(), clip_denoised=clip, model_kwargs=dict(H=H, W=W, D=D)).cpu().numpy()
     assert relerr(final, g[f"{tag}.final"]) < 2e-4
     # the D x D corner: the model's output is zero there.  As an x0 prediction that ends the corner at exactly 0; as an eps
-    # prediction x0 = x_t / sqrt(alphas_cumprod) there, clamped — the reference's corner is +-1, and so is ours
+    # prediction x0 = x_t / sqrt(alphas_cumprod) there (clamped): the reference's corner is NOT zero, and ours equals it
     corner, ref_corner = final[..., H:, W:], g[f"{tag}.final"][..., H:, W:]
-    assert np.all(corner == 0) if px else (np.all(np.abs(ref_corner) == 1) and np.array_equal(corner, ref_corner))
+    if px:
+        assert np.all(corner == 0)
+    else:
+        assert np.abs(ref_corner).max() > 0.5 and relerr(corner, ref_corner) < 2e-4
 
 
-@pytest.mark.parametrize("mc", [32, 64])
-def test_fused_denoise_step_equals_forward_plus_sampler_kernel(mc):
-    """The sampling loops' step (s3d_unet_step_film: the output head applies the sampler update, SURVEY section 2b K8 + K9) against
-    the single-step API (forward, then s3d_sampler_step), bit for bit: DDPM, DDIM with eta, the in-painting branch, EPSILON and
-    unclipped, t = 0 included; mc = 64 takes the pixel-chunk head (one launch), mc = 32 the generic head followed by the sampler
-    kernel.  And the loops draw their eps ahead from the device generator without changing the single-step API's stream use."""
+@pytest.mark.parametrize("mc,B", [(32, 2), (64, 1), (64, 2)])
+def test_fused_denoise_step_equals_forward_plus_sampler_kernel(mc, B):
+    """The sampling loops' step (s3d_unet_step_film: ONE library call; SURVEY section 2b K8 + K9) against the single-step API
+    (forward, then s3d_sampler_step), bit for bit: DDPM, DDIM with eta, the in-painting branch, EPSILON and unclipped, t = 0
+    included.  mc = 64, batch 1: the pixel-chunk output head applies the update in its own launch and the model output is never
+    stored; batch 2: the same head writes to the workspace and the sampler kernel follows (bandwidth-bound regime); mc = 32: the
+    generic head.  And the loops draw their eps ahead from the device generator."""
     from sin3dm_amd import _lib
     from sin3dm_amd.diffusion.gaussian_diffusion import HostTimesteps
     from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
     H, W, D = 12, 9, 7
     kw = dict(H=H, W=W, D=D)
     model = make_model(mc)
-    B = 2
     shape = (B, 12, H + D, W + D)
     x, eps = cu(T.synthetic_noise(shape, 91)), cu(T.synthetic_noise(shape, 92))
     y0 = cu(T.synthetic_noise(shape, 93))
@@ -365,7 +368,7 @@ def test_fused_denoise_step_equals_forward_plus_sampler_kernel(mc):
                     with torch.no_grad():
                         a = diff._step(mode, model, x, ht, clip, None, kw, fuse=False, noise=eps, **extra)
                         b = diff._step(mode, model, x, ht, clip, None, kw, fuse=True, noise=eps, **extra)
-                    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (mc, px, ti, mode, extra.keys(), clip)
+                    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (mc, B, px, ti, mode, extra.keys(), clip)
     # device-generator loops: reproducible under a seed, finite, corner at zero
     diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True, timestep_respacing="10")
     outs = []

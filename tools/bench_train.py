@@ -42,11 +42,17 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--cpu-baseline", action="store_true")
-ap.add_argument("--gpus", type=int, default=1)
-ap.add_argument("--overlap", type=int, default=-1, help="gradient all-reduce chunks overlapped with backward (-1: TrainLoop default)")
+ap.add_argument("--gpus", type=int, default=None, help="ranks (default: WORLD_SIZE under torchrun, else 1)")
+ap.add_argument("--overlap", type=int, default=-1, choices=(-1, 0, 1),
+                help="1 / 0: gradient all-reduce cut into groups overlapped with the backward pass / one all-reduce after it "
+                     "(sets S3D_OVERLAP_ALLREDUCE for TrainLoop); -1: whatever the environment says (TrainLoop's default is off)")
 args = ap.parse_args()
 
 rank, local, world = parallel.env_rank_world()
+if args.gpus is None:
+    args.gpus = world                    # `torchrun ... tools/bench_train.py` without --gpus: the launcher's world size
+if args.overlap >= 0:
+    os.environ["S3D_OVERLAP_ALLREDUCE"] = str(args.overlap)
 if world != args.gpus:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 if local >= torch.cuda.device_count():
@@ -85,6 +91,7 @@ if rank == 0:
     fwd = f_dense_per_step(args.mc, H, W, D) * args.batch
     line = {"what": "diffusion training step", "config": f"{args.mc}-ch UNet, (H,W,D)=({H},{W},{D}), batch {args.batch}/GPU, {world} GPU(s)",
             "ms_per_step": round(dt * 1e3, 3), "samples_per_s": round(args.batch * world / dt, 2),
+            "overlap_allreduce": bool(loop.overlap_allreduce) if world > 1 else None,
             "effective_dense_tflops_per_gpu": round(3 * fwd / dt / 1e12, 1),
             "note": "effective = 3 x F_dense(forward) per step (fwd + dgrad + wgrad as the reference executes them)"}
     if args.cpu_baseline and world == 1:
