@@ -30,10 +30,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;          // channels per K chunk
 constexpr int LDP = KC + 4;     // padded LDS row (floats)
 
-template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1, int PF_ = 0>
+template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1, int PF_ = 0, bool TR_ = false>
 struct ConvCfg {
     static constexpr int KS = KS_;       // independent partial accumulators over K (breaks the MFMA dependency chain)
     static constexpr int PF = PF_;       // 1x1 only: K chunks of global loads kept in flight (0: the one-stage-ahead pipeline)
+    // 1x1 only (round 4): the MFMA operands are swapped, D^T[cout][pixel] = W X^T — a lane's accumulator registers are then
+    // runs of FOUR CONSECUTIVE OUTPUT CHANNELS of one pixel ((r & 3) + 8 (r >> 2) + 4 (lane >> 5)): the epilogue (bias, residual,
+    // the bilinear samples of a half-resolution residual, the store) moves 16 bytes per access instead of 4, a quarter of the
+    // memory instructions of the launch's longest phase.  Same products, same k order per output: bit-identical to TR = false.
+    static constexpr bool TR = TR_;
     static constexpr int TH = TH_, TW = TW_, KH = KH_, KW = KW_, WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
     static constexpr int BM = TH * TW, BN = WN * NTW * 32;
     static constexpr int HH = TH + KH - 1, HW = TW + KW - 1;
@@ -176,7 +181,8 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                             for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                                 for (int nt = 0; nt < NTW; ++nt)
-                                    acc[(k8 * 4 + e) % KS][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt][e], b4[nt][e], acc[(k8 * 4 + e) % KS][mt][nt], 0, 0, 0);
+                                    acc[(k8 * 4 + e) % KS][mt][nt] = CFG::TR ? __builtin_amdgcn_mfma_f32_32x32x2f32(b4[nt][e], a4[mt][e], acc[(k8 * 4 + e) % KS][mt][nt], 0, 0, 0)
+                                                                             : __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mt][e], b4[nt][e], acc[(k8 * 4 + e) % KS][mt][nt], 0, 0, 0);
                     }
                     // chunk + 1 (slot d) -> the other LDS buffer (its last readers passed the previous barrier), slot refilled
                     if (chunk + 1 < nchunks) {
@@ -250,6 +256,76 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
         }
     }
 
+    if constexpr (CFG::TR) {
+        // ---- transposed epilogue: lane = pixel (lane & 31) of an MFMA tile, registers 4q .. 4q+3 = output channels
+        // 8q + 4 (lane >> 5) + {0..3} of the tile's 32: one 16-byte access per (pixel, q).  No rank-1 terms / GroupNorm partials
+        // here (the launcher only sends plain 1x1 convolutions this way).
+        static_assert(TAPS == 1 && CFG::PF > 0, "transposed accumulators: 1x1 only");
+        const float* __restrict__ p_bias = J.bias;
+        const float* __restrict__ p_bbias = J.bbias;
+        const float* __restrict__ p_res = J.res;
+        float* __restrict__ p_out = J.out;
+        const size_t img = size_t(b) * h;
+        const int hi = h >> 1, wi = w >> 1;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int p = (wm * MTW + mt) * 32 + (lane & 31);
+            const int y = ty0 + p / TW, x = tx0 + p % TW;
+            const bool pix_ok = y < h && x < w;
+            const int yc = min(y, h - 1), xc = min(x, w - 1);
+            const size_t obase = ((img + yc) * w + xc) * cout;
+            // bilinear source of a half-resolution residual (F.interpolate arithmetic, as the plain epilogue below)
+            float fy = 0.5f * (float(yc) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+            float fx = 0.5f * (float(xc) + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            int y0 = int(fy); y0 = y0 > hi - 1 ? hi - 1 : y0;
+            int x0 = int(fx); x0 = x0 > wi - 1 ? wi - 1 : x0;
+            y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+            const int y1 = y0 + (y0 < hi - 1 ? 1 : 0), x1 = x0 + (x0 < wi - 1 ? 1 : 0);
+            const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
+            const float* rb = p_res && J.res_up ? p_res + size_t(b) * hi * wi * cout : nullptr;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int cobase = n0 + (wn * NTW + nt) * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int qh = 0; qh < 2; ++qh) {                // two channel quads at a time: 10 loads in flight, 40 registers (all four: 186 VGPRs, two waves per SIMD)
+                f32x4 addv[2], r00[2], r01[2], r10[2], r11[2];
+                bool ok[2];
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {                // every load of the pair first ...
+                    const int co4 = cobase + 8 * (2 * qh + qq);
+                    ok[qq] = pix_ok && co4 < cout;
+                    const int coc = co4 < cout ? co4 : 0;
+                    addv[qq] = p_bias ? *reinterpret_cast<const f32x4*>(p_bias + coc) : zero4;
+                    if (p_bbias) addv[qq] += *reinterpret_cast<const f32x4*>(p_bbias + size_t(b) * J.bbias_stride + coc);
+                    if (p_res && !J.res_up) addv[qq] += *reinterpret_cast<const f32x4*>(p_res + obase + coc);
+                    if (rb) {
+                        r00[qq] = *reinterpret_cast<const f32x4*>(rb + (size_t(y0) * wi + x0) * cout + coc);
+                        r01[qq] = *reinterpret_cast<const f32x4*>(rb + (size_t(y0) * wi + x1) * cout + coc);
+                        r10[qq] = *reinterpret_cast<const f32x4*>(rb + (size_t(y1) * wi + x0) * cout + coc);
+                        r11[qq] = *reinterpret_cast<const f32x4*>(rb + (size_t(y1) * wi + x1) * cout + coc);
+                    }
+                }
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {                // ... then the arithmetic and the stores
+                    const int q = 2 * qh + qq;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = acc[0][mt][nt][4 * q + e];
+#pragma unroll
+                        for (int ks = 1; ks < KS; ++ks) t += acc[ks][mt][nt][4 * q + e];
+                        float ad = addv[qq][e];
+                        if (rb) ad += ly0 * (lx0 * r00[qq][e] + lx1 * r01[qq][e]) + ly1 * (lx0 * r10[qq][e] + lx1 * r11[qq][e]);
+                        t += ad;
+                        v[e] = args.relu ? fmaxf(t, 0.f) : t;
+                    }
+                    if (ok[qq]) *reinterpret_cast<f32x4*>(p_out + obase + cobase + 8 * q) = v;
+                }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Structured for memory-level parallelism: per 32-channel column block, first issue every rank-1 / residual
     // load of the lane's 16 pixels (predicated, clamped addresses, no per-element branches), then add and store.
@@ -491,6 +567,10 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         blocks += J.tiles_per_img * J.n_tiles_n * ((a.B + ns - 1) / ns) * (roll3 && a.r1_slices > 1 ? a.r1_slices : 1);
     }
     if (!blocks) return 0;
+    // (round 4, measured and removed: a wide form — 32 positions x 32 output channels x the three taps per block, three
+    // accumulator tiles per wave, weight operands straight from L2 into registers; bit-identical tables — 0.117 -> 0.153 ms/step
+    // at batch 1, 0.490 -> 0.500 at batch 8, 0.155 -> 0.196 on the (256,256,128) planes: a lane's 16-byte reads of 32 different
+    // weight rows use a quarter of every cache line they touch, profiles/r04_rank1_wide.txt)
     // (measured in round 2 and dropped: whole-chunk stages with two chunks of loads in flight, and eight waves per block —
     // 9.4 / 14.7 / 18.7 us at 128 / 256 / 384 channels either way: the launch is bound by the ~21 MB per 128-channel chunk that
     // 384 blocks pull through L2 at once, not by its stage latency or its MFMA chains)
@@ -563,7 +643,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
     }
     if (!blocks) return 0;
     a.xcd_swizzle = 1;                       // XCD-aware block order (was switchable in rounds 1-2: always a win)
-    conv_note_kernel(CFG::KH == 3 ? "k_conv_mfma<3x3> direct MFMA convolution" : (CFG::KH == 1 ? "k_conv_mfma<1x1> direct MFMA convolution" : "k_conv_mfma<5x5> direct MFMA convolution"));
+    conv_note_kernel(CFG::KH == 3 ? "k_conv_mfma<3x3> direct MFMA convolution" : (CFG::KH == 1 ? (CFG::TR ? "k_conv_mfma<1x1, transposed accumulators> direct MFMA convolution" : "k_conv_mfma<1x1> direct MFMA convolution") : "k_conv_mfma<5x5> direct MFMA convolution"));
     hipLaunchKernelGGL(k_conv_mfma<CFG>, dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
@@ -607,6 +687,20 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
                                //  64-channel K chunks (70 KB LDS, two blocks per CU) 0.084, 16-channel chunks 0.077 vs 0.072 ms/step)
             // two K chunks of global loads in flight (round 3: one stage ahead 0.0713 ms/step, 2 chunks 0.0686, whole K 0.0711 — the
             // stages' memory latency is NOT what these launches wait for, profiles/r03_conv1x1.txt)
+            {
+                // transposed accumulators (16-byte epilogue accesses) for plain 1x1 convolutions — no rank-1 terms, no GroupNorm
+                // partials, channel quads — of at least four rounds of blocks: batch 8 0.383 -> 0.357 ms/step, the auto-encoder
+                // iteration 6.31 -> 6.26 ms; the one-round launches of the batch-1 step are a latency chain either way
+                // (0.0693 -> 0.0714 ms/step) and keep the 4-byte epilogue.  S3D_CONV1X1_T=0 never / =1 always (tests).
+                static const int tr_mode = getenv("S3D_CONV1X1_T") ? atoi(getenv("S3D_CONV1X1_T")) : -1;
+                bool plain = tr_mode != 0 && a.cout % 4 == 0;
+                long long blocks = 0;
+                for (int j = 0; j < a.njobs; ++j) {
+                    plain = plain && !a.job[j].rrow && !a.job[j].rcol && !a.job[j].gn_part;
+                    blocks += (long long)((a.job[j].w + 7) / 8) * ((a.job[j].h + 7) / 8) * ((a.cout + 63) / 64) * a.B;
+                }
+                if (plain && (tr_mode == 1 || blocks >= 4 * 768)) return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2, true>>(a, st);
+            }
             return launch_cfg<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2>>(a, st);
         case CONV_1x3_VEC:
             return launch_rank1(a, st, false);

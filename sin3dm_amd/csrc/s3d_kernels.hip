@@ -1138,7 +1138,7 @@ constexpr int kOhPx = 64;
 // output of exactly 0 (compose_featmaps' zero fill, src/utils/triplane_util.py:7-18).  Same arithmetic in the same order as
 // k_out_head_px<CQ, false> followed by k_sampler: bit-identical results.
 template <int CQ, bool FUSED>                              // channel quads per pixel: 16, 32 or 64
-__global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2, s3d_sampler_args sa) {
+__global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2, s3d_sampler_args sa) {
     constexpr int C = 4 * CQ, CPW = C / 4, LANES = 256 / CQ, LD = C + 4;
     __shared__ __attribute__((aligned(16))) float sx[kOhPx * LD];
     __shared__ float sp[4][16][kOhPx];
@@ -1146,36 +1146,25 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
     const int b = blockIdx.y, tid = threadIdx.x;
     const int Hc = a.H + a.D, Wc = a.W + a.D;
     int blk = blockIdx.x, p = 0;
-    if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; if (blk >= segs2) { blk -= segs2; p = 3; } } }
-    if (p == 3) {                                           // the D x D corner of compose_featmaps: zeros
-        const long long n = (long long)a.Cout * a.D * a.D;
-        // FUSED: the corner takes the sampler update too (a quarter of the composed map at D = H = W): four independent
-        // elements per thread with their loads issued together — a one-element grid-stride loop is a chain of dependent
-        // load -> store round trips, 12 deep on 64 blocks: it made this launch 31 us instead of 15 + 7
-        constexpr int U = 4;
-        SamplerCoef sc;
-        if (FUSED) sc = sampler_coef(sa, int(sa.t[b]));
-        const long long stride = 256LL * U * (gridDim.x - segs0 - segs1 - segs2);
-        for (long long base = (long long)blk * 256 * U + tid; base < n; base += stride) {
-            size_t o[U]; float xv[U], nv[U];
+    if (blk >= segs0) { blk -= segs0; p = 1; if (blk >= segs1) { blk -= segs1; p = 2; } }
+    // The D x D corner of compose_featmaps (zeros; FUSED: the sampler update with a model output of 0 — a quarter of the composed
+    // map at D = H = W) is spread over the pixel blocks: element i = block * 256 + thread (+ k * all threads).  Extra corner
+    // blocks behind the pixel blocks were a second, nearly empty round of the chip (768 + 192 blocks on 768 slots: 25 us);
+    // here x_t / eps of the thread's first two corner elements are requested with the block's other early loads.
+    const long long n_corner = (long long)a.Cout * a.D * a.D;
+    const long long corner_stride = 256LL * gridDim.x;
+    const long long corner_i0 = (long long)blockIdx.x * 256 + tid;
+    constexpr int CU_ = 2;
+    size_t corner_o[CU_]; float corner_x[CU_], corner_n[CU_];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const long long i = base + 256LL * u;
-                xv[u] = nv[u] = 0.f; o[u] = 0;
-                if (i < n) {
-                    const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
-                    o[u] = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
-                    if (FUSED) { xv[u] = sa.x[o[u]]; if (sa.noise) nv[u] = sa.noise[o[u]]; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (base + 256LL * u >= n) continue;
-                if (!FUSED || a.out) a.out[o[u]] = 0.f;
-                if (FUSED) sampler_element(sa, sc, (long long)o[u], 0.f, xv[u], nv[u]);
-            }
+    for (int u = 0; u < CU_; ++u) {
+        const long long i = corner_i0 + u * corner_stride;
+        corner_o[u] = 0; corner_x[u] = corner_n[u] = 0.f;
+        if (i < n_corner) {
+            const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
+            corner_o[u] = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
+            if (FUSED) { corner_x[u] = sa.x[corner_o[u]]; if (sa.noise) corner_n[u] = sa.noise[corner_o[u]]; }
         }
-        return;
     }
     const int h = a.h[p], w = a.wd[p];
     const int len = p == 2 ? h : w, nseg = (len + kOhPx - 1) / kOhPx;
@@ -1265,11 +1254,20 @@ __global__ __launch_bounds__(256) void k_out_head_px(OutHeadArgs a, int segs0, i
         if (!FUSED || a.out) a.out[o] = v;
         if (FUSED) sampler_element(sa, sc, (long long)o, v, pre_x[k], pre_n[k]);
     }
+#pragma unroll
+    for (int u = 0; u < CU_; ++u) {
+        if (corner_i0 + u * corner_stride >= n_corner) continue;
+        if (!FUSED || a.out) a.out[corner_o[u]] = 0.f;
+        if (FUSED) sampler_element(sa, sc, (long long)corner_o[u], 0.f, corner_x[u], corner_n[u]);
+    }
+    for (long long i = corner_i0 + CU_ * corner_stride; i < n_corner; i += corner_stride) {      // (shapes with D*D > 2 x the plane pixels)
+        const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
+        const size_t o = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
+        if (!FUSED || a.out) a.out[o] = 0.f;
+        if (FUSED) sampler_element(sa, sc, (long long)o, 0.f);
+    }
 }
-static bool out_head_px_form(int C, int Cout) {
-    static const bool px_form = !(getenv("S3D_OUT_HEAD") && strcmp(getenv("S3D_OUT_HEAD"), "0") == 0);
-    return px_form && (C == 64 || C == 128 || C == 256) && Cout <= 16;
-}
+static bool out_head_px_form(int C, int Cout) { return (C == 64 || C == 128 || C == 256) && Cout <= 16; }      // (other widths: k_out_head)
 // The in-head sampler update pays at batch 1, where the step is a chain of launch-bound kernels (head + sampler kernel + their
 // launch gap 23 -> 20 us at 128^3); from batch 2 on the launches are bandwidth-bound and the head's 256-byte row segments
 // (64 pixels of one channel) move the four extra tensors at half the rate of k_sampler's linear sweep (batch 8: 172 us fused
@@ -1305,8 +1303,7 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
     if (out_head_px_form(x.C, Cout)) {
         int segs[3];
         for (int p = 0; p < 3; ++p) { const int len = p == 2 ? a.h[p] : a.wd[p], lines = p == 2 ? a.wd[p] : a.h[p]; segs[p] = lines * cdiv(len, kOhPx); }
-        const int corner = D * D ? std::min(fuse_here ? 256 : 64, cdiv(Cout * D * D, 256 * 4)) : 0;
-        const dim3 grid(segs[0] + segs[1] + segs[2] + corner, B);
+        const dim3 grid(segs[0] + segs[1] + segs[2], B);
         s3d_sampler_args sa;
         memset(&sa, 0, sizeof sa);
         if (fuse_here) {

@@ -99,14 +99,15 @@ def test_unet_forward_golden(tag, mc, raw, ssn, cm):
     assert np.all(y[..., H:, W:] == 0)
 
 
-@pytest.mark.parametrize("variant", ["24w", "4", "2", "0", "novcat", "oldhead", "gnsplit", "naive"])
+@pytest.mark.parametrize("variant", ["24w", "4", "2", "0", "novcat", "gnsplit", "1x1t", "naive"])
 def test_unet_forward_golden_other_conv_kernels(variant):
     """Every 3x3 kernel on the golden planes (24w: S3D_WINO24W=1, the 64-output-channel block k_conv_wino24w of the mixed Winograd
     F(2x4,3x3) kernel forced onto every launch whose widths allow it — by default it only takes launches of several rounds of
     blocks; 4 / 2: F(2x2) with one / two frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors,
     leaf convolutions and ragged shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual
-    concat of Fwd::resblock_cat; oldhead: S3D_OUT_HEAD=0, the thread-per-quad output head; gnsplit: S3D_GN_FUSED=0, every
-    GroupNorm statistic through k_gn_finalize instead of being added inside k_gn_act; naive: S3D_CONV_IMPL=naive, the
+    concat of Fwd::resblock_cat; gnsplit: S3D_GN_FUSED=0, every GroupNorm statistic through k_gn_finalize instead of being added
+    inside k_gn_act / the output head; 1x1t: S3D_CONV1X1_T=1, the transposed-accumulator epilogue of the 1x1 convolutions (16-byte
+    accesses; by default only launches of four rounds of blocks take it) on every plain 1x1 launch; naive: S3D_CONV_IMPL=naive, the
     one-thread-per-output convolutions used for triangulation).  The choices are read once per process, hence the subprocess."""
     import os, subprocess, sys
     code = (
@@ -125,7 +126,7 @@ def test_unet_forward_golden_other_conv_kernels(variant):
         "    e = relerr(y, g[f'{tag}.y'])\n"
         "    assert e < 1e-4, (tag, e)\n"
         "print('ok')\n")
-    env = {"24w": dict(S3D_WINO24W="1"), "novcat": dict(S3D_VCAT="0"), "oldhead": dict(S3D_OUT_HEAD="0"), "gnsplit": dict(S3D_GN_FUSED="0"),
+    env = {"24w": dict(S3D_WINO24W="1"), "novcat": dict(S3D_VCAT="0"), "1x1t": dict(S3D_CONV1X1_T="1"), "gnsplit": dict(S3D_GN_FUSED="0"),
            "naive": dict(S3D_CONV_IMPL="naive")}.get(variant, dict(S3D_WINO=variant))
     env = dict(os.environ, **env)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
