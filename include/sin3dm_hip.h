@@ -94,7 +94,8 @@ S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film
  * recorded events, ADDS their durations to `out` (caller zero-initialises) and recycles them.
  * flops = algorithmic flops of the launches, 2*taps*cin*cout*pixels; mfma_flops = what the
  * matrix cores really multiply for them (Winograd F(2x2,3x3): 4/9 of the direct count, F(2x4,3x3): 1/3, F(4x4,3x3): 1/4).
- * s3d_unet_profile_kernel: name of the kernel the most recent timed launch of class cls actually dispatched ("" if none):
+ * s3d_unet_profile_kernel: names of the kernels the timed launches of class cls actually dispatched since profiling was switched
+ * on (" + "-joined when a class used more than one, e.g. both blockings of the mixed Winograd kernel; "" if none):
  * bench.py labels its roofline line with it instead of deriving a name from environment switches. */
 typedef struct {
     double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */

@@ -118,7 +118,13 @@ struct s3d_unet {
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int64_t prof_forwards = 0;
-    const char* prof_kernel[3] = {"", "", ""};
+    std::string prof_kernel[3];                          // every distinct kernel the timed launches of a class dispatched, " + "-joined
+    void note_prof_kernel(int cls) {
+        if (cls < 0 || cls >= 3) return;
+        const std::string n = conv_last_kernel();
+        if (n.empty() || prof_kernel[cls].find(n) != std::string::npos) return;
+        prof_kernel[cls] += (prof_kernel[cls].empty() ? "" : " + ") + n;
+    }
     hipEvent_t prof_event() {
         hipEvent_t e = nullptr;
         if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); }
@@ -135,7 +141,7 @@ struct s3d_unet {
         r.mfma_flops = r.flops * conv_exec_fraction(kind, ca);
         if (r.e0) (void)hipEventRecord(r.e0, st);
         int rc = launch_conv(kind, ca, st);
-        if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
+        note_prof_kernel(cls);
         if (r.e1) (void)hipEventRecord(r.e1, st);
         prof_recs.push_back(r);
         return rc;
@@ -146,7 +152,7 @@ struct s3d_unet {
         ProfRec r{cls, prof_event(), prof_event(), flops, mfma_flops};
         if (r.e0) (void)hipEventRecord(r.e0, st);
         int rc = fn();
-        if (cls >= 0 && cls < 3) prof_kernel[cls] = conv_last_kernel();
+        note_prof_kernel(cls);
         if (r.e1) (void)hipEventRecord(r.e1, st);
         prof_recs.push_back(r);
         return rc;

@@ -480,6 +480,7 @@ int s3d_unet_profile(s3d_unet* m, int every) {
     S3D_CHECK(m && every >= 0, S3D_ERR_INVALID, "unet_profile: bad argument");
     m->prof_every = every;
     m->fwd_count = 0;
+    if (every > 0) for (auto& k : m->prof_kernel) k.clear();          // a new measurement names its own kernels
     return 0;
 }
 
@@ -505,7 +506,7 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
 }
 
 const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls) {
-    return m && cls >= 0 && cls < 3 ? m->prof_kernel[cls] : "";
+    return m && cls >= 0 && cls < 3 ? m->prof_kernel[cls].c_str() : "";
 }
 
 }  // extern "C"

@@ -301,9 +301,9 @@ class GaussianDiffusion:
             with th.no_grad():
                 sample, pred, _ = self._step(mode, model, img, t, clip_denoised, denoised_fn, model_kwargs, fuse=True,
                                              noise=eps, **kw)
-                out = {"sample": sample, "pred_xstart": pred}
-                yield out
-                img = out["sample"]
+            out = {"sample": sample, "pred_xstart": pred}
+            yield out                 # (outside the no_grad block: a generator abandoned mid-loop must not unwind a context manager at interpreter exit)
+            img = out["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False):

@@ -23,5 +23,5 @@ cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p1
 timeout 600 rocprofv3 --kernel-trace -d /tmp/p1 -o t --output-format csv -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-every 0 > /tmp/p1.log 2>&1
 F=$(find /tmp/p1 -name "*kernel_trace.csv" | head -1)
 python3 $ROOT/tools/trace_timeline.py $F > $OUT/${TAG}_timeline.txt
-python3 $ROOT/tools/prof_summary.py $F 95 > $OUT/${TAG}_kernel_summary.txt
+python3 $ROOT/tools/prof_summary.py $F 185 > $OUT/${TAG}_kernel_summary.txt
 head -60 $OUT/${TAG}_timeline.txt

@@ -12,7 +12,7 @@ python bench.py --steps 300 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench.jso
 cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/p1
 rocprofv3 --kernel-trace -d /tmp/p1 -o t --output-format csv -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --profile-every 0 > /tmp/p1.log 2>&1
 python3 $ROOT/tools/trace_timeline.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) > $OUT/${TAG}_timeline.txt
-python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 95 > $OUT/${TAG}_kernel_summary.txt
+python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 185 > $OUT/${TAG}_kernel_summary.txt
 tail -4 $OUT/${TAG}_pytest.log
 python3 -c "
 import json,sys

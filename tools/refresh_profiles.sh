@@ -1,23 +1,23 @@
 #!/bin/bash
 # Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r04'
 # Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
-R=${1:-r03}
+R=${1:-r04}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline --profile-every 0"
+B="python3 $ROOT/bench.py --steps 60 --warmup 5 --no-cpu-baseline --profile-every 0 --traffic off"
 # 1. kernel trace + stats, one step's timeline
 rm -rf /tmp/p1 && rocprofv3 --kernel-trace --stats -d /tmp/p1 -o t --output-format csv -- $B > /tmp/p1.log 2>&1
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $OUT/${R}_kernel_stats.csv
-python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 125 > $OUT/${R}_kernel_summary.txt
+python3 $ROOT/tools/prof_summary.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) 215 > $OUT/${R}_kernel_summary.txt
 python3 $ROOT/tools/trace_timeline.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) > $OUT/${R}_timeline.txt
 # 2. HBM traffic: two PMC passes (counters only with --kernel-trace)
-P="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-every 0"
+P="python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-every 0 --traffic off --prewarm 4"
 rm -rf /tmp/p2 && rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o t --output-format csv -- $P > /tmp/p2.log 2>&1
 rm -rf /tmp/p3 && rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p3 -o t --output-format csv -- $P > /tmp/p3.log 2>&1
-python3 $ROOT/tools/pmc_traffic.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_traffic.json k_conv_wino24s
+python3 $ROOT/tools/pmc_traffic.py $(find /tmp/p2 -name "*counter_collection.csv" | head -1) $(find /tmp/p3 -name "*counter_collection.csv" | head -1) $OUT/${R}_pmc_traffic.json k_conv_wino24
 # 3. SQ counters
 rm -rf /tmp/p4 && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p4 -o t --output-format csv -- $P > /tmp/p4.log 2>&1
 { echo "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -- python3 bench.py --steps 6 --warmup 2";
@@ -36,15 +36,23 @@ for n, c in agg.items():
         print(f"  {n:60s} {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']:.3f}")
 PY
 cd $ROOT
-# 4. the headline line (uses profiles/<round>_pmc_traffic.json as committed; copy the new one in first for the traffic field)
+# 4. the headline line (bench.py measures roofline.traffic itself with two rocprofv3 --pmc children; the committed
+#    profiles/<round>_pmc_traffic.json is only its fallback)
 cp $OUT/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
 python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench_driver_flags.json
-# 5. other configurations, the graph-replay experiment, training, decode
-python3 tools/bench_configs.py 2>/dev/null | grep "^{" > $OUT/${R}_other_configs.txt
-python3 tools/graph_experiment.py 2>/dev/null | grep "^{" > $OUT/${R}_graph_experiment.txt
-{ python3 tools/bench_train.py 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
+# 5. the other BASELINE configs through bench.py (each line with its own roofline), the small ones through tools/bench_configs.py,
+#    training, decode
+{ for C in c3 c5; do python3 bench.py --config $C --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; done
+  python3 tools/bench_configs.py "C1 " 2>/dev/null | grep "^{"; python3 tools/bench_configs.py "64-ch" 2>/dev/null | grep "^{"; } > $OUT/${R}_other_configs.txt
+{ python3 tools/bench_train.py --steps 50 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
 { python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
-# 6. the 3x3 kernels alone
-[ -x tools/ub_wino24 ] && timeout 300 tools/ub_wino24 > $OUT/${R}_wino_ubench.txt
+# 6. the 3x3 kernels alone (steady state), with phase stamps and one / two / three blocks per CU; clock + power under them
+[ -x tools/ub_wino24 ] && timeout 400 tools/ub_wino24 2>&1 | grep -v "wino4 " > $OUT/${R}_wino_ubench.txt
+[ -x tools/ub_wino24_t ] && timeout 300 tools/ub_wino24_t 0 2 3 4 5 2>&1 | grep -v "wino4 " > $OUT/${R}_wino_ubench_phases.txt
+[ -x tools/ub_clock ] && timeout 300 tools/ub_clock > $OUT/${R}_clock.txt 2>&1
+# 7. config 3's kernel table
+cd /tmp && rm -rf /tmp/p6 && rocprofv3 --kernel-trace -d /tmp/p6 -o t --output-format csv -- python3 $ROOT/bench.py --config c3 --steps 30 --warmup 5 --no-cpu-baseline --profile-every 0 --traffic off > /tmp/p6.log 2>&1
+python3 $ROOT/tools/prof_summary.py $(find /tmp/p6 -name "*kernel_trace.csv" | head -1) 185 > $OUT/${R}_config3_kernel_summary.txt
+cd $ROOT
 ls -la $OUT
