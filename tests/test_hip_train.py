@@ -373,15 +373,20 @@ def test_adamw_ema_kernel_elementwise(wd):
 
 def test_backward_progress_marks_and_overlapped_exchange_groups():
     """s3d_unet_backward_marked: the same gradient bits as the unmarked call; its two events fire in order before the pass ends,
-    and at each of them the ranges grad_ready_groups() assigns to it already hold their final values (read on a second stream
-    behind the event — exactly what the data-parallel trainer's communication stream does with them)."""
+    and at each of them the ranges grad_ready_groups() assigns to it already hold their FINAL values — nothing writes them
+    afterwards.  A second stream waits for each mark, copies the group's ranges out and then POISONS them in place (what the
+    data-parallel trainer's communication stream does at that moment is an in-place all-reduce): the copies must equal the plain
+    gradients, the poison must still be there at the end (a kernel that touched a range after its mark would have overwritten
+    it), and the poisoning of the first group must have finished before the backward pass did (so the check really ran inside the pass)."""
     import torch
-    g = golden("train_grads")
-    tag, mc, B = "mc32_a", 32, 2
+    tag, mc, B = "big", 64, 2
     m = _model(mc)
     diffusion = _diffusion()
-    H, W, D, x0, noise = _inputs(g, tag, B)
-    t = torch.from_numpy(g[f"{tag}.t"]).cuda()
+    H, W, D = 96, 128, 96                                # a GPU-bound backward pass (the host has enqueued all of it long before the first mark fires)
+    dev = torch.device("cuda:0")
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1).to(dev)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 401)).to(dev)
+    t = torch.tensor([700, 3], device=dev)
     w = torch.tensor([1.0, 0.5], device="cuda")
     kw = dict(H=H, W=W, D=D)
     _, g_plain = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
@@ -389,18 +394,33 @@ def test_backward_progress_marks_and_overlapped_exchange_groups():
     groups = m.grad_ready_groups()
     marks = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
     end = torch.cuda.Event(enable_timing=True)
+    poisoned = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
     out = torch.full_like(g_plain, float("nan"))
     side = torch.cuda.Stream()
+    POISON = 12345.678
+    idx = [torch.cat([torch.arange(b, e, device=dev) for b, e in groups[k]]) for k in range(2)]   # one gather / one fill per group
+    snaps = [torch.empty(len(idx[k]), device=dev) for k in range(2)]
+    with torch.cuda.stream(side):                        # warm-up: the gather / fill kernels are loaded and their buffers exist before the
+        scratch = torch.zeros_like(out)                  # measured pass (a first-use code-object load or allocation would stall the side stream
+        for k in range(2):                               # for longer than the whole backward pass)
+            torch.index_select(scratch, 0, idx[k], out=snaps[k])
+            scratch.index_fill_(0, idx[k], POISON)
+    torch.cuda.synchronize()
     _, g_marked = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise, grad_out=out, grad_marks=marks)
     end.record()
-    snaps = []
-    for k in range(2):                                   # copy each early group out on the side stream as soon as its mark fires
+    for k in range(2):                                   # (the host is far ahead of the GPU: these run when the mark fires)
         side.wait_event(marks[k])
         with torch.cuda.stream(side):
-            snaps.append([out[b:e].clone() for b, e in groups[k]])
+            torch.index_select(out, 0, idx[k], out=snaps[k])
+            out.index_fill_(0, idx[k], POISON)
+            poisoned[k].record(side)
     torch.cuda.synchronize()
-    assert torch.equal(g_marked, g_plain)
+    assert g_marked.data_ptr() == out.data_ptr()
     assert marks[0].elapsed_time(marks[1]) > 0 and marks[1].elapsed_time(end) > 0
     for k in range(2):
-        for (b, e), s in zip(groups[k], snaps[k]):
-            assert torch.equal(s, g_plain[b:e]), (k, b, e)
+        if k == 0:                                       # (after mark 1 only the ~10 small timestep-linear launches remain: no such bound there)
+            assert poisoned[k].elapsed_time(end) > 0, f"group {k} was only copied and poisoned after the backward pass had ended"
+        assert torch.equal(snaps[k], g_plain.index_select(0, idx[k])), f"group {k} was not final at its mark"
+        assert bool((out.index_select(0, idx[k]) == POISON).all()), f"a kernel wrote a gradient range of group {k} after its mark"
+    for b, e in groups[2]:                               # the late group (timestep linears) is final at the end of the pass
+        assert torch.equal(out[b:e], g_plain[b:e])

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One-off full-size parity run: N consecutive DDPM steps of BASELINE config 2 (128-ch UNet, 128^3) on the HIP path and on
-the CPU port with identical noise, relative error (max|a-b| / max|b|) after every 10th step.
-    python tools/validate_full_size.py [--steps 100]"""
+the CPU port with identical noise, relative error (max|a-b| / max|b|) after every 10th step.  The HIP side is driven through the
+public loop, p_sample_loop_progressive — one library call per step since round 4 (the output head applies the sampler update);
+--single-step uses p_sample (forward + sampler kernel) instead.
+    python tools/validate_full_size.py [--steps 100] [--single-step]"""
 import argparse, os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "oracle"))
@@ -12,6 +14,7 @@ from sin3dm_amd import testing as T
 from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
 from sin3dm_amd.diffusion.unet_triplane import TriplaneUNetModelSmall
 ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=100); ap.add_argument("--stride", type=int, default=10)
+ap.add_argument("--single-step", action="store_true")
 a = ap.parse_args()
 torch.set_num_threads(usable_cores())
 mc, (H, W, D) = 128, (128, 128, 128)
@@ -24,12 +27,18 @@ x_cpu = torch.randn((1, 12, H + D, W + D), generator=g); x_gpu = x_cpu.cuda()
 # spread the steps over the whole schedule: every (1000 // steps)-th timestep would change the process; instead walk the
 # FIRST `steps` steps (t = 999 ...), where the state is noise-dominated, and the LAST ones would need the whole chain
 t0 = time.time()
+pending = []
+diffusion.noise_fn = lambda z: pending.pop(0).to(z.device)
+loop = None if a.single_step else diffusion.p_sample_loop_progressive(model, tuple(x_gpu.shape), noise=x_gpu, model_kwargs=dict(H=H, W=W, D=D))
 for k in range(a.steps):
     t = 999 - k
     eps = torch.randn(x_cpu.shape, generator=g)
-    diffusion.noise_fn = lambda z, e=eps: e.to(z.device)
+    pending.append(eps)
     with torch.no_grad():
-        x_gpu = diffusion.p_sample(model, x_gpu, torch.tensor([t], device="cuda"), model_kwargs=dict(H=H, W=W, D=D))["sample"]
+        if loop is None:
+            x_gpu = diffusion.p_sample(model, x_gpu, torch.tensor([t], device="cuda"), model_kwargs=dict(H=H, W=W, D=D))["sample"]
+        else:
+            x_gpu = next(loop)["sample"]
         out = tp.unet_forward(sd, x_cpu, torch.tensor([float(t)]), H, W, D, mc)
         x_cpu, _ = tp.p_sample_update(out, x_cpu, eps, tab, t)
     if (k + 1) % a.stride == 0 or k == a.steps - 1:
