@@ -117,6 +117,7 @@ struct ConvJob {
     const float* wgt;     // packed [taps][cout][cin]
     const float* wgt_wino;// 3x3 only: Winograd-transformed weights in MFMA fragment order (s3d_wino.hip) or null
     const float* wgt_wino24s;// 3x3 only: the mixed F(2x4,3x3) image of k_conv_wino24s / k_conv_wino24w (s3d_wino24.hip) or null (null: the F(2x2) kernels are used)
+    const float* wgt_r1f; // CONV_1x3_ROLL only: the rank-1 weights in MFMA fragment order (k_rank1b, pack_rank1_frag) or null (null: k_rank1 on `wgt`)
     const float* bias;    // [cout] or null
     const float* bbias;   // [B][bbias_stride] per-sample bias (h + emb path) or null
     const float* rrow;    // [B][h][4][cout] rank-1 rollout term indexed by pixel row, variant by column; or null
@@ -163,12 +164,23 @@ struct ConvW {
     size_t bias[3] = {0, 0, 0};
     size_t rrow[3] = {0, 0, 0};       // rank-1 weights for the row-varying mean vector  [3 taps][ceil(cout/8)*24][C], row (co/8)*24 + o*8 + co%8
     size_t rcol[3] = {0, 0, 0};       // rank-1 weights for the column-varying mean vector
+    size_t rrow_f[3] = {0, 0, 0};     // the same two in the fragment order of k_rank1b (0 = not packed: cin not a multiple of 128, or the training tier's image)
+    size_t rcol_f[3] = {0, 0, 0};
     size_t wino[3] = {0, 0, 0};       // 3x3: G g G^T in fragment order (0 = not packed)
     size_t wino24s[3] = {0, 0, 0};    // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24s / k_conv_wino24w
     int cin = 0, cout = 0, k = 0;
     bool rollout = false;
 };
 size_t push(std::vector<float>& stage, const float* src, size_t n);
+// Fragment-order image of the rank-1 weights (k_rank1b, s3d_conv.hip): float index of W[tap][o][co][c] — group g = co / 32 and
+// K quarter w = (c % 128) / 32 select a stream of steps (chunk, tap, k8), three 1-KB fragments (o) per step, lane = half * 32 +
+// co % 32 holds channels c0 + half * 4 + {0..3} of its output channel.  cin % 128 == 0; ceil(cout / 32) * cin * 288 floats.
+__host__ __device__ inline size_t rank1_frag_index(int cin, int tap, int o, int co, int c) {
+    const int g = co >> 5, i = co & 31, chunk = c >> 7, cc = c & 127, w = cc >> 5, k8 = (cc >> 3) & 3, half = (cc >> 2) & 1, e = cc & 3;
+    const size_t step = size_t(g * 4 + w) * (cin / 128 * 12) + chunk * 12 + tap * 4 + k8;
+    return ((step * 3 + o) * 64 + half * 32 + i) * 4 + e;
+}
+inline size_t rank1_frag_floats(int cin, int cout) { return size_t((cout + 31) / 32) * cin * 288; }
 void pack_tconv_raw(std::vector<float>& stage, const float* const W[3], const float* const bias[3], int cin, int cout,
                     int k, bool roll, ConvW& cw);
 
@@ -245,17 +257,21 @@ struct MeanPartials {        // per plane: rowpart [B][ntc][h][C] (sum over a ti
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                   hipStream_t st, const GnPartials* stats_part = nullptr);
 bool gn_act_can_add_parts(const GnPartials& part, int C);
+bool gn_parts_in_consumer(long long consumer_blocks);      // the consumer's own blocks add them (small launches) / k_gn_finalize_as does
+int gn_act_threads(int C);                                  // block size of k_gn_act for C channels
+long long gn_act_blocks(const Geo& g, int B);               // its grid
+int launch_gn_finalize_as(const GnPartials& part, const Geo& g, int C, int B, int threads, GnStats out, hipStream_t st);
 // the same on the virtual concat [bilinear2x(u) | sk] (y.C = u.C + sk.C, y.g = sk.g = 2 * u.g)
 int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const ActArgs& a, Tri& y, const MeanPartials* mp,
                       hipStream_t st);
 // finalize the six mean vectors: rowmean[p] [B][h][C], colmean[p] [B][w][C]
 struct MeanVecs { float* rowmean[3]; float* colmean[3]; };
-struct MeanFinArgs {
-    const float* rowpart[3]; const float* colpart[3];
-    float* rowmean[3]; float* colmean[3];
-    int h[3], w[3];
+struct MeanFinArgs {          // per vector v = 2 * plane + is_col (blockIdx.y): everything a block needs comes from wave-uniform scalar loads
+    const float* src[6];      // tile partials [B][nt][len][C]
+    float* dst[6];            // the mean vector [B][len][C]
+    int len[6], nt[6];        // positions along the kept axis, tile partials per position
+    float inv[6];             // 1 / length of the summed-out axis
     int C, cq, B;
-    long long begin[7];      // prefix over the 6 vectors, in float4 items per sample
 };
 MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv);
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st);
@@ -285,6 +301,7 @@ bool out_head_fuses_sampler(int C, int Cout, int B);     // the update happens i
 bool out_head_px_takes(int C, int Cout);                 // the pixel-chunk head serves this width (it can add GroupNorm partials itself)
 // part (with stats.mr == null): the head adds its input's GroupNorm partials itself — no k_gn_finalize launch before it
 bool out_head_adds_parts(const GnPartials& part, int C, int Cout);
+long long out_head_px_blocks(const Geo& g, int B);         // grid of the pixel-chunk head
 
 // small dense layers for the timestep path: y[b][o] = act_out( sum_i f(in[b][i]) * W[o][i] + bias[o] )
 // in_mode 0: plain, 1: SiLU(in), 2: in is t[b] -> sinusoidal embedding of width I (cos | sin)

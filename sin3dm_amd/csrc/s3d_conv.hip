@@ -30,6 +30,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int KC = 32;          // channels per K chunk
 constexpr int LDP = KC + 4;     // padded LDS row (floats)
 
+// ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11) of an upsampled residual with the multiply-adds spelled out: the
+// two epilogues of k_conv_mfma (plain / transposed accumulators) are chosen by launch size, and left to the compiler the
+// expression was contracted into different fma chains in them — a sample's bits then depended on the batch it ran in
+// (test_unet_properties_full_size).  Three fmas, two products, no free choice left.
+__device__ __forceinline__ float up2x_blend(float ly0, float ly1, float lx0, float lx1, float v00, float v01, float v10, float v11) {
+    const float top = __fmaf_rn(lx1, v01, __fmul_rn(lx0, v00));
+    const float bot = __fmaf_rn(lx1, v11, __fmul_rn(lx0, v10));
+    return __fmaf_rn(ly1, bot, __fmul_rn(ly0, top));
+}
+
 template <int TH_, int TW_, int KH_, int KW_, int WM_, int WN_, int MTW_, int NTW_, int KS_ = 1, int PF_ = 0, bool TR_ = false>
 struct ConvCfg {
     static constexpr int KS = KS_;       // independent partial accumulators over K (breaks the MFMA dependency chain)
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
 #pragma unroll
                         for (int ks = 1; ks < KS; ++ks) t += acc[ks][mt][nt][4 * q + e];
                         float ad = addv[qq][e];
-                        if (rb) ad += ly0 * (lx0 * r00[qq][e] + lx1 * r01[qq][e]) + ly1 * (lx0 * r10[qq][e] + lx1 * r11[qq][e]);
+                        if (rb) ad += up2x_blend(ly0, ly1, lx0, lx1, r00[qq][e], r01[qq][e], r10[qq][e], r11[qq][e]);
                         t += ad;
                         v[e] = args.relu ? fmaxf(t, 0.f) : t;
                     }
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                     const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
                     const float v00 = rb[(size_t(y0) * wi + x0) * cout], v01 = rb[(size_t(y0) * wi + x1) * cout];
                     const float v10 = rb[(size_t(y1) * wi + x0) * cout], v11 = rb[(size_t(y1) * wi + x1) * cout];
-                    addv[mt][r] += ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+                    addv[mt][r] += up2x_blend(ly0, ly1, lx0, lx1, v00, v01, v10, v11);
                 }
         }
         float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
@@ -518,6 +528,134 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     rank1_block<ROLL3, NS>(blk, lds);
 }
 
+// ------------------------------------------------------------------ rank-1 rollout tables, batched form (batch >= 2)
+// k_rank1 is built for batch 1: weight tiles through LDS with two barriers per (tap, chunk) stage, 70 KB of LDS — two blocks
+// per CU, a latency chain that every block of a batched launch repeats (batch 8: 37 / 68 / 114 us per launch at 128 / 256 /
+// 384 channels for 12-35 us of MFMA work).  k_rank1b keeps that kernel's split of K over the four waves of a block (wave w
+// contracts channels [32w, 32w+32) of every 128-channel chunk) but
+//  * a block owns 32 positions of one sample x 32 output channels x the three taps o of the summed-out axis — three 32x32
+//    accumulators per wave, the four edge variants are formed from complete sums, no zero-padded weight rows;
+//  * the weights come from a second image in MFMA fragment order (rank1_frag_index): a B operand is one coalesced 1-KB load
+//    straight into a register ring three k-steps deep — no LDS, no barrier inside the K walk;
+//  * the blocks that read the same weights (same vector, slice and channel group) are neighbours on one XCD: its L2 fetches
+//    them once;
+//  * 48 KB of LDS (the vector tile, then the four waves' partial sums) -> three blocks per CU.
+// BIT-IDENTICAL to k_rank1<true>: same products in the same order per wave (chunk, tap, k8, e ascending), the four partial sums
+// meet as ((q0 + q1) + q2) + q3, the variants are (u0 + u1) + u2, u1 + u2, u0 + u1, u1.
+// cin must be a multiple of 128 (whole chunks); slices as in k_rank1.
+constexpr int kR1bLdsFloats = 4 * 48 * 64;                 // the reduction image; the vector tile (34 x (slice channels + 4)) sits in the same bytes
+__global__ __launch_bounds__(256) void k_rank1b(ConvArgs args, int total_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+    int bid = blockIdx.x;
+    if ((total_blocks & 7) == 0) bid = (bid & 7) * (total_blocks >> 3) + (bid >> 3);     // consecutive logical ids share an XCD
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
+    const ConvJob& J = args.job[j];
+    int local = bid - J.block_begin;
+    const int L = J.w, cin = args.cin, cout = args.cout, B = args.B;
+    const int mtile = local % J.tiles_per_img; local /= J.tiles_per_img;     // (tile, sample) fastest: neighbours read the same weights
+    const int b = local % B; local /= B;
+    const int g = local % J.n_tiles_n, sl = local / J.n_tiles_n;            // 32-output-channel group, K slice
+    const int nchunks = cin / kR1Chunk;
+    int chunk0 = 0, nch = nchunks;
+    if (args.r1_slices > 1) { const int first = (nchunks + 1) / 2; chunk0 = sl ? first : 0; nch = sl ? nchunks - first : first; }
+    const int csl = nch * kR1Chunk, ld = csl + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 31, half = lane >> 5;
+    // this wave's fragment stream: steps (chunk, tap, k8) of (group g, quarter wid), three fragments (o = 0, 1, 2) per step
+    const int nsteps = nch * 12;
+    const r1_f32x4* pf = reinterpret_cast<const r1_f32x4*>(J.wgt_r1f) + (size_t(g * 4 + wid) * (nchunks * 12) + chunk0 * 12) * 192 + lane;
+    constexpr int D = 3;                                    // (four deep: no faster)
+    r1_f32x4 ring[D][3];
+    int pf_s = 0;
+    auto prefetch = [&](int slot) {                         // unconditional (past the end: the last step again, unused) — the
+        ring[slot][0] = ((r1_gf4ptr)(uintptr_t)pf)[0];      // compiler can then count the loads in flight (vmcnt(6)) instead of
+        ring[slot][1] = ((r1_gf4ptr)(uintptr_t)(pf + 64))[0];   // draining them at every step
+        ring[slot][2] = ((r1_gf4ptr)(uintptr_t)(pf + 128))[0];
+        ++pf_s;
+        pf += pf_s < nsteps ? 192 : 0;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) prefetch(d);               // (the weights do not depend on the vector tile: requested first)
+    {   // the sample's vector tile: rows = positions mtile*32 - 1 .. + 32, zero outside [0, L)
+        const int q4 = csl / 4, items = 34 * q4;
+        const float* vb = J.in + (size_t(b) * L) * cin + chunk0 * kR1Chunk;
+        const r1_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int it0 = tid; it0 < items; it0 += 256 * 5) {
+            r1_f32x4 v[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int it = it0 + 256 * u, row = it / q4, q = it - row * q4, pos = mtile * 32 - 1 + row;
+                const bool ok = it < items && pos >= 0 && pos < L;
+                v[u] = ((r1_gf4ptr)(uintptr_t)(vb + size_t(ok ? pos : 0) * cin + (ok ? q : 0) * 4))[0];
+                if (!ok) v[u] = zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const int it = it0 + 256 * u, row = it / q4, q = it - row * q4;
+                if (it < items) *reinterpret_cast<r1_f32x4*>(lds_dyn + row * ld + q * 4) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    r1_f32x16 q[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[o][r] = 0.f;
+    const float* Ab = lds_dyn + i * ld + half * 4 + wid * 32;
+    for (int ch = 0; ch < nch; ++ch) {
+        const float* Ac = Ab + ch * kR1Chunk;
+#pragma unroll
+        for (int st = 0; st < 12; ++st) {
+            const int tap = st >> 2, k8 = st & 3;
+            const r1_f32x4 a4 = *reinterpret_cast<const r1_f32x4*>(Ac + tap * ld + k8 * 8);
+            r1_f32x4 b4[3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) b4[o] = ring[st % D][o];
+            __builtin_amdgcn_sched_barrier(0);              // (left alone, the scheduler sinks the ring's loads to their use: one exposed L2 round trip per step)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) q[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[o][e], q[o], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch(st % D);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();                                        // every wave is done with the vector tile: the same bytes take the partial sums
+    float* red = lds_dyn;                                   // [wave][o][r][lane]
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wid * 3 + o) * 16 + r) * 64 + lane] = q[o][r];
+    __syncthreads();
+    float* out = J.out + size_t(sl) * B * L * 4 * cout;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int it = tid + 256 * k, r = it >> 6, l = it & 63;
+        float u[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float* p = red + (o * 16 + r) * 64 + l;
+            u[o] = ((p[0] + p[3 * 1024]) + p[2 * 3 * 1024]) + p[3 * 3 * 1024];
+        }
+        const int row = mtile * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), co = g * 32 + (l & 31);
+        if (row < L && co < cout) {
+            float* o4 = out + (size_t(b) * L + row) * 4 * cout + co;        // [pos][variant][cout]
+            o4[0] = (u[0] + u[1]) + u[2]; o4[cout] = u[1] + u[2]; o4[2 * cout] = u[0] + u[1]; o4[3 * cout] = u[1];
+        }
+    }
+}
+bool rank1b_takes(const ConvArgs& a) {
+    if (a.cin % kR1Chunk != 0 || a.B < 2) return false;
+    for (int j = 0; j < a.njobs; ++j) if (!a.job[j].wgt_r1f) return false;
+    const int nchunks = a.cin / kR1Chunk, maxch = a.r1_slices > 1 ? (nchunks + 1) / 2 : nchunks;
+    if (34 * (maxch * kR1Chunk + 4) > kR1bLdsFloats) return false;     // the vector tile must fit the reduction image's 48 KB
+    static const bool on = !(getenv("S3D_RANK1_BATCH") && atoi(getenv("S3D_RANK1_BATCH")) == 0);
+    return on;
+}
+
 int conv_rank1_slices(int cin) {
     static const bool on = !(getenv("S3D_RANK1_SLICES") && atoi(getenv("S3D_RANK1_SLICES")) == 0);
     return on && cin >= 2 * kR1Chunk && cin % kR1Chunk == 0 ? 2 : 1;
@@ -552,6 +690,21 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
     if (conv_use_naive()) {
         if (!roll3) return launch_conv_naive(CONV_1x3_VEC, a, st);
         hipLaunchKernelGGL(k_rank1_roll_naive, dim3(512), dim3(256), 0, st, a);
+        S3D_HIP(hipGetLastError());
+        return 0;
+    }
+    if (roll3 && rank1b_takes(a)) {                       // batch >= 2, fragment-order weights at hand
+        int blocks = 0;
+        for (int j = 0; j < a.njobs; ++j) {
+            ConvJob& J = a.job[j];
+            J.tiles_x = J.tiles_per_img = (J.w + 31) / 32;
+            J.n_tiles_n = (a.cout + 31) / 32;
+            J.block_begin = blocks;
+            blocks += J.tiles_per_img * a.B * J.n_tiles_n * (a.r1_slices > 1 ? a.r1_slices : 1);
+        }
+        if (!blocks) return 0;
+        conv_note_kernel("k_rank1b (three-tap rollout tables, fragment-order weights)");
+        hipLaunchKernelGGL(k_rank1b, dim3(blocks), dim3(256), kR1bLdsFloats * sizeof(float), st, a, blocks);
         S3D_HIP(hipGetLastError());
         return 0;
     }

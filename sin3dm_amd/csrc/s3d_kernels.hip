@@ -527,6 +527,23 @@ static GnPartSrc gn_part_src(const GnPartials& part, const Geo& g, int C) {
     return s;
 }
 
+// The same sums as a consumer that adds the partials itself, as a launch of their own: one block of the CONSUMER's size per
+// (plane, sample) runs gn_stats_from_parts — lane count per group, trip order and meeting order are the consumer's, so the
+// statistics are bit-identical to the in-consumer form.  It pays when the consumer has many rounds of blocks (batch >= 2, the
+// (256,256,128) planes): every one of them repeats the ~3-us addition as its prologue (config 3: 5.42 -> 5.35 ms/step).
+__global__ void k_gn_finalize_as(GnPartSrc ps, float* mr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    gn_stats_from_parts(ps, blockIdx.y, blockIdx.x, reinterpret_cast<double*>(smem_raw), mr);
+}
+int launch_gn_finalize_as(const GnPartials& part, const Geo& g, int C, int B, int threads, GnStats out, hipStream_t st) {
+    S3D_CHECK(gn_act_can_add_parts(part, C) && threads >= 32 && threads % 32 == 0 && out.mr, S3D_ERR_INVALID, "gn_finalize_as: layout");
+    if (!B) return 0;
+    const GnPartSrc ps = gn_part_src(part, g, C);
+    hipLaunchKernelGGL(k_gn_finalize_as, dim3(3, B), dim3(threads), size_t(threads) * 2 * sizeof(double) + 64 * sizeof(float), st, ps, out.mr);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 struct GnActArgs {
     const float* x[3]; float* y[3];
     const float* gamma[3]; const float* beta[3];
@@ -625,8 +642,19 @@ __global__ void k_gn_act(GnActArgs a) {
 }
 bool gn_act_can_add_parts(const GnPartials& part, int C) {
     if (!part.p || part.nsub % 32 != 0 || C % 32 != 0) return false;
-    static const bool on = !(getenv("S3D_GN_FUSED") && atoi(getenv("S3D_GN_FUSED")) == 0);
-    return on && (part.nsub / 32) * part.maxparts <= 160;      // entries per group a block adds (x 32 groups x 16 bytes; the 256 of an avgpool producer: +4.1 us in the act kernel for a 4.6-us launch, not taken)
+    return (part.nsub / 32) * part.maxparts <= 160;      // entries per group a block adds (x 32 groups x 16 bytes; the 256 of an avgpool producer: +4.1 us in the act kernel for a 4.6-us launch, not taken)
+}
+// Who adds them: the consumer's own blocks (S3D_GN_FUSED=1: always) when the launch is at most two rounds of blocks — one
+// dependent launch less on a latency-bound step —, k_gn_finalize_as ahead of it (S3D_GN_FUSED=0: always) otherwise.  Same bits.
+bool gn_parts_in_consumer(long long consumer_blocks) {
+    static const int mode = getenv("S3D_GN_FUSED") ? atoi(getenv("S3D_GN_FUSED")) : -1;
+    return mode < 0 ? consumer_blocks <= 1536 : mode != 0;
+}
+int gn_act_threads(int C) { int cq, pl; thread_shape(C, cq, pl); return cq * std::min(pl, kActCols); }
+long long gn_act_blocks(const Geo& g, int B) {
+    int maxtiles = 0;
+    for (int p = 0; p < 3; ++p) maxtiles = std::max(maxtiles, cdiv(g.h[p], kActRows) * cdiv(g.w[p], kActCols));
+    return (long long)maxtiles * 3 * B;
 }
 int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y, const MeanPartials* mp,
                   hipStream_t st, const GnPartials* stats_part) {
@@ -783,25 +811,27 @@ int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const A
 // th.mean over one axis of the activated planes (src/diffusion/unet_triplane.py:38-46): add the tile partials
 // in index order and divide by the axis length.
 __global__ __launch_bounds__(256) void k_means_finalize(MeanFinArgs a) {
-    means_finalize_thread(a, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+    means_finalize_thread(a, blockIdx.y, blockIdx.z, int(blockIdx.x * 256 + threadIdx.x));
 }
 MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv) {
     MeanFinArgs a;
-    a.C = C; a.cq = C / 4; a.B = B; a.begin[0] = 0;
+    a.C = C; a.cq = C / 4; a.B = B;
     for (int p = 0; p < 3; ++p) {
-        a.rowpart[p] = mp.rowpart[p]; a.colpart[p] = mp.colpart[p];
-        a.rowmean[p] = mv.rowmean[p]; a.colmean[p] = mv.colmean[p];
-        a.h[p] = g.h[p]; a.w[p] = g.w[p];
-        a.begin[2 * p + 1] = a.begin[2 * p] + (long long)g.h[p] * a.cq;
-        a.begin[2 * p + 2] = a.begin[2 * p + 1] + (long long)g.w[p] * a.cq;
+        const int h = g.h[p], w = g.w[p];
+        a.src[2 * p] = mp.rowpart[p]; a.dst[2 * p] = mv.rowmean[p];
+        a.len[2 * p] = h; a.nt[2 * p] = cdiv(w, kActCols); a.inv[2 * p] = 1.0f / float(w);
+        a.src[2 * p + 1] = mp.colpart[p]; a.dst[2 * p + 1] = mv.colmean[p];
+        a.len[2 * p + 1] = w; a.nt[2 * p + 1] = cdiv(h, kActRows); a.inv[2 * p + 1] = 1.0f / float(h);
     }
     return a;
 }
 int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, MeanVecs mv, hipStream_t st) {
     MeanFinArgs a = means_finalize_args(g, C, B, mp, mv);
-    long long n = a.begin[6] * B;
-    if (!n) return 0;
-    hipLaunchKernelGGL(k_means_finalize, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, st, a);
+    int maxlen = 0;
+    for (int v = 0; v < 6; ++v) maxlen = std::max(maxlen, a.len[v]);
+    if (!maxlen || !B || !a.cq) return 0;
+    S3D_CHECK((long long)maxlen * a.cq * 4 < (1ll << 31), S3D_ERR_INVALID, "means_finalize: vector too long");
+    hipLaunchKernelGGL(k_means_finalize, dim3(cdiv(maxlen * a.cq * 4, 256), 6, B), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -1169,6 +1199,17 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
     const int h = a.h[p], w = a.wd[p];
     const int len = p == 2 ? h : w, nseg = (len + kOhPx - 1) / kOhPx;
     const int line = blk / nseg, s0 = (blk % nseg) * kOhPx;
+    // the plane's weight rows [Cout][C] are requested NOW and parked in registers: read from memory inside the contraction
+    // (wave-uniform addresses, eight 16-byte loads and a full wait per pair of output channels) they were ~8 us of exposed L2
+    // round trips per block (batch 8: 171 -> see profiles/r04_out_head.txt); they move into the staging area once every lane
+    // holds its activations
+    constexpr int kWIts = (16 * CQ + 255) / 256;             // float4 items of Cout <= 16 rows per thread
+    float4 wreg[kWIts];
+#pragma unroll
+    for (int k = 0; k < kWIts; ++k) {
+        const int it = tid + 256 * k;
+        wreg[k] = it < a.Cout * CQ ? reinterpret_cast<const float4*>(a.w + size_t(p) * a.Cout * C)[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // FUSED: x_t and the step's eps of this thread's output positions are requested NOW — as the tail of the block (behind the
     // last barrier) their latency was the block's critical path: 31 us per launch instead of 15 + 7 for head + sampler kernel
     constexpr int kOutIts = 16 * kOhPx / 256;                 // Cout <= 16
@@ -1234,12 +1275,23 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
             const float4 v = *reinterpret_cast<const float4*>(sx + e * LD + wv * CPW + 4 * j);
             act[4 * j] = v.x; act[4 * j + 1] = v.y; act[4 * j + 2] = v.z; act[4 * j + 3] = v.w;
         }
-        const float* __restrict__ wb = a.w + (size_t(p) * a.Cout) * C + wv * CPW;     // wave-uniform: scalar loads
+        __syncthreads();                                    // every lane holds its activations: the staging area takes the weight rows
+#pragma unroll
+        for (int k = 0; k < kWIts; ++k) {
+            const int it = tid + 256 * k;
+            if (it < 16 * CQ) reinterpret_cast<float4*>(sx)[it] = wreg[k];
+        }
+        __syncthreads();
+        const float* wb = sx + wv * CPW;                    // [Cout][C]; wave-uniform addresses: LDS broadcast reads
         for (int co = 0; co < a.Cout; ++co) {
-            const float* __restrict__ wr = wb + size_t(co) * C;
+            const float4* wr = reinterpret_cast<const float4*>(wb + co * C);
             float s0a = 0.f, s1a = 0.f;
 #pragma unroll
-            for (int j = 0; j < CPW; j += 2) { s0a = fmaf(act[j], wr[j], s0a); s1a = fmaf(act[j + 1], wr[j + 1], s1a); }
+            for (int j = 0; j < CPW / 4; ++j) {
+                const float4 w4 = wr[j];
+                s0a = fmaf(act[4 * j], w4.x, s0a); s1a = fmaf(act[4 * j + 1], w4.y, s1a);
+                s0a = fmaf(act[4 * j + 2], w4.z, s0a); s1a = fmaf(act[4 * j + 3], w4.w, s1a);
+            }
             sp[wv][co][e] = s0a + s1a;
         }
     }
@@ -1278,6 +1330,11 @@ bool out_head_px_takes(int C, int Cout) { return out_head_px_form(C, Cout); }
 // the pixel-chunk form takes the launch it happens in the same kernel and `out` may be null (the model output is then never
 // stored); otherwise `out` is required and the stand-alone k_sampler follows.
 // part != null (stats.mr == null; only when out_head_adds_parts() says so): the kernel adds the producer's GroupNorm partials itself.
+long long out_head_px_blocks(const Geo& g, int B) {
+    long long n = 0;
+    for (int p = 0; p < 3; ++p) { const int len = p == 2 ? g.h[p] : g.w[p], lines = p == 2 ? g.w[p] : g.h[p]; n += (long long)lines * cdiv(len, kOhPx); }
+    return n * B;
+}
 bool out_head_adds_parts(const GnPartials& part, int C, int Cout) { return out_head_px_form(C, Cout) && gn_act_can_add_parts(part, C); }
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const float* w, const float* bias,
                     int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse, const GnPartials* part) {

@@ -64,7 +64,7 @@ struct ConvWT {
     size_t rcol_T[3] = {0, 0, 0};
 };
 struct ResBlockWT { ConvWT c1, c2, skip; };
-enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD, PK_WINO24S_T };
+enum PackKind { PK_COPY = 0, PK_TRANS2D, PK_DENSE, PK_DENSE_SLICE, PK_DENSE_T, PK_WINO, PK_WINO_T, PK_WINO24S, PK_RANK1, PK_RANK1_BWD, PK_DENSE_PAD, PK_DENSE_T_PAD, PK_WINO24S_T, PK_RANK1F };
 struct PackDesc {                     // one device-side repacking job: flat reference-layout parameter -> packed image
     int kind, cout, ctot, cin, slot, taps, col_varying, to_tbuf;
     long long src, dst, n;
@@ -266,8 +266,10 @@ struct Fwd {
         for (int p = 0; p < 3; ++p) {
             ConvJob& jr = ca.job[2 * p];
             jr.in = rowvec[p]; jr.wgt = m->dev(cw.rrow[p]); jr.out = const_cast<float*>(rrow[p]); jr.h = 1; jr.w = y.g.h[p];
+            jr.wgt_r1f = cw.rrow_f[p] ? m->dev(cw.rrow_f[p]) : nullptr;
             ConvJob& jc = ca.job[2 * p + 1];
             jc.in = colvec[p]; jc.wgt = m->dev(cw.rcol[p]); jc.out = const_cast<float*>(rcol[p]); jc.h = 1; jc.w = y.g.w[p];
+            jc.wgt_r1f = cw.rcol_f[p] ? m->dev(cw.rcol_f[p]) : nullptr;
         }
         return m->timed_conv(2, CONV_1x3_ROLL, ca, st);
     }
@@ -279,8 +281,12 @@ struct Fwd {
         GnStats stats{nullptr};
         // when x carries its producer's partial sums and they are few, the act kernel adds them itself
         // (with a tape, block 0 of each plane also writes them out for the backward pass)
-        const bool add_parts = !x.gn && gn_act_can_add_parts(x.part, x.C);
-        if (!add_parts) S3D_TRY(stats_of(x, stats));
+        const bool few_parts = !x.gn && gn_act_can_add_parts(x.part, x.C);
+        const bool add_parts = few_parts && gn_parts_in_consumer(gn_act_blocks(x.g, B));
+        if (few_parts && !add_parts) {                      // many rounds of act blocks: the same sums once, ahead of them
+            stats.mr = ar().alloc<float>(size_t(B) * 3 * 64);
+            if (!measuring) S3D_TRY(launch_gn_finalize_as(x.part, x.g, x.C, B, gn_act_threads(x.C), stats, st));
+        } else if (!add_parts) S3D_TRY(stats_of(x, stats));
         else if (nt) stats.mr = ar().alloc<float>(size_t(B) * 3 * 64);
         if (nt) { nt->stats = stats; nt->roll = cw && cw->rollout; }
         y = alloc_tri(x.C, x.g);

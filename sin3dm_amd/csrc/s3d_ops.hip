@@ -87,8 +87,10 @@ int s3d_op_triplane_conv(const float* const in[3], float* const out[3], int B, i
         for (int p = 0; p < 3; ++p) {
             ConvJob& jr = ca.job[2 * p];
             jr.in = rowvec[p]; jr.wgt = wdev + cw.rrow[p]; jr.out = tab_row[p]; jr.h = 1; jr.w = g.h[p];
+            jr.wgt_r1f = cw.rrow_f[p] ? wdev + cw.rrow_f[p] : nullptr;
             ConvJob& jc = ca.job[2 * p + 1];
             jc.in = colvec[p]; jc.wgt = wdev + cw.rcol[p]; jc.out = tab_col[p]; jc.h = 1; jc.w = g.w[p];
+            jc.wgt_r1f = cw.rcol_f[p] ? wdev + cw.rcol_f[p] : nullptr;
         }
         S3D_TRY(launch_conv(CONV_1x3_ROLL, ca, st));
     }

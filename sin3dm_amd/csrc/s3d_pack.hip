@@ -126,6 +126,14 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
             dst[((size_t)t * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin + c] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw];
             break;
         }
+        case PK_RANK1F: {                        // the same items in the fragment order of k_rank1b (rank1_frag_index)
+            const int c = int(i % cin); long long r = i / cin;
+            const int co = int(r % cout); r /= cout;
+            const int o = int(r % 3), t = int(r / 3);
+            const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
+            dst[rank1_frag_index(cin, t, o, co, c)] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw];
+            break;
+        }
         case PK_RANK1_BWD: {                     // dst [(tap*cin + c)*(3*cout) + j*cout + co]
             const int co = int(i % cout); long long r = i / cout;
             const int j = int(r % 3); r /= 3;
@@ -193,6 +201,7 @@ struct Plan {
             for (int slot = 1; slot <= 2; ++slot) {
                 const bool colv = (slot == 1) ? a_is_col : !a_is_col;
                 add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)3 * 3 * cout * cin, cout, ctot, cin, 9, slot, colv);
+                if (colv ? cw.rcol_f[p] : cw.rrow_f[p]) add(PK_RANK1F, w, colv ? cw.rcol_f[p] : cw.rrow_f[p], (long long)3 * 3 * cout * cin, cout, ctot, cin, 9, slot, colv);
                 const size_t off = talloc(size_t(3) * cin * 3 * cout);
                 (colv ? wt.rcol_T[p] : wt.rrow_T[p]) = off;
                 add(PK_RANK1_BWD, w, off, (long long)3 * cin * 3 * cout, cout, ctot, cin, 9, slot, colv, 1);

@@ -20,38 +20,40 @@ constexpr int kR1LdsFloats = (34 + 2 * 32) * kR1Ld;       // A tile (34 rows) + 
 
 // ------------------------------------------------------------------ stage A: th.mean over one axis of the activated planes
 // (src/diffusion/unet_triplane.py:38-46): add the tile partials in index order and divide by the axis length.
-// item = (vector, position, channel quad); four adjacent lanes share an item: lane k takes partials k, k+4, ... and the four
-// sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch).  gthread = global thread index.
-__device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, long long gthread) {
-    const long long i = gthread >> 2;
-    const int part0 = int(gthread & 3);
-    const bool live = i < a.begin[6] * a.B;
-    const long long ii = live ? i : 0;
-    const int b = int(ii / a.begin[6]);
-    long long r = ii % a.begin[6];
-    int v = 0;
-    while (r >= a.begin[v + 1]) ++v;
-    r -= a.begin[v];
-    const int p = v >> 1, is_col = v & 1;
-    const int pos = int(r / a.cq), q = int(r % a.cq);
-    const int h = a.h[p], w = a.w[p];
+// item = (position, channel quad) of vector v = blockIdx.y of sample blockIdx.z; four adjacent lanes share an item: lane k
+// takes partials k, k+4, ... and the four sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch).
+// The launch is a pure latency chain (1.6 us of dispatch + index arithmetic + one round of loads + a store), so the index
+// arithmetic is 32-bit on wave-uniform scalars and a lane's (up to four) partials are requested together (round 4: 5.0 -> see
+// profiles/r04_small_kernels.txt; sums and their order unchanged).
+__device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, int v, int b, int gthread) {
+    const int i = gthread >> 2, part0 = gthread & 3;
+    const int len = a.len[v], nt = a.nt[v], cq = a.cq;
+    const bool live = i < len * cq;
+    const int ii = live ? i : 0;
+    const int pos = ii / cq, q = ii - pos * cq;
+    const float4* src = reinterpret_cast<const float4*>(a.src[v]) + (size_t(b) * nt * len + pos) * cq + q;
+    const size_t tstride = size_t(len) * cq;
     float4 s = make_float4(0, 0, 0, 0);
-    const int nt = is_col ? (h + kActRows - 1) / kActRows : (w + kActCols - 1) / kActCols;
-    const int len = is_col ? w : h;
-    const float* src = is_col ? a.colpart[p] : a.rowpart[p];
-    for (int t = part0; t < nt; t += 4) {
-        const float4 u = reinterpret_cast<const float4*>(src + ((size_t(b) * nt + t) * len + pos) * a.C)[q];
-        s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w;
+    for (int t0 = part0; t0 < nt; t0 += 16) {
+        float4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = t0 + 4 * k;
+            u[k] = src[size_t(t < nt ? t : part0) * tstride];
+            if (t >= nt) u[k] = make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t0 + 4 * k < nt) { s.x += u[k].x; s.y += u[k].y; s.z += u[k].z; s.w += u[k].w; }
     }
 #pragma unroll
     for (int off = 1; off <= 2; off <<= 1) {
         s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64); s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
     }
     if (!live || part0 != 0) return;
-    const float inv = 1.0f / float(is_col ? h : w);
+    const float inv = a.inv[v];
     s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-    float* dst = (is_col ? a.colmean[p] : a.rowmean[p]) + (size_t(b) * len + pos) * a.C + q * 4;
-    *reinterpret_cast<float4*>(dst) = s;
+    reinterpret_cast<float4*>(a.dst[v])[(size_t(b) * len + pos) * cq + q] = s;
 }
 
 // ------------------------------------------------------------------ stage B: rank-1 rollout tables (skinny GEMMs)

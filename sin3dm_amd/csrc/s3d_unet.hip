@@ -122,6 +122,19 @@ void pack_tconv_raw(std::vector<float>& stage, const float* const Wp[3], const f
                         for (int c = 0; c < cin; ++c) dst[c] = W[(size_t(co) * ctot + slot * cin + c) * 9 + kh * 3 + kw];
                     }
             if (col_varying) cw.rcol[p] = off; else cw.rrow[p] = off;
+            if (cin % 128 == 0) {                            // the same values in the fragment order of k_rank1b (batch >= 2)
+                const size_t off_f = push(stage, nullptr, rank1_frag_floats(cin, cout));
+                float* f = stage.data() + off_f;
+                std::fill(f, f + rank1_frag_floats(cin, cout), 0.f);
+                const float* r2 = stage.data() + off;        // (push may have moved the staging image)
+                for (int t = 0; t < 3; ++t)
+                    for (int o = 0; o < 3; ++o)
+                        for (int co = 0; co < cout; ++co) {
+                            const float* src = r2 + (size_t(t) * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin;
+                            for (int c = 0; c < cin; ++c) f[rank1_frag_index(cin, t, o, co, c)] = src[c];
+                        }
+                if (col_varying) cw.rcol_f[p] = off_f; else cw.rrow_f[p] = off_f;
+            }
         }
     }
 }
@@ -334,8 +347,12 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
     }
     // the decoder's Upsample of the LAST level-0 block does not exist (level > 0 only), so h is at full size
     GnStats stats{nullptr};
-    const bool head_adds = !tape && !h.gn && h.part.p && out_head_adds_parts(h.part, h.C, c.out_channels);
-    if (!head_adds) S3D_TRY(f.stats_of(h, stats));
+    const bool head_few = !tape && !h.gn && h.part.p && out_head_adds_parts(h.part, h.C, c.out_channels);
+    const bool head_adds = head_few && gn_parts_in_consumer(out_head_px_blocks(h.g, B));
+    if (head_few && !head_adds) {                           // (bit-identical to the in-head addition: the head's 256-thread blocks)
+        stats.mr = ar.alloc<float>(size_t(B) * 3 * 64);
+        if (!meas) S3D_TRY(launch_gn_finalize_as(h.part, h.g, h.C, B, 256, stats, st));
+    } else if (!head_adds) S3D_TRY(f.stats_of(h, stats));
     if (tape) { tape->head_in = h; tape->head_stats = stats; tape->arena_off = ar.off; tape->valid = !meas; }
     // a fused step on a width the pixel-chunk head does not take: the model output goes through a workspace buffer
     if (fuse && !out && !out_head_fuses_sampler(h.C, c.out_channels, B)) out = ar.alloc<float>(size_t(B) * c.out_channels * (H + D) * (W + D));

@@ -105,8 +105,8 @@ def test_unet_forward_golden_other_conv_kernels(variant):
     F(2x4,3x3) kernel forced onto every launch whose widths allow it — by default it only takes launches of several rounds of
     blocks; 4 / 2: F(2x2) with one / two frequency rows per wave; 0: direct MFMA convolution) against the same golden vectors,
     leaf convolutions and ragged shapes included; novcat: S3D_VCAT=0, the upsample + concat materialised instead of the virtual
-    concat of Fwd::resblock_cat; gnsplit: S3D_GN_FUSED=0, every GroupNorm statistic through k_gn_finalize instead of being added
-    inside k_gn_act / the output head; 1x1t: S3D_CONV1X1_T=1, the transposed-accumulator epilogue of the 1x1 convolutions (16-byte
+    concat of Fwd::resblock_cat; gnsplit: S3D_GN_FUSED=0, every GroupNorm statistic from a launch of its own (k_gn_finalize_as) instead of
+    being added inside k_gn_act / the output head; 1x1t: S3D_CONV1X1_T=1, the transposed-accumulator epilogue of the 1x1 convolutions (16-byte
     accesses; by default only launches of four rounds of blocks take it) on every plain 1x1 launch; naive: S3D_CONV_IMPL=naive, the
     one-thread-per-output convolutions used for triangulation).  The choices are read once per process, hence the subprocess."""
     import os, subprocess, sys
@@ -182,10 +182,39 @@ def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, va
         assert np.array_equal(a, b), (mc, B, hwd, float(np.abs(a - b).max()))
 
 
+def test_groupnorm_statistics_forms_are_bit_identical(tmp_path):
+    """GroupNorm32 statistics (nn.py:17-19, 93-100) of a convolution output are the sum of its epilogue's partial records.  Small
+    launches add them in the CONSUMER's own blocks (k_gn_act, k_out_head_px: one dependent launch less), launches of many rounds
+    of blocks (batch >= 2, big planes) get them from k_gn_finalize_as, which runs the consumer's own summation (same lanes per
+    group, same trip and meeting order) once ahead of it.  S3D_GN_FUSED=1 / =0 force either form everywhere, the default chooses
+    by launch size: whole-UNet outputs agree bit for bit — so a sample's result does not depend on the batch it is computed in."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for tag, val in (("in", "1"), ("ahead", "0")):
+        code = (
+            "import numpy as np, sys\n"
+            "sys.path.insert(0, 'tests')\n"
+            "import test_hip_parity as tp\n"
+            "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
+            "    y, _ = tp._r1_forward(mc, B, hwd, 90 + i)\n"
+            f"    np.save(r'{tmp_path}/{tag}_' + str(i) + '.npy', y)\n"
+            "print('ok')\n")
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_GN_FUSED=val), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    for i, (mc, B, hwd) in enumerate(R1_CASES):
+        y, _ = _r1_forward(mc, B, hwd, 90 + i)
+        a, b = np.load(f"{tmp_path}/in_{i}.npy"), np.load(f"{tmp_path}/ahead_{i}.npy")
+        assert np.array_equal(a, b), (mc, B, hwd, float(np.abs(a - b).max()))
+        assert np.array_equal(y, a), (mc, B, hwd)
+
+
 def test_rank1_sample_pairs_are_bit_identical(tmp_path):
-    """Batch >= 2: a k_rank1 block builds the rollout tables (unet_triplane.py:37-58) of TWO samples per staged weight tile
-    (s3d_rank1.h, NS = 2; an odd batch leaves a one-sample block).  Each sample's sums are formed in the same order as with one
-    sample per block: the default against S3D_RANK1_BATCH=0 in a separate process, K slices on in both, bit for bit."""
+    """Batch >= 2: the rollout tables (unet_triplane.py:37-58) come from the batched forms — k_rank1b when the own channels are
+    whole 128-channel chunks (fragment-order weights straight into registers, 32 positions x 32 output channels x 3 taps per
+    block, XCD-local weight reuse; s3d_conv.hip), otherwise k_rank1 with TWO samples per staged weight tile (s3d_rank1.h, NS = 2;
+    an odd batch leaves a one-sample block).  Each sample's sums are formed in the same order as in the batch-1 kernel: the
+    default against S3D_RANK1_BATCH=0 (one sample per k_rank1 block) in a separate process, K slices on in both, bit for bit."""
     import os, subprocess, sys
     cases = [(i, c) for i, c in enumerate(R1_CASES) if c[1] >= 2]
     code = (
