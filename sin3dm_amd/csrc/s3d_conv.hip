@@ -528,11 +528,11 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
     rank1_block<ROLL3, NS>(blk, lds);
 }
 
-// ------------------------------------------------------------------ rank-1 rollout tables, batched form (batch >= 2)
-// k_rank1 is built for batch 1: weight tiles through LDS with two barriers per (tap, chunk) stage, 70 KB of LDS — two blocks
-// per CU, a latency chain that every block of a batched launch repeats (batch 8: 37 / 68 / 114 us per launch at 128 / 256 /
-// 384 channels for 12-35 us of MFMA work).  k_rank1b keeps that kernel's split of K over the four waves of a block (wave w
-// contracts channels [32w, 32w+32) of every 128-channel chunk) but
+// ------------------------------------------------------------------ rank-1 rollout tables, fragment-order form (own channels in whole 128-channel chunks)
+// k_rank1 stages its weight tiles through LDS with two barriers per (tap, chunk) stage and 52-70 KB of LDS — two blocks per
+// CU, a latency chain that every block of a batched launch repeats (batch 8: 37 / 68 / 114 us per launch at 128 / 256 / 384
+// channels for 12-35 us of MFMA work; batch 1 on the (256,256,128) planes: 19.6 us).  k_rank1b keeps that kernel's split of K over
+// the four waves of a block (wave w contracts channels [32w, 32w+32) of every 128-channel chunk) but
 //  * a block owns 32 positions of one sample x 32 output channels x the three taps o of the summed-out axis — three 32x32
 //    accumulators per wave, the four edge variants are formed from complete sums, no zero-padded weight rows;
 //  * the weights come from a second image in MFMA fragment order (rank1_frag_index): a B operand is one coalesced 1-KB load
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void k_rank1b(ConvArgs args, int total_blocks)
     }
 }
 bool rank1b_takes(const ConvArgs& a) {
-    if (a.cin % kR1Chunk != 0 || a.B < 2) return false;
+    if (a.cin % kR1Chunk != 0) return false;
     for (int j = 0; j < a.njobs; ++j) if (!a.job[j].wgt_r1f) return false;
     const int nchunks = a.cin / kR1Chunk, maxch = a.r1_slices > 1 ? (nchunks + 1) / 2 : nchunks;
     if (34 * (maxch * kR1Chunk + 4) > kR1bLdsFloats) return false;     // the vector tile must fit the reduction image's 48 KB
@@ -693,7 +693,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         S3D_HIP(hipGetLastError());
         return 0;
     }
-    if (roll3 && rank1b_takes(a)) {                       // batch >= 2, fragment-order weights at hand
+    if (roll3 && rank1b_takes(a)) {                       // fragment-order weights at hand (S3D_RANK1_BATCH=0: k_rank1, one sample per block)
         int blocks = 0;
         for (int j = 0; j < a.njobs; ++j) {
             ConvJob& J = a.job[j];
@@ -708,7 +708,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         S3D_HIP(hipGetLastError());
         return 0;
     }
-    // two samples per block from batch 2 on (S3D_RANK1_BATCH=0: one): same sums per sample, the weight tiles staged half as often
+    // other widths: k_rank1, two samples per block from batch 2 on (S3D_RANK1_BATCH=0: one): same sums per sample, the weight tiles staged half as often
     static const bool pair_ok = !(getenv("S3D_RANK1_BATCH") && atoi(getenv("S3D_RANK1_BATCH")) == 0);
     const int ns = roll3 && pair_ok && a.B >= 2 ? 2 : 1;
     int blocks = 0;

@@ -138,7 +138,7 @@ R1_CASES = [(32, 2, (10, 14, 6)), (64, 3, (40, 24, 56)), (128, 2, (64, 48, 32)),
             (128, 3, (96, 80, 64))]      # the last two have more 8x16-pixel tiles than co-resident blocks
 
 
-def _r1_forward(mc, B, hwd, seed):
+def _r1_forward(mc, B, hwd, seed, rank1_name=False):
     H, W, D = hwd
     model = make_model(mc)
     x = cu(T.synthetic_noise((B, 12, H + D, W + D), seed))
@@ -148,6 +148,8 @@ def _r1_forward(mc, B, hwd, seed):
         ys = [model(x, t, H=H, W=W, D=D) for _ in range(3)]
     model.profile_read()
     assert all(torch.equal(ys[0], y) for y in ys[1:])
+    if rank1_name:
+        return ys[0].cpu().numpy(), model.profile_kernel(0), model.profile_kernel(2)
     return ys[0].cpu().numpy(), model.profile_kernel(0)
 
 
@@ -209,29 +211,31 @@ def test_groupnorm_statistics_forms_are_bit_identical(tmp_path):
         assert np.array_equal(y, a), (mc, B, hwd)
 
 
-def test_rank1_sample_pairs_are_bit_identical(tmp_path):
-    """Batch >= 2: the rollout tables (unet_triplane.py:37-58) come from the batched forms — k_rank1b when the own channels are
-    whole 128-channel chunks (fragment-order weights straight into registers, 32 positions x 32 output channels x 3 taps per
-    block, XCD-local weight reuse; s3d_conv.hip), otherwise k_rank1 with TWO samples per staged weight tile (s3d_rank1.h, NS = 2;
-    an odd batch leaves a one-sample block).  Each sample's sums are formed in the same order as in the batch-1 kernel: the
-    default against S3D_RANK1_BATCH=0 (one sample per k_rank1 block) in a separate process, K slices on in both, bit for bit."""
+def test_rank1_forms_are_bit_identical(tmp_path):
+    """The rollout tables (unet_triplane.py:37-58) come from k_rank1b when the own channels are whole 128-channel chunks
+    (fragment-order weights straight into a register ring, 32 positions x 32 output channels x 3 taps per block, XCD-local weight
+    reuse; s3d_conv.hip), otherwise from k_rank1 — with TWO samples per staged weight tile from batch 2 on (s3d_rank1.h, NS = 2;
+    an odd batch leaves a one-sample block).  Every form builds each sample's sums in the order of the plain kernel: the default
+    against S3D_RANK1_BATCH=0 (k_rank1, one sample per block, everywhere) in a separate process, K slices on in both, bit for bit;
+    the library reports which kernels built the tables."""
     import os, subprocess, sys
-    cases = [(i, c) for i, c in enumerate(R1_CASES) if c[1] >= 2]
     code = (
         "import numpy as np, sys\n"
         "sys.path.insert(0, 'tests')\n"
         "import test_hip_parity as tp\n"
         "for i, (mc, B, hwd) in enumerate(tp.R1_CASES):\n"
-        "    if B < 2: continue\n"
-        "    y, name = tp._r1_forward(mc, B, hwd, 110 + i)\n"
+        "    y, _, name = tp._r1_forward(mc, B, hwd, 110 + i, rank1_name=True)\n"
+        "    assert 'k_rank1<' in name, name\n"
         f"    np.save(r'{tmp_path}/one_' + str(i) + '.npy', y)\n"
         "print('ok')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_RANK1_BATCH="0"), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    for i, (mc, B, hwd) in cases:
-        y, _ = _r1_forward(mc, B, hwd, 110 + i)
+    for i, (mc, B, hwd) in enumerate(R1_CASES):
+        y, _, name = _r1_forward(mc, B, hwd, 110 + i, rank1_name=True)
+        # (a 64-channel UNet has one 128-channel level: both kernels; 32 channels: 32 / 64 / 96 own channels, k_rank1 only)
+        assert ("k_rank1b" in name) == (mc >= 64) and ("k_rank1<" in name) == (mc < 128), (mc, name)
         assert np.array_equal(y, np.load(f"{tmp_path}/one_{i}.npy")), (mc, B, hwd)
 
 
