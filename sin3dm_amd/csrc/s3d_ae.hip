@@ -133,12 +133,10 @@ static int ae_plan(s3d_ae* a) {
             if (l < 5) { N.mT[l] = palloc(size_t(I[l]) * O[l]); add(PK_TRANS2D, N.f_mw[l], N.mT[l], (long long)I[l] * O[l], O[l], 0, I[l]); }
         }
     }
-    int blocks = 0;
-    for (auto& d : a->descs) { d.block_begin = blocks; blocks += int((d.n + 255) / 256); }
-    a->pack_blocks = blocks; a->psize = ps;
+    a->psize = ps;
     S3D_TRY(a->pbuf.reserve(ps * sizeof(float)));
     S3D_HIP(hipMemset(a->pbuf.p, 0, ps * sizeof(float)));
-    S3D_TRY(upload(a->descs_dev, a->descs.data(), a->descs.size() * sizeof(PackDesc)));
+    S3D_TRY(finalize_pack_plan(a->descs, a->descs_dev, a->pack_blocks));
     return 0;
 }
 

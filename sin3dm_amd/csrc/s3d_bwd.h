@@ -1,6 +1,7 @@
 // s3d_bwd.h — launchers of the backward kernels (s3d_bwd.hip), used by the training driver (s3d_train.hip).
 #pragma once
 #include "s3d_common.h"
+#include <vector>
 
 namespace s3d {
 
@@ -29,7 +30,21 @@ struct WgradArgs {
 };
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps);
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps);
-int launch_wgrad(const WgradArgs& w, hipStream_t st);
+// The small tail launches of a convolution's backward — the split-K reduction of its weight gradient and the bias gradient from
+// the row sums — have no consumer inside the pass: a DeferredTail collects them (operands live in the pass's arena) and
+// flush() runs each kind as ONE launch over all collected jobs (same arithmetic per job: same bits).  A training step has
+// ten of each, 6-10 us of dependent-launch latency apiece.
+struct DeferredTail {
+    struct Red { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store, nplanes, wino; };
+    struct Bias { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
+    std::vector<Red> red;
+    std::vector<Bias> bias;
+    int flush(hipStream_t st);
+};
+// tail != null: the reduction launch is queued there instead of being enqueued behind the partial kernel
+int launch_wgrad(const WgradArgs& w, hipStream_t st, DeferredTail* tail = nullptr);
+int launch_bias_grad_deferred(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
+                              int per_sample_stride, DeferredTail& tail);
 
 struct GnActBwd {
     Tri x, dy, dx;

@@ -80,12 +80,12 @@ int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3]
 // emb_out when it is added to h, use_scale_shift_norm=False, src/diffusion/unet_triplane.py:298-303).
 struct BiasArgs { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
 constexpr int kBiasCh = 16, kBiasLanes = 1024 / kBiasCh;   // channels per block x row lanes (few channels: more blocks for a latency-bound sum)
-__global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
+__device__ __forceinline__ void bias_grad_block(const BiasArgs& a, int block) {
     // All (sample, plane) partial sums are accumulated first (independent loads in flight), then reduced over the lanes
     // through LDS in lane order, four samples at a time.
     __shared__ float sm[12][kBiasLanes][kBiasCh];
     __shared__ float sm2[12][kBiasCh];
-    const int cl = threadIdx.x % kBiasCh, lane = threadIdx.x / kBiasCh, co = blockIdx.x * kBiasCh + cl;
+    const int cl = threadIdx.x % kBiasCh, lane = threadIdx.x / kBiasCh, co = block * kBiasCh + cl;
     float tot_p[3] = {0.f, 0.f, 0.f};
     for (int b0 = 0; b0 < a.B; b0 += 4) {
         const int nb = min(4, a.B - b0);
@@ -129,6 +129,24 @@ __global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) {
     if (lane == 0 && co < a.C)
         for (int p = 0; p < 3; ++p)
             if (a.dbias[p]) a.dbias[p][co] = tot_p[p];
+}
+__global__ __launch_bounds__(1024) void k_bias_grad(BiasArgs a) { bias_grad_block(a, blockIdx.x); }
+// every queued job in one launch (DeferredTail): block -> (job, channel block) through a prefix table
+constexpr int kTailJobs = 12;
+struct BiasMultiArgs { BiasArgs job[kTailJobs]; int begin[kTailJobs + 1]; int njobs; };
+__global__ __launch_bounds__(1024) void k_bias_grad_multi(BiasMultiArgs m) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kTailJobs; ++k) j += (k < m.njobs && int(blockIdx.x) >= m.begin[k]) ? 1 : 0;
+    bias_grad_block(m.job[j], int(blockIdx.x) - m.begin[j]);
+}
+int launch_bias_grad_deferred(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
+                              int per_sample_stride, DeferredTail& tail) {
+    DeferredTail::Bias b;
+    for (int p = 0; p < 3; ++p) { b.R[p] = R[p]; b.dbias[p] = dbias ? dbias[p] : nullptr; b.h[p] = g.h[p]; }
+    b.per_sample = per_sample; b.per_sample_stride = per_sample_stride; b.B = B; b.C = C;
+    tail.bias.push_back(b);
+    return 0;
 }
 int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
                      int per_sample_stride, hipStream_t st) {
@@ -520,14 +538,13 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
 }
 // adds the slices' dg in slice order and scatters to OIHW
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
-__global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) {
+__device__ __forceinline__ void wgrad_wino_reduce_block(const WgwRedArgs& a, int bx, int p) {
     // block = 64 (co, ci) pairs x 4 slice lanes: lane j adds slices j, j+4, ..., the four sums meet through LDS in lane order
     // (one thread per pair over all slices left 48 blocks walking 64 x 16 dependent loads each: 24 us at 64 channels)
     __shared__ float red[3][9][64];
     const long long n = (long long)a.cout * a.cin;
     const int l = threadIdx.x & 63, kl = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + l;
-    const int p = blockIdx.y;
+    const long long idx = (long long)bx * 64 + l;
     float S[9];
 #pragma unroll
     for (int f = 0; f < 9; ++f) S[f] = 0.f;
@@ -547,18 +564,19 @@ __global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) {
 #pragma unroll
     for (int f = 0; f < 9; ++f) d[f] = ((S[f] + red[0][f][l]) + red[1][f][l]) + red[2][f][l];
 }
+__global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) { wgrad_wino_reduce_block(a, blockIdx.x, blockIdx.y); }
 static bool wgrad_use_wino() {
     static const bool on = !(getenv("S3D_WGRAD_WINO") && atoi(getenv("S3D_WGRAD_WINO")) == 0);
     return on;
 }
 
 struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
-__global__ __launch_bounds__(256) void k_wgrad_reduce(WgRedArgs a) {
+__device__ __forceinline__ void wgrad_reduce_block(const WgRedArgs& a, int bx, int p) {
     // block = 64 items x 4 slice lanes (lane j adds slices j, j+4, ...; the four sums meet through LDS in lane order)
     __shared__ float red[4][64];
     const long long n = (long long)a.cout * a.cin * a.taps;
-    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int p = blockIdx.y, kl = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long long idx = (long long)bx * 64 + (threadIdx.x & 63);
+    const int kl = threadIdx.x >> 6, l = threadIdx.x & 63;
     float s = 0.f;
     if (idx < n)
 #pragma unroll 4
@@ -571,6 +589,61 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(WgRedArgs a) {
     const long long r = idx / a.taps;
     const int ci = int(r % a.cin), co = int(r / a.cin);
     if (ci < a.cin_store) a.dW[p][(size_t(co) * a.ctot + ci) * a.taps + t] = s;
+}
+__global__ __launch_bounds__(256) void k_wgrad_reduce(WgRedArgs a) { wgrad_reduce_block(a, blockIdx.x, blockIdx.y); }
+// every queued reduction in one launch (DeferredTail): block -> (job, plane, item block) through a prefix table
+struct RedMultiJob { WgRedArgs r; int wino, bx, nplanes; };
+struct RedMultiArgs { RedMultiJob job[kTailJobs]; int begin[kTailJobs + 1]; int njobs; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedMultiArgs m) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < kTailJobs; ++k) j += (k < m.njobs && int(blockIdx.x) >= m.begin[k]) ? 1 : 0;
+    const RedMultiJob& J = m.job[j];
+    const int local = int(blockIdx.x) - m.begin[j], p = local / J.bx, bx = local - p * J.bx;
+    if (J.wino) {
+        WgwRedArgs w;
+        for (int q = 0; q < 3; ++q) { w.part[q] = J.r.part[q]; w.dW[q] = J.r.dW[q]; }
+        w.ksplit = J.r.ksplit; w.cout = J.r.cout; w.cin = J.r.cin; w.ctot = J.r.ctot; w.cin_store = J.r.cin_store;
+        wgrad_wino_reduce_block(w, bx, p);
+    } else wgrad_reduce_block(J.r, bx, p);
+}
+int DeferredTail::flush(hipStream_t st) {
+    for (size_t i0 = 0; i0 < red.size(); i0 += kTailJobs) {
+        RedMultiArgs m;
+        m.njobs = int(std::min(red.size() - i0, size_t(kTailJobs)));
+        int blocks = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            const Red& r = red[i0 + j];
+            RedMultiJob& J = m.job[j];
+            for (int p = 0; p < 3; ++p) { J.r.part[p] = r.part[p]; J.r.dW[p] = r.dW[p]; }
+            J.r.ksplit = r.ksplit; J.r.cout = r.cout; J.r.cin = r.cin; J.r.ctot = r.ctot; J.r.taps = r.taps; J.r.cin_store = r.cin_store;
+            J.wino = r.wino; J.nplanes = r.nplanes;
+            const long long n = (long long)r.cout * r.cin * (r.wino ? 1 : r.taps);
+            J.bx = int((n + 63) / 64);
+            m.begin[j] = blocks;
+            blocks += J.bx * r.nplanes;
+        }
+        m.begin[m.njobs] = blocks;
+        if (blocks) { hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, st, m); S3D_HIP(hipGetLastError()); }
+    }
+    red.clear();
+    for (size_t i0 = 0; i0 < bias.size(); i0 += kTailJobs) {
+        BiasMultiArgs m;
+        m.njobs = int(std::min(bias.size() - i0, size_t(kTailJobs)));
+        int blocks = 0;
+        for (int j = 0; j < m.njobs; ++j) {
+            const Bias& b = bias[i0 + j];
+            BiasArgs& a = m.job[j];
+            for (int p = 0; p < 3; ++p) { a.R[p] = b.R[p]; a.dbias[p] = b.dbias[p]; a.h[p] = b.h[p]; }
+            a.per_sample = b.per_sample; a.per_sample_stride = b.per_sample_stride; a.B = b.B; a.C = b.C;
+            m.begin[j] = blocks;
+            blocks += cdiv(b.C, kBiasCh);
+        }
+        m.begin[m.njobs] = blocks;
+        if (blocks) { hipLaunchKernelGGL(k_bias_grad_multi, dim3(blocks), dim3(1024), 0, st, m); S3D_HIP(hipGetLastError()); }
+    }
+    bias.clear();
+    return 0;
 }
 
 // 1x1: the 128 x 128 channel tile halves the staging traffic per flop, but a 64 -> 128 or 192 -> 64 skip convolution would
@@ -605,7 +678,14 @@ int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
 }
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps) { return size_t(ksplit) * cin * cout * taps; }
 
-int launch_wgrad(const WgradArgs& w, hipStream_t st) {
+static void queue_reduce(DeferredTail& tail, const WgradArgs& w, int wino) {
+    DeferredTail::Red r;
+    for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
+    r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.taps = w.taps;
+    r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin; r.nplanes = w.nplanes; r.wino = wino;
+    tail.red.push_back(r);
+}
+int launch_wgrad(const WgradArgs& w, hipStream_t st, DeferredTail* tail) {
     S3D_CHECK(w.taps == 9 || w.taps == 1 || w.taps == 25, S3D_ERR_INVALID, "wgrad: taps=%d", w.taps);
     S3D_CHECK(w.cin % 32 == 0 && w.cout % 32 == 0, S3D_ERR_INVALID, "wgrad: channels must be multiples of 32");
     if (w.taps == 9 && wgrad_use_wino()) {
@@ -624,6 +704,7 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
         if (!blocks || !w.B) return 0;
         hipLaunchKernelGGL(k_wgrad_wino, dim3(blocks), dim3(256), 0, st, a);
         S3D_HIP(hipGetLastError());
+        if (tail) { queue_reduce(*tail, w, 1); return 0; }
         WgwRedArgs r;
         for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
         r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.cin_store = w.cin_store > 0 ? w.cin_store : w.cin;
@@ -655,6 +736,7 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st) {
     else if (wide) hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 2>), dim3(blocks), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad_mfma<1, 1, 1>), dim3(blocks), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
+    if (tail) { queue_reduce(*tail, w, 0); return 0; }
     WgRedArgs r;
     for (int p = 0; p < 3; ++p) { r.part[p] = p < w.nplanes ? w.part[p] : nullptr; r.dW[p] = p < w.nplanes ? w.dW[p] : nullptr; }
     r.ksplit = w.ksplit; r.cout = w.cout; r.cin = w.cin; r.ctot = w.ctot; r.taps = w.taps;
@@ -682,6 +764,7 @@ struct GnBwdArgs {
     const float* mr; const float* film; int film_stride;
     float* part;                                          // [B][3][nchunk][C][2]
     const float* coef;                                    // [B][3][C][8]: per-channel constants of the apply pass (k_gn_bwd_coefs)
+    const float* A; float* dgamma[3]; float* dbeta[3]; float* dfilm;   // the apply launch's extra blocks: parameter / FiLM gradients from A[b][p][c][2]
     int h[3], w[3];
     int C, cq, pl, B, nchunk, ngroups;
 };
@@ -763,30 +846,33 @@ struct GnBwdFinArgs {
     double count[3];
     int C, B, nchunk, ngroups;
 };
-__global__ void k_gn_bwd_sum(GnBwdFinArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // over B*3*C
-    if (idx >= a.B * 3 * a.C) return;
-    const int ch = idx % a.C, bp = idx / a.C;
-    double s1 = 0, s2 = 0;
-#pragma unroll 8
-    for (int k = 0; k < a.nchunk; ++k) {
-        const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * a.C + ch) * 2);
-        s1 += q.x; s2 += q.y;
-    }
-    a.A[size_t(idx) * 2] = float(s1); a.A[size_t(idx) * 2 + 1] = float(s2);
-}
-// (measured: folding k_gn_bwd_sum into this single block costs 16.5 us against 5.0 + 6.3 for the two launches)
-__global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
+// One block per (sample, plane): A[c] = the chunk partials added in chunk order (double), then the group coefficients of the
+// apply pass.  (One launch: the sums used to be a launch of their own ahead of a single-block coefficient kernel — 5.0 + 6.3 us
+// of dependent launches per GroupNorm, ten per training step; folding the sums into that single block cost 16.5 us.)  The
+// parameter and FiLM gradients, which add A over samples / planes, moved into extra blocks of the apply launch.
+__global__ __launch_bounds__(256) void k_gn_bwd_fin(GnBwdFinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sA[];          // [C][2]
     const int C = a.C, G = a.ngroups, cg = C / G;
-    // (1) group coefficients
-    for (int idx = threadIdx.x; idx < a.B * 3 * G; idx += blockDim.x) {
-        const int g = idx % G, bp = idx / G, b = bp / 3, p = bp % 3;
+    const int bp = blockIdx.x, b = bp / 3, p = bp % 3;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        double s1 = 0, s2 = 0;
+#pragma unroll 8
+        for (int k = 0; k < a.nchunk; ++k) {
+            const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * C + ch) * 2);
+            s1 += q.x; s2 += q.y;
+        }
+        const float f1 = float(s1), f2 = float(s2);
+        a.A[(size_t(bp) * C + ch) * 2] = f1; a.A[(size_t(bp) * C + ch) * 2 + 1] = f2;
+        sA[2 * ch] = f1; sA[2 * ch + 1] = f2;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
         double g1 = 0, g2 = 0;
         for (int k = 0; k < cg; ++k) {
             const int ch = g * cg + k;
             const double sc = a.film ? 1.0 + a.film[size_t(b) * a.film_stride + ch] : 1.0;
             const double gg = double(a.gamma[p][ch]) * sc;
-            g1 += gg * a.A[(size_t(bp) * C + ch) * 2]; g2 += gg * a.A[(size_t(bp) * C + ch) * 2 + 1];
+            g1 += gg * sA[2 * ch]; g2 += gg * sA[2 * ch + 1];
         }
         // per-channel constants of the apply pass, 8 floats per channel:
         //   xh = x*c0 + c1 ; z = xh*c2 + c3 ; dx = dz*c4 - c5 - xh*c6        (c7 unused)
@@ -802,25 +888,27 @@ __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
             o[4] = rstd * gam * sc; o[5] = rstd * k1; o[6] = rstd * k2; o[7] = 0.f;
         }
     }
-    // (2) dgamma / dbeta (sum over the batch)
-    for (int idx = threadIdx.x; idx < 3 * C; idx += blockDim.x) {
-        const int ch = idx % C, p = idx / C;
-        double dg = 0, db = 0;
-        for (int b = 0; b < a.B; ++b) {
-            const double sc = a.film ? 1.0 + a.film[size_t(b) * a.film_stride + ch] : 1.0;
-            const float* A = a.A + ((size_t(b) * 3 + p) * C + ch) * 2;
-            db += sc * A[0]; dg += sc * A[1];
+}
+// extra block (plane p, sample b) of the apply launch: dgamma / dbeta of plane p (sum over the batch; b == 0 only) and the FiLM
+// gradients of sample b (sum over the planes, which share emb_out; p == 0 only)
+__device__ __forceinline__ void gn_bwd_param_grads(const GnBwdArgs& a, int p, int b) {
+    const int C = a.C;
+    if (b == 0)
+        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+            double dg = 0, db = 0;
+            for (int bb = 0; bb < a.B; ++bb) {
+                const double sc = a.film ? 1.0 + a.film[size_t(bb) * a.film_stride + ch] : 1.0;
+                const float* A = a.A + ((size_t(bb) * 3 + p) * C + ch) * 2;
+                db += sc * A[0]; dg += sc * A[1];
+            }
+            a.dgamma[p][ch] = float(dg); a.dbeta[p][ch] = float(db);
         }
-        a.dgamma[p][ch] = float(dg); a.dbeta[p][ch] = float(db);
-    }
-    // (3) FiLM gradients (sum over the planes: the three planes share emb_out)
-    if (a.dfilm)
-        for (int idx = threadIdx.x; idx < a.B * C; idx += blockDim.x) {
-            const int ch = idx % C, b = idx / C;
+    if (p == 0 && a.dfilm)
+        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
             double ds = 0, dh = 0;
-            for (int p = 0; p < 3; ++p) {
-                const float* A = a.A + ((size_t(b) * 3 + p) * C + ch) * 2;
-                ds += double(a.gamma[p][ch]) * A[1] + double(a.beta[p][ch]) * A[0];
+            for (int pp = 0; pp < 3; ++pp) {
+                const float* A = a.A + ((size_t(b) * 3 + pp) * C + ch) * 2;
+                ds += double(a.gamma[pp][ch]) * A[1] + double(a.beta[pp][ch]) * A[0];
                 dh += A[0];
             }
             a.dfilm[size_t(b) * a.film_stride + ch] = float(ds);
@@ -831,6 +919,7 @@ __global__ void k_gn_bwd_coefs(GnBwdFinArgs a) {
 // registers and four pixels are in flight per trip
 __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, int nchunk) {
     const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    if (chunk == nchunk) { gn_bwd_param_grads(a, p, b); return; }
     const int w = a.w[p], h = a.h[p];
     const int npix = h * w;
     const int p0 = int((long long)npix * chunk / nchunk), p1 = int((long long)npix * (chunk + 1) / nchunk);
@@ -905,14 +994,14 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
         f.count[p] = double(x.C / s.ngroups) * x.g.h[p] * x.g.w[p];
     }
     f.C = x.C; f.B = s.B; f.nchunk = kGnBwdChunks; f.ngroups = s.ngroups;
-    hipLaunchKernelGGL(k_gn_bwd_sum, dim3(cdiv(s.B * 3 * x.C, 256)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(k_gn_bwd_fin, dim3(s.B * 3), dim3(256), size_t(x.C) * 2 * sizeof(float), st, f);
     S3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_gn_bwd_coefs, dim3(1), dim3(1024), 0, st, f);
-    S3D_HIP(hipGetLastError());
+    a.A = A; a.dfilm = s.dfilm;
+    for (int p = 0; p < 3; ++p) { a.dgamma[p] = s.dgamma[p]; a.dbeta[p] = s.dbeta[p]; }
     long long maxpix = 0;
     for (int p = 0; p < 3; ++p) maxpix = std::max(maxpix, (long long)x.g.h[p] * x.g.w[p]);
     const int nchunk = int(std::max(1LL, (maxpix + a.pl * 8 - 1) / (a.pl * 8)));          // two trips of four pixels per thread
-    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(nchunk, 3, s.B), dim3(a.cq * a.pl), 0, st, a, nchunk);
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(nchunk + 1, 3, s.B), dim3(a.cq * a.pl), 0, st, a, nchunk);   // (+1: the parameter-gradient blocks)
     S3D_HIP(hipGetLastError());
     return 0;
 }

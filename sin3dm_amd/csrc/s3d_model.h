@@ -168,6 +168,7 @@ struct s3d_unet {
 namespace s3d {
 
 int pack_all(s3d_unet* m);
+int finalize_pack_plan(std::vector<PackDesc>& descs, DevBuf& dev, int& blocks_out);   // block prefix + per-block job table, uploaded
 int launch_repack_generic(const PackDesc* descs_dev, int ndesc, int blocks, const float* flat, float* wbuf, float* tbuf, hipStream_t st);
 // ext_film != null: the FiLM table [B or 1][film_total] is given (s3d_unet_film), t is not read
 // fuse != null: one denoising step — the sampler update is applied to the model output by the output head; `out` may then be

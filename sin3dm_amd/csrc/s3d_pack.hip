@@ -11,17 +11,12 @@ namespace s3d {
 
 
 
-__global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ descs, int ndesc, const float* __restrict__ flat,
-                                                float* __restrict__ wbuf, float* __restrict__ tbuf) {
-    // find this block's job (descs are sorted by block_begin)
-    int lo = 0, hi = ndesc - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_begin <= int(blockIdx.x)) lo = mid; else hi = mid - 1;
-    }
-    const PackDesc d = descs[lo];
-    const long long i = (long long)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
-    if (i >= d.n) return;
+// a launch is ~10^7 items: 1024 per block (four per thread) and the block's job from a per-block table — with 256-item blocks
+// that each binary-searched the job list (nine dependent loads) the launch was 32 rounds of blocks waiting on that chain:
+// 90 us per training step (profiles/r04_train_step.txt)
+constexpr int kPackItems = 1024;
+__device__ __forceinline__ void repack_item(const PackDesc& d, long long i, const float* __restrict__ flat, float* __restrict__ wbuf,
+                                            float* __restrict__ tbuf) {
     const float* W = flat + d.src;
     float* dst = (d.to_tbuf ? tbuf : wbuf) + d.dst;
     const int cout = d.cout, ctot = d.ctot, cin = d.cin, taps = d.taps;
@@ -144,6 +139,35 @@ __global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ des
         }
     }
 }
+__global__ __launch_bounds__(256) void k_repack(const PackDesc* __restrict__ descs, int ndesc, const float* __restrict__ flat,
+                                                float* __restrict__ wbuf, float* __restrict__ tbuf) {
+    const int* block_desc = reinterpret_cast<const int*>(descs + ndesc);      // (finalize_pack_plan: the table sits behind the jobs)
+    const PackDesc d = descs[block_desc[blockIdx.x]];
+    const long long i0 = (long long)(int(blockIdx.x) - d.block_begin) * kPackItems + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < kPackItems / 256; ++u) {
+        const long long i = i0 + u * 256;
+        if (i < d.n) repack_item(d, i, flat, wbuf, tbuf);
+    }
+}
+// block prefix + per-block job table, uploaded behind the job list
+int finalize_pack_plan(std::vector<PackDesc>& descs, DevBuf& dev, int& blocks_out) {
+    int blocks = 0;
+    std::vector<int> table;
+    for (size_t i = 0; i < descs.size(); ++i) {
+        PackDesc& d = descs[i];
+        d.block_begin = blocks;
+        const int nb = int((d.n + kPackItems - 1) / kPackItems);
+        table.insert(table.end(), nb, int(i));
+        blocks += nb;
+    }
+    std::vector<char> img(descs.size() * sizeof(PackDesc) + table.size() * sizeof(int));
+    memcpy(img.data(), descs.data(), descs.size() * sizeof(PackDesc));
+    memcpy(img.data() + descs.size() * sizeof(PackDesc), table.data(), table.size() * sizeof(int));
+    S3D_TRY(upload(dev, img.data(), img.size()));
+    blocks_out = blocks;
+    return 0;
+}
 
 namespace {
 
@@ -263,16 +287,10 @@ int build_pack_plan(s3d_unet* m) {
             P.add(PK_COPY, P.flat_of(std::string("out.2.conv_") + kP[p] + ".bias"), m->out_b + size_t(p) * co, co);
         }
     }
-    int blocks = 0;
-    for (auto& d : m->descs) {
-        S3D_CHECK(d.src >= 0 && d.src < m->flat_numel, S3D_ERR_INVALID, "build_pack_plan: unresolved parameter");
-        d.block_begin = blocks;
-        blocks += int((d.n + 255) / 256);
-    }
-    m->pack_blocks = blocks;
+    for (auto& d : m->descs) S3D_CHECK(d.src >= 0 && d.src < m->flat_numel, S3D_ERR_INVALID, "build_pack_plan: unresolved parameter");
     S3D_TRY(m->tbuf.reserve(std::max<size_t>(P.tsize, 64) * sizeof(float)));
     S3D_HIP(hipMemset(m->tbuf.p, 0, P.tsize * sizeof(float)));       // the Winograd images are zero-padded to 32 outputs
-    S3D_TRY(upload(m->descs_dev, m->descs.data(), m->descs.size() * sizeof(PackDesc)));
+    S3D_TRY(finalize_pack_plan(m->descs, m->descs_dev, m->pack_blocks));
     return 0;
 }
 

@@ -19,6 +19,7 @@ struct Bwd {
     hipStream_t st;
     float* grads;                 // flat, same layout as the parameters
     float* dfilm = nullptr;       // [B][film_total]
+    DeferredTail tail;            // the pass's split-K reductions and bias gradients, run in batches (before each progress mark)
     Arena& ar() { return m->arena; }
     bool meas() { return m->arena.measuring; }
 
@@ -72,7 +73,7 @@ struct Bwd {
         }
         if (!meas()) {
             S3D_TRY(launch_edge_sums(dy, B, R, Cs, st));
-            S3D_TRY(launch_bias_grad(R, g, cout, B, dbias, per_sample_bias, m->film_total, st));
+            S3D_TRY(launch_bias_grad_deferred(R, g, cout, B, dbias, per_sample_bias, m->film_total, tail));
         }
         if (roll) {
             const MeanVecs& mv = nt->mv;
@@ -116,7 +117,7 @@ struct Bwd {
             w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps));
             w.dW[p] = dW[p];
         }
-        if (!meas()) S3D_TRY(launch_wgrad(w, st));
+        if (!meas()) S3D_TRY(launch_wgrad(w, st, &tail));
         return 0;
     }
 
@@ -224,6 +225,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         d_h = d_prev;
     }
 
+    if (!meas) S3D_TRY(b.tail.flush(st));             // (the output blocks' weight / bias gradients are final at mark 0)
     if (!meas && n_marks > 0 && marks[0]) S3D_HIP(hipEventRecord(marks[0], st));
 
     // ---- input blocks, deepest to first
@@ -261,6 +263,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         }
     }
 
+    if (!meas) S3D_TRY(b.tail.flush(st));             // (... the input blocks' at mark 1; the per-sample bias sums feed the timestep MLP below)
     if (!meas && n_marks > 1 && marks[1]) S3D_HIP(hipEventRecord(marks[1], st));
 
     // ---- timestep MLP: film = Lf(silu(emb)), emb = L2(silu(pre1)), pre1 = L0(temb(t))
