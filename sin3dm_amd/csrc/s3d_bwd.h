@@ -80,6 +80,10 @@ int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out
 int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
                       float* db, float* dx, hipStream_t st);
 
+// dW / db of nseg linears on one input whose dy rows are the column ranges [seg_begin[k], seg_begin[k+1]) of one matrix (contiguous, from 0)
+int launch_linear_bwd_w_multi(const float* dy, int dy_stride, const float* in, int B, int I, int in_mode, int nseg, const int* seg_begin,
+                              float* const* dW, float* const* db, hipStream_t st);
+
 int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
                     float* xt, hipStream_t st);
 constexpr int kMseWsFloats = 3 * 32;     // per sample

@@ -277,8 +277,23 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
                 return launch_linear_bwd(b.dfilm + rb.film_off, m->film_total, T.emb, B, ted, nullptr, eo, 1,
                                          b.G(rb.prefix + ".emb_layers.1.weight"), b.G(rb.prefix + ".emb_layers.1.bias"), nullptr, st);
             };
-            for (auto& rb : m->in_blocks) S3D_TRY(film_w(rb));
-            for (auto& rb : m->out_blocks) S3D_TRY(film_w(rb));
+            // one launch for all of them when the blocks' FiLM rows tile [0, film_total) in order (they do: build_specs)
+            std::vector<const ResBlockW*> rbs;
+            for (auto& rb : m->in_blocks) rbs.push_back(&rb);
+            for (auto& rb : m->out_blocks) rbs.push_back(&rb);
+            std::vector<int> seg; std::vector<float*> gw, gb;
+            bool tiled = rbs.size() <= 16;
+            int at = 0;
+            for (auto* rb : rbs) {
+                tiled = tiled && rb->film_off == at;
+                seg.push_back(at); at += ssn ? 2 * rb->Cout : rb->Cout;
+                gw.push_back(b.G(rb->prefix + ".emb_layers.1.weight")); gb.push_back(b.G(rb->prefix + ".emb_layers.1.bias"));
+            }
+            seg.push_back(at);
+            if (tiled && at == m->film_total)
+                S3D_TRY(launch_linear_bwd_w_multi(b.dfilm, m->film_total, T.emb, B, ted, 1, int(rbs.size()), seg.data(), gw.data(), gb.data(), st));
+            else
+                for (auto* rb : rbs) S3D_TRY(film_w(*rb));
             S3D_TRY(launch_linear_bwd(b.dfilm, m->film_total, T.emb, B, ted, m->dev(m->film_w), m->film_total, 1, nullptr, nullptr, d_emb, st));
             S3D_TRY(launch_linear_bwd(d_emb, ted, T.pre1, B, ted, m->dev(m->te2_w), ted, 1, b.G("time_embed.2.weight"),
                                       b.G("time_embed.2.bias"), d_pre1, st));
