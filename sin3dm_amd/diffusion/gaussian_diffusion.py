@@ -261,7 +261,10 @@ class GaussianDiffusion:
         return {"sample": sample, "pred_xstart": pred}
 
     # ------------------------------------------------------------------ loops
-    _NOISE_AHEAD_BYTES = 256 << 20      # eps of this many bytes' worth of steps is drawn by ONE randn launch
+    # eps of this many bytes' worth of steps is drawn by ONE randn launch: 15 steps at 128^3 (a launch's fixed ~5 us spread over
+    # them; the 85-step draws of a 256-MB buffer were a 100-us stall every 85 steps — 5 us/step in any 20-step timing window
+    # that happened to contain one, profiles/r04_bench_driver_flags.json)
+    _NOISE_AHEAD_BYTES = 48 << 20
 
     def _loop(self, mode, model, shape, noise, device, progress, clip_denoised=True, denoised_fn=None, cond_fn=None,
               model_kwargs=None, **kw):
