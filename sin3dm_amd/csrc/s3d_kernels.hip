@@ -1320,11 +1320,10 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
     }
 }
 static bool out_head_px_form(int C, int Cout) { return (C == 64 || C == 128 || C == 256) && Cout <= 16; }      // (other widths: k_out_head)
-// The in-head sampler update pays at batch 1, where the step is a chain of launch-bound kernels (head + sampler kernel + their
-// launch gap 23 -> 20 us at 128^3); from batch 2 on the launches are bandwidth-bound and the head's 256-byte row segments
-// (64 pixels of one channel) move the four extra tensors at half the rate of k_sampler's linear sweep (batch 8: 172 us fused
-// against 82 + 35) — there the head writes the model output to the workspace and the stand-alone kernel follows.
-bool out_head_fuses_sampler(int C, int Cout, int B) { return out_head_px_form(C, Cout) && B == 1; }
+// The in-head sampler update: head + sampler kernel + their launch gap 23 -> 20 us at 128^3, batch 1.  Until the head's weight
+// rows stopped being fetched inside the contraction (round 4) it lost from batch 2 on (batch 8: 172 us fused against 82 + 35);
+// now it wins there too (config 3: 5.173 -> 5.160 ms/step) and is taken at every batch.
+bool out_head_fuses_sampler(int C, int Cout, int B) { (void)B; return out_head_px_form(C, Cout); }
 bool out_head_px_takes(int C, int Cout) { return out_head_px_form(C, Cout); }
 // fuse != null: the sampler update of one denoising step is applied to the model output (fuse->model_out is ignored).  When
 // the pixel-chunk form takes the launch it happens in the same kernel and `out` may be null (the model output is then never
