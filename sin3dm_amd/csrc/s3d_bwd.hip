@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
 }
 // adds the slices' dg in slice order and scatters to OIHW
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
-__device__ __forceinline__ void wgrad_wino_reduce_block(const WgwRedArgs& a, int bx, int p) {
+template <class Args>                                    // WgwRedArgs, or the WgRedArgs of a batched job (same fields)
+__device__ __forceinline__ void wgrad_wino_reduce_block(const Args& a, int bx, int p) {
     // block = 64 (co, ci) pairs x 4 slice lanes: lane j adds slices j, j+4, ..., the four sums meet through LDS in lane order
     // (one thread per pair over all slices left 48 blocks walking 64 x 16 dependent loads each: 24 us at 64 channels)
     __shared__ float red[3][9][64];
@@ -600,12 +601,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedMultiArgs m) {
     for (int k = 1; k < kTailJobs; ++k) j += (k < m.njobs && int(blockIdx.x) >= m.begin[k]) ? 1 : 0;
     const RedMultiJob& J = m.job[j];
     const int local = int(blockIdx.x) - m.begin[j], p = local / J.bx, bx = local - p * J.bx;
-    if (J.wino) {
-        WgwRedArgs w;
-        for (int q = 0; q < 3; ++q) { w.part[q] = J.r.part[q]; w.dW[q] = J.r.dW[q]; }
-        w.ksplit = J.r.ksplit; w.cout = J.r.cout; w.cin = J.r.cin; w.ctot = J.r.ctot; w.cin_store = J.r.cin_store;
-        wgrad_wino_reduce_block(w, bx, p);
-    } else wgrad_reduce_block(J.r, bx, p);
+    if (J.wino) wgrad_wino_reduce_block(J.r, bx, p);
+    else wgrad_reduce_block(J.r, bx, p);
 }
 int DeferredTail::flush(hipStream_t st) {
     for (size_t i0 = 0; i0 < red.size(); i0 += kTailJobs) {

@@ -557,7 +557,7 @@ struct GnActArgs {
     GnPartSrc ps;
     float* mr_out;            // ... and block 0 of each (plane, sample) also leaves {mean, rstd} [B][3][32][2] (the training tape)
 };
-__global__ void k_gn_act(GnActArgs a) {
+__global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);           // [64] stats, then [pl][kActRows][C] row sums
     const int p = blockIdx.y, b = blockIdx.z;
@@ -676,7 +676,7 @@ int launch_gn_act(const Tri& x, int B, GnStats stats, const ActArgs& aa, Tri& y,
     a.mr = stats.mr; a.film = aa.film; a.film_stride = aa.film_stride;
     a.C = x.C; thread_shape(x.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
     a.pl = std::min(a.pl, kActCols);          // a pixel lane per tile column at most (64 channels: 16 lanes left half the block idle)
-    S3D_CHECK(x.C % 32 == 0 && a.cq <= 1024, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
+    S3D_CHECK(x.C % 32 == 0 && a.cq * a.pl <= 256, S3D_ERR_INVALID, "GroupNorm(32, C): C=%d unsupported", x.C);
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
     if (a.ps.part) shm = std::max(shm, size_t(a.cq) * a.pl * 2 * sizeof(double) + 64 * sizeof(float));
@@ -692,7 +692,9 @@ struct GnActCatArgs {
     const float* u[3]; const float* sk[3];
     int cuq, csq;
 };
-__global__ void k_gn_act_cat(GnActCatArgs ca) {
+// (__launch_bounds__: without one the compiler budgets for 1024-thread blocks — 128 VGPRs — and this kernel spilled 84 bytes per
+// thread into scratch inside its column loop: 38.5 us for 57 MB at 128^3.  Its blocks are 192-512 threads.)
+__global__ __launch_bounds__(512) void k_gn_act_cat(GnActCatArgs ca) {
     const GnActArgs& a = ca.base;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* sm = reinterpret_cast<float*>(smem_raw);
@@ -800,7 +802,7 @@ int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const A
     ca.cuq = u.C / 4; ca.csq = sk.C / 4;
     a.mr = stats.mr; a.film = aa.film; a.film_stride = aa.film_stride;
     a.C = y.C; thread_shape(y.C, a.cq, a.pl); a.with_means = mp ? 1 : 0;
-    S3D_CHECK(y.C == u.C + sk.C && y.C % 32 == 0 && a.cq <= 1024 && stats.mr, S3D_ERR_INVALID, "gn_act_cat: C=%d unsupported", y.C);
+    S3D_CHECK(y.C == u.C + sk.C && y.C % 32 == 0 && a.cq * a.pl <= 512 && stats.mr, S3D_ERR_INVALID, "gn_act_cat: C=%d unsupported", y.C);
     if (!maxtiles || !B) return 0;
     size_t shm = std::max(size_t(64) * sizeof(float), size_t(a.pl) * kActRows * a.C * sizeof(float));
     hipLaunchKernelGGL(k_gn_act_cat, dim3(maxtiles, 3, B), dim3(a.cq * a.pl), shm, st, ca);
