@@ -355,54 +355,56 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
         const int coc = co_ok ? co : 0;
         float base = p_bias ? p_bias[coc] : 0.f;
         if (p_bbias) base += p_bbias[size_t(b) * J.bbias_stride + coc];
-        float addv[MTW][16];
-        bool ok[MTW][16];
-        size_t oidx[MTW][16];
+        float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
+        // eight of the lane's sixteen pixel rows at a time: all sixteen (addends, flags and 64-bit output indices) cost 184
+        // VGPRs — two blocks per CU, 1.5 and 3 rounds of blocks for the 1x1 launches of the batch-1 step
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+        for (int rh = 0; rh < 2; ++rh) {
+            float addv[8];
+            bool ok[8];
+            unsigned oidx[8];                         // element index inside the sample's plane (< 2^32: checked by the launcher)
+            const size_t plane0 = size_t(b) * h * w * cout;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = rh * 8 + rr;
                 const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int y = ty0 + p / TW, x = tx0 + p % TW;
-                ok[mt][r] = y < h && x < w && co_ok;
-                oidx[mt][r] = ok[mt][r] ? ((img + y) * w + x) * cout + co : 0;
-                addv[mt][r] = base;
+                ok[rr] = y < h && x < w && co_ok;
+                oidx[rr] = ok[rr] ? unsigned(y * w + x) * unsigned(cout) + unsigned(co) : 0u;
+                addv[rr] = base;
             }
-        if (p_rcol) {
+            if (p_rcol) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rh * 8 + rr;
                     const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int y = ty0 + p / TW, x = tx0 + p % TW;
-                    const float t = p_rcol[ok[mt][r] ? ((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co : 0];
-                    addv[mt][r] += ok[mt][r] ? t : 0.f;
+                    const float t = p_rcol[ok[rr] ? ((size_t(b) * w + x) * 4 + edge_variant(y, h)) * cout + co : 0];
+                    addv[rr] += ok[rr] ? t : 0.f;
                 }
-        }
-        if (p_rrow) {
+            }
+            if (p_rrow) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rh * 8 + rr;
                     const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int y = ty0 + p / TW, x = tx0 + p % TW;
-                    const float t = p_rrow[ok[mt][r] ? ((img + y) * 4 + edge_variant(x, w)) * cout + co : 0];
-                    addv[mt][r] += ok[mt][r] ? t : 0.f;
+                    const float t = p_rrow[ok[rr] ? ((img + y) * 4 + edge_variant(x, w)) * cout + co : 0];
+                    addv[rr] += ok[rr] ? t : 0.f;
                 }
-        }
-        if (p_res && !J.res_up) {
+            }
+            if (p_res && !J.res_up) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+                for (int rr = 0; rr < 8; ++rr) addv[rr] += p_res[plane0 + oidx[rr]];      // index 0 when !ok: finite, unused
+            }
+            if (p_res && J.res_up) {                  // residual = exact-2x bilinear upsample of a half-resolution tensor (F.interpolate arithmetic)
+                const int hi = h >> 1, wi = w >> 1;
+                const float* rb = p_res + size_t(b) * hi * wi * cout + coc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) addv[mt][r] += p_res[oidx[mt][r]];      // index 0 when !ok: finite, unused
-        }
-        if (p_res && J.res_up) {                  // residual = exact-2x bilinear upsample of a half-resolution tensor (F.interpolate arithmetic)
-            const int hi = h >> 1, wi = w >> 1;
-            const float* rb = p_res + size_t(b) * hi * wi * cout + coc;
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rh * 8 + rr;
                     const int p = (wm * MTW + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     const int y = min(ty0 + p / TW, h - 1), x = min(tx0 + p % TW, w - 1);
                     float fy = 0.5f * (float(y) + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
@@ -413,24 +415,23 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                     const float ly1 = fy - float(y0), ly0 = 1.f - ly1, lx1 = fx - float(x0), lx0 = 1.f - lx1;
                     const float v00 = rb[(size_t(y0) * wi + x0) * cout], v01 = rb[(size_t(y0) * wi + x1) * cout];
                     const float v10 = rb[(size_t(y1) * wi + x0) * cout], v11 = rb[(size_t(y1) * wi + x1) * cout];
-                    addv[mt][r] += up2x_blend(ly0, ly1, lx0, lx1, v00, v01, v10, v11);
+                    addv[rr] += up2x_blend(ly0, ly1, lx0, lx1, v00, v01, v10, v11);
                 }
-        }
-        float gs = 0.f, gss = 0.f;                    // GroupNorm partial sums of this lane's channel
+            }
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = rh * 8 + rr;
                 float v = acc[0][mt][nt][r];
 #pragma unroll
                 for (int ks = 1; ks < KS; ++ks) v += acc[ks][mt][nt][r];
-                v += addv[mt][r];
+                v += addv[rr];
                 if (args.relu) v = fmaxf(v, 0.f);
-                if (ok[mt][r]) {
-                    p_out[oidx[mt][r]] = v;
+                if (ok[rr]) {
+                    p_out[plane0 + oidx[rr]] = v;
                     gs += v; gss = fmaf(v, v, gss);
                 }
             }
+        }
         if (p_gn) {
             // this wave's {sum, sumsq} per subgroup of sg consecutive channels: fold the two lane halves (the other
             // 16 pixel rows), then the sg channels; one part per (pixel tile, wave row) — see GnPartials
@@ -793,6 +794,7 @@ static int launch_cfg(ConvArgs& a, hipStream_t st) {
         J.n_tiles_n = (a.cout + CFG::BN - 1) / CFG::BN;
         J.block_begin = blocks;
         blocks += J.tiles_per_img * J.n_tiles_n * a.B;
+        S3D_CHECK((long long)J.h * J.w * a.cout < (1LL << 32), S3D_ERR_INVALID, "conv: a plane of one sample must stay below 2^32 elements");
     }
     if (!blocks) return 0;
     a.xcd_swizzle = 1;                       // XCD-aware block order (was switchable in rounds 1-2: always a win)
