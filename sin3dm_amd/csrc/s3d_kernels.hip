@@ -566,6 +566,27 @@ __global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
     if (int(blockIdx.x) >= ntc * ntr) return;
     const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
     const bool ident = a.mr == nullptr && a.ps.part == nullptr;
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    const int i0 = tr * kActRows, j0 = tc * kActCols;
+    const int i1 = min(h, i0 + kActRows), j1 = min(w, j0 + kActCols);
+    const float4* xs = reinterpret_cast<const float4*>(a.x[p] + size_t(b) * h * w * a.C) + q;
+    float4* ys = reinterpret_cast<float4*>(a.y[p] + size_t(b) * h * w * a.C) + q;
+    // the thread's first column of pixels and its channel quad's parameters are requested NOW: their round trip (the tensor
+    // was just written by another kernel: a miss all the way to memory) runs beside the statistics' (the same kind of miss)
+    // instead of behind them.  (Round 2 measured this slower — under the 128-VGPR budget the kernel then had, see __launch_bounds__.)
+    float4 xfirst[kActRows];
+    {
+        const int j = min(j0 + l, j1 - 1);
+#pragma unroll
+        for (int r = 0; r < kActRows; ++r) xfirst[r] = xs[(size_t(min(i0 + r, i1 - 1)) * w + j) * a.cq];
+    }
+    const bool film = a.film != nullptr;
+    float4 gam4 = make_float4(1, 1, 1, 1), bet4 = make_float4(0, 0, 0, 0), fsc4 = make_float4(0, 0, 0, 0), fsh4 = make_float4(0, 0, 0, 0);
+    if (!ident) { gam4 = reinterpret_cast<const float4*>(a.gamma[p])[q]; bet4 = reinterpret_cast<const float4*>(a.beta[p])[q]; }
+    if (film) {
+        fsc4 = reinterpret_cast<const float4*>(a.film + size_t(b) * a.film_stride)[q];
+        fsh4 = reinterpret_cast<const float4*>(a.film + size_t(b) * a.film_stride + a.C)[q];
+    }
     if (a.mr) {
         if (threadIdx.x < 32) {
             const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
@@ -575,31 +596,35 @@ __global__ __launch_bounds__(256) void k_gn_act(GnActArgs a) {
         sm = gn_stats_from_parts(a.ps, b, p, reinterpret_cast<double*>(smem_raw), a.mr_out && blockIdx.x == 0 ? a.mr_out : nullptr);
     }
     __syncthreads();
-    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
     const int cg = a.C / 32;
     float A[4], Bc[4], sc[4], sh[4];
-    const bool film = a.film != nullptr;
-    for (int k = 0; k < 4; ++k) {
-        const int c = 4 * q + k, g = c / cg;
-        const float scale = ident ? 1.0f : sm[32 + g] * a.gamma[p][c];
-        A[k] = scale;
-        Bc[k] = ident ? 0.0f : a.beta[p][c] - scale * sm[g];
-        sc[k] = film ? 1.0f + a.film[size_t(b) * a.film_stride + c] : 1.0f;
-        sh[k] = film ? a.film[size_t(b) * a.film_stride + a.C + c] : 0.0f;
+    {
+        const float gv[4] = {gam4.x, gam4.y, gam4.z, gam4.w}, bv[4] = {bet4.x, bet4.y, bet4.z, bet4.w};
+        const float s1[4] = {fsc4.x, fsc4.y, fsc4.z, fsc4.w}, s2[4] = {fsh4.x, fsh4.y, fsh4.z, fsh4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * q + k, g = c / cg;
+            const float scale = ident ? 1.0f : sm[32 + g] * gv[k];
+            A[k] = scale;
+            Bc[k] = ident ? 0.0f : bv[k] - scale * sm[g];
+            sc[k] = film ? 1.0f + s1[k] : 1.0f;
+            sh[k] = film ? s2[k] : 0.0f;
+        }
     }
     __syncthreads();                                            // stats region of sm is reused below
-    const int i0 = tr * kActRows, j0 = tc * kActCols;
-    const int i1 = min(h, i0 + kActRows), j1 = min(w, j0 + kActCols);
-    const float4* xs = reinterpret_cast<const float4*>(a.x[p] + size_t(b) * h * w * a.C) + q;
-    float4* ys = reinterpret_cast<float4*>(a.y[p] + size_t(b) * h * w * a.C) + q;
     float4 rowacc[kActRows];
 #pragma unroll
     for (int r = 0; r < kActRows; ++r) rowacc[r] = make_float4(0, 0, 0, 0);
     for (int j = j0 + l; j < j1; j += a.pl) {
         float4 colacc = make_float4(0, 0, 0, 0);
         float4 xin[kActRows];
+        if (j == j0 + l) {
 #pragma unroll
-        for (int r = 0; r < kActRows; ++r) xin[r] = xs[(size_t(min(i0 + r, i1 - 1)) * w + j) * a.cq];   // all loads first
+            for (int r = 0; r < kActRows; ++r) xin[r] = xfirst[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < kActRows; ++r) xin[r] = xs[(size_t(min(i0 + r, i1 - 1)) * w + j) * a.cq];   // all loads first
+        }
 #pragma unroll
         for (int r = 0; r < kActRows; ++r) {
             const int i = i0 + r;
