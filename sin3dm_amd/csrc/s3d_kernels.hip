@@ -728,26 +728,38 @@ __global__ __launch_bounds__(512) void k_gn_act_cat(GnActCatArgs ca) {
     const int ntc = (w + kActCols - 1) / kActCols, ntr = (h + kActRows - 1) / kActRows;
     if (int(blockIdx.x) >= ntc * ntr) return;
     const int tr = blockIdx.x / ntc, tc = blockIdx.x % ntc;
-    if (threadIdx.x < 32) {
-        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
-        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
-    }
-    __syncthreads();
     // threads of the upsampled half first (cuq quads x pl pixel lanes), then the skip half: with cuq a multiple of 64 every
     // wave runs one of the two load paths only
     const int nup = ca.cuq * a.pl;
     const int q = int(threadIdx.x) < nup ? int(threadIdx.x) % ca.cuq : ca.cuq + (int(threadIdx.x) - nup) % ca.csq;
     const int l = int(threadIdx.x) < nup ? int(threadIdx.x) / ca.cuq : (int(threadIdx.x) - nup) / ca.csq;
+    const bool film = a.film != nullptr;
+    // (the quad's parameters are requested beside the statistics, not behind them)
+    const float4 gam4 = reinterpret_cast<const float4*>(a.gamma[p])[q], bet4 = reinterpret_cast<const float4*>(a.beta[p])[q];
+    float4 fsc4 = make_float4(0, 0, 0, 0), fsh4 = make_float4(0, 0, 0, 0);
+    if (film) {
+        fsc4 = reinterpret_cast<const float4*>(a.film + size_t(b) * a.film_stride)[q];
+        fsh4 = reinterpret_cast<const float4*>(a.film + size_t(b) * a.film_stride + a.C)[q];
+    }
+    if (threadIdx.x < 32) {
+        const float* mr = a.mr + ((size_t(b) * 3 + p) * 32 + threadIdx.x) * 2;
+        sm[threadIdx.x] = mr[0]; sm[32 + threadIdx.x] = mr[1];
+    }
+    __syncthreads();
     const int cg = a.C / 32;
     float A[4], Bc[4], sc[4], sh[4];
-    const bool film = a.film != nullptr;
-    for (int k = 0; k < 4; ++k) {
-        const int c = 4 * q + k, g = c / cg;
-        const float scale = sm[32 + g] * a.gamma[p][c];
-        A[k] = scale;
-        Bc[k] = a.beta[p][c] - scale * sm[g];
-        sc[k] = film ? 1.0f + a.film[size_t(b) * a.film_stride + c] : 1.0f;
-        sh[k] = film ? a.film[size_t(b) * a.film_stride + a.C + c] : 0.0f;
+    {
+        const float gv[4] = {gam4.x, gam4.y, gam4.z, gam4.w}, bv[4] = {bet4.x, bet4.y, bet4.z, bet4.w};
+        const float s1[4] = {fsc4.x, fsc4.y, fsc4.z, fsc4.w}, s2[4] = {fsh4.x, fsh4.y, fsh4.z, fsh4.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * q + k, g = c / cg;
+            const float scale = sm[32 + g] * gv[k];
+            A[k] = scale;
+            Bc[k] = bv[k] - scale * sm[g];
+            sc[k] = film ? 1.0f + s1[k] : 1.0f;
+            sh[k] = film ? s2[k] : 0.0f;
+        }
     }
     __syncthreads();
     const int i0 = tr * kActRows, j0 = tc * kActCols;
