@@ -850,7 +850,7 @@ int launch_gn_act_cat(const Tri& u, const Tri& sk, int B, GnStats stats, const A
 // th.mean over one axis of the activated planes (src/diffusion/unet_triplane.py:38-46): add the tile partials
 // in index order and divide by the axis length.
 __global__ __launch_bounds__(256) void k_means_finalize(MeanFinArgs a) {
-    means_finalize_thread(a, blockIdx.y, blockIdx.z, int(blockIdx.x * 256 + threadIdx.x));
+    means_finalize_thread(a, blockIdx.y, blockIdx.z, int(blockIdx.x * 128 + threadIdx.x));
 }
 MeanFinArgs means_finalize_args(const Geo& g, int C, int B, const MeanPartials& mp, const MeanVecs& mv) {
     MeanFinArgs a;
@@ -869,8 +869,8 @@ int launch_means_finalize(const Geo& g, int C, int B, const MeanPartials& mp, Me
     int maxlen = 0;
     for (int v = 0; v < 6; ++v) maxlen = std::max(maxlen, a.len[v]);
     if (!maxlen || !B || !a.cq) return 0;
-    S3D_CHECK((long long)maxlen * a.cq * 4 < (1ll << 31), S3D_ERR_INVALID, "means_finalize: vector too long");
-    hipLaunchKernelGGL(k_means_finalize, dim3(cdiv(maxlen * a.cq * 4, 256), 6, B), dim3(256), 0, st, a);
+    S3D_CHECK((long long)maxlen * a.cq < (1ll << 31), S3D_ERR_INVALID, "means_finalize: vector too long");
+    hipLaunchKernelGGL(k_means_finalize, dim3(cdiv(maxlen * a.cq, 128), 6, B), dim3(128), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }

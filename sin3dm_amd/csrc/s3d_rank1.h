@@ -26,34 +26,34 @@ constexpr int kR1LdsFloats = (34 + 2 * 32) * kR1Ld;       // A tile (34 rows) + 
 // arithmetic is 32-bit on wave-uniform scalars and a lane's (up to four) partials are requested together (round 4: 5.0 -> see
 // profiles/r04_small_kernels.txt; sums and their order unchanged).
 __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, int v, int b, int gthread) {
-    const int i = gthread >> 2, part0 = gthread & 3;
+    // one thread per item, all of its partials requested together; the sums are formed as the four-lane form formed them —
+    // s_k = p_k + p_{k+4} + p_{k+8} + ... in order, then (s0 + s1) + (s2 + s3) — so the bits are those of every earlier round
+    const int i = gthread;
     const int len = a.len[v], nt = a.nt[v], cq = a.cq;
-    const bool live = i < len * cq;
-    const int ii = live ? i : 0;
-    const int pos = ii / cq, q = ii - pos * cq;
+    if (i >= len * cq) return;
+    const int pos = i / cq, q = i - pos * cq;
     const float4* src = reinterpret_cast<const float4*>(a.src[v]) + (size_t(b) * nt * len + pos) * cq + q;
     const size_t tstride = size_t(len) * cq;
-    float4 s = make_float4(0, 0, 0, 0);
-    for (int t0 = part0; t0 < nt; t0 += 16) {
-        float4 u[4];
+    float4 s[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int t = t0 + 4 * k;
-            u[k] = src[size_t(t < nt ? t : part0) * tstride];
-            if (t >= nt) u[k] = make_float4(0, 0, 0, 0);
+    for (int k = 0; k < 4; ++k) s[k] = make_float4(0, 0, 0, 0);
+    for (int t0 = 0; t0 < nt; t0 += 16) {
+        float4 u[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int t = t0 + k;
+            u[k] = src[size_t(t < nt ? t : 0) * tstride];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (t0 + 4 * k < nt) { s.x += u[k].x; s.y += u[k].y; s.z += u[k].z; s.w += u[k].w; }
+        for (int k = 0; k < 16; ++k)
+            if (t0 + k < nt) { float4& d = s[k & 3]; d.x += u[k].x; d.y += u[k].y; d.z += u[k].z; d.w += u[k].w; }
     }
-#pragma unroll
-    for (int off = 1; off <= 2; off <<= 1) {
-        s.x += __shfl_xor(s.x, off, 64); s.y += __shfl_xor(s.y, off, 64); s.z += __shfl_xor(s.z, off, 64); s.w += __shfl_xor(s.w, off, 64);
-    }
-    if (!live || part0 != 0) return;
+    float4 r;
+    r.x = (s[0].x + s[1].x) + (s[2].x + s[3].x); r.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+    r.z = (s[0].z + s[1].z) + (s[2].z + s[3].z); r.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
     const float inv = a.inv[v];
-    s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
-    reinterpret_cast<float4*>(a.dst[v])[(size_t(b) * len + pos) * cq + q] = s;
+    r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+    reinterpret_cast<float4*>(a.dst[v])[(size_t(b) * len + pos) * cq + q] = r;
 }
 
 // ------------------------------------------------------------------ stage B: rank-1 rollout tables (skinny GEMMs)
