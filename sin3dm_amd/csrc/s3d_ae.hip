@@ -120,8 +120,8 @@ static int ae_plan(s3d_ae* a) {
             const size_t win = N.f_in_w + size_t(p) * up * cin[k] * 25, wout = N.f_out_w + size_t(p) * up * up * 25, wsc = N.f_sc_w + size_t(p) * up * cin[k];
             N.in_dense[p] = palloc(size_t(25) * up * 32); add(PK_DENSE_PAD, win, N.in_dense[p], (long long)25 * up * cin[k], up, cin[k], cin[k], 25, 32);
             N.in_T[p] = palloc(size_t(25) * 32 * up);     add(PK_DENSE_T_PAD, win, N.in_T[p], (long long)25 * up * cin[k], up, cin[k], cin[k], 25, 32);
-            N.out_dense[p] = palloc(size_t(25) * up * up); add(PK_DENSE, wout, N.out_dense[p], (long long)25 * up * up, up, up, up, 25);
-            N.out_T[p] = palloc(size_t(25) * up * up);    add(PK_DENSE_T, wout, N.out_T[p], (long long)25 * up * up, up, up, up, 25);
+            N.out_dense[p] = palloc(size_t(25) * up * up); add(PK_DENSE, wout, N.out_dense[p], (long long)up * up, up, up, up, 25);
+            N.out_T[p] = palloc(size_t(25) * up * up);    add(PK_DENSE_T, wout, N.out_T[p], (long long)up * up, up, up, up, 25);
             N.sc_dense[p] = palloc(size_t(up) * 32);      add(PK_DENSE_PAD, wsc, N.sc_dense[p], (long long)up * cin[k], up, cin[k], cin[k], 1, 32);
             N.sc_T[p] = palloc(size_t(32) * up);          add(PK_DENSE_T_PAD, wsc, N.sc_T[p], (long long)up * cin[k], up, cin[k], cin[k], 1, 32);
         }

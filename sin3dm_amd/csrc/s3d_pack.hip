@@ -27,10 +27,13 @@ __device__ __forceinline__ void repack_item(const PackDesc& d, long long i, cons
             dst[i] = W[(size_t)o * cin + c];
             break;
         }
-        case PK_DENSE: {                         // dst [(t*cout + co)*cin + c]
-            const int c = int(i % cin); long long r = i / cin;
-            const int co = int(r % cout), t = int(r / cout);
-            dst[i] = W[((size_t)co * ctot + c) * taps + t];
+        // The tap-permuting kinds below take one (co, c) FILTER per item and move all its taps: the thread reads `taps`
+        // consecutive floats (a wave: one contiguous run) and every tap's store is coalesced across the wave.  (One item per
+        // element gathered its source with a stride of `taps` floats: nine times the bytes through L2 -> L1, the launch's bound.)
+        case PK_DENSE: {                         // dst [(t*cout + co)*cin + c]; item = (co, c), c fastest
+            const int c = int(i % cin), co = int(i / cin);
+            const float* src = W + ((size_t)co * ctot + c) * taps;
+            for (int t = 0; t < taps; ++t) dst[((size_t)t * cout + co) * cin + c] = src[t];
             break;
         }
         case PK_DENSE_SLICE: {                   // 1x1: dst [co*cin + c] = W[co][slot + c] (an input-channel slice, Fwd::resblock_cat)
@@ -38,10 +41,10 @@ __device__ __forceinline__ void repack_item(const PackDesc& d, long long i, cons
             dst[i] = W[(size_t)co * ctot + d.slot + c];
             break;
         }
-        case PK_DENSE_T: {                       // dst [(t*cin + c)*cout + co]: the dgrad operator as a forward conv
-            const int co = int(i % cout); long long r = i / cout;
-            const int c = int(r % cin), t = int(r / cin);
-            dst[i] = W[((size_t)co * ctot + c) * taps + (taps - 1 - t)];
+        case PK_DENSE_T: {                       // dst [(t*cin + c)*cout + co]: the dgrad operator as a forward conv; item = (c, co), co fastest
+            const int co = int(i % cout), c = int(i / cout);
+            const float* src = W + ((size_t)co * ctot + c) * taps;
+            for (int t = 0; t < taps; ++t) dst[((size_t)t * cin + c) * cout + co] = src[taps - 1 - t];
             break;
         }
         case PK_DENSE_PAD: {                     // like PK_DENSE with the input channels zero-padded to d.slot per row
@@ -85,56 +88,80 @@ __device__ __forceinline__ void repack_item(const PackDesc& d, long long i, cons
             break;
         }
         case PK_WINO24S_T:
-        case PK_WINO24S: {                       // item = one (n, k) filter: G2 g G4^T, fragment order [n32][k16][24][2][64][4]
-            // operator dims as in PK_WINO: forward N = cout, K = cin; transposed (dgrad) N = cin, K = cout, taps flipped
+        case PK_WINO24S: {                       // G2 g G4^T in the fragment order [n32][k16][24][2][64][4]
+            // operator dims as in PK_WINO: forward N = cout, K = cin; transposed (dgrad) N = cin, K = cout, taps flipped.
+            // item = one LANE of a fragment group: (16 outputs n) x (four input quads of one k16 step) — the thread transforms
+            // the four filters (n, k0 .. k0+3) and each of its 24 stores is one float4 of a 1-KB fragment the wave writes whole.
+            // (One filter per item scattered 24 four-byte stores each: the repack's bound after the tap-permuting kinds.)
             const bool tr = d.kind == PK_WINO24S_T;
-            const int K = tr ? cout : cin;
-            const int n = int(i / K), k = int(i % K);
-            double g[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q)
-                g[q] = tr ? double(W[((size_t)k * ctot + n) * 9 + (8 - q)]) : double(W[((size_t)n * ctot + k) * 9 + q]);
+            const int N = tr ? cin : cout, K = tr ? cout : cin;
+            const int lane = int(i & 63);
+            const long long blk = i >> 6;
+            const int k16n = K / 16, nblk = int(blk / k16n), k16 = int(blk % k16n);
+            const int n = nblk * 16 + (lane & 15), k0 = k16 * 16 + (lane >> 4) * 4;
+            if (n >= N) break;
             const double G2[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
             const double G4[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                                      {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
-            double t[4][3];
+            float out[24][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                double g[9];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) t[u][q] = G2[u][0] * g[0 * 3 + q] + G2[u][1] * g[1 * 3 + q] + G2[u][2] * g[2 * 3 + q];
-            const int nt = n >> 5, e = k & 3;
+                for (int q = 0; q < 9; ++q)
+                    g[q] = tr ? double(W[((size_t)k * ctot + n) * 9 + (8 - q)]) : double(W[((size_t)n * ctot + k) * 9 + q]);
+                double t[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int v = 0; v < 6; ++v) {
-                    const double uv = fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2]));       // as pack_wino24s_weights
-                    dst[(((((size_t)nt * (K / 16) + (k >> 4)) * 24 + (u * 6 + v)) * 2 + ((n >> 4) & 1)) * 64 + (((k >> 2) & 3) * 16 + (n & 15))) * 4 + e] = float(uv);
+                    for (int q = 0; q < 3; ++q) t[u][q] = G2[u][0] * g[0 * 3 + q] + G2[u][1] * g[1 * 3 + q] + G2[u][2] * g[2 * 3 + q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 6; ++v)
+                        out[u * 6 + v][e] = float(fma(t[u][0], G4[v][0], fma(t[u][1], G4[v][1], t[u][2] * G4[v][2])));       // as pack_wino24s_weights
+            }
+            float4* d4 = reinterpret_cast<float4*>(dst) + (((size_t)(nblk >> 1) * k16n + k16) * 24 * 2 + (nblk & 1)) * 64 + lane;
+#pragma unroll
+            for (int f = 0; f < 24; ++f) d4[(size_t)f * 2 * 64] = make_float4(out[f][0], out[f][1], out[f][2], out[f][3]);
+            break;
+        }
+        case PK_RANK1: {                         // item (co, c), c fastest: the nine (t, o) entries dst [(t*n3 + (co/8)*24 + o*8 + co%8)*cin + c], n3 = ceil(cout/8)*24
+            const int c = int(i % cin), co = int(i / cin);
+            const int n3 = (cout + 7) / 8 * 24;
+            const float* src = W + ((size_t)co * ctot + d.slot * cin + c) * 9;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
+                    dst[((size_t)t * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin + c] = src[kh * 3 + kw];
                 }
             break;
         }
-        case PK_RANK1: {                         // item (t, o, co, c) -> dst [(t*n3 + (co/8)*24 + o*8 + co%8)*cin + c], n3 = ceil(cout/8)*24
-            const int c = int(i % cin); long long r = i / cin;
-            const int co = int(r % cout); r /= cout;
-            const int o = int(r % 3), t = int(r / 3);
-            const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
-            const int n3 = (cout + 7) / 8 * 24;
-            dst[((size_t)t * n3 + (co / 8) * 24 + o * 8 + (co & 7)) * cin + c] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw];
+        case PK_RANK1F: {                        // the same entries in the fragment order of k_rank1b (rank1_frag_index)
+            const int c = int(i % cin), co = int(i / cin);
+            const float* src = W + ((size_t)co * ctot + d.slot * cin + c) * 9;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
+                    dst[rank1_frag_index(cin, t, o, co, c)] = src[kh * 3 + kw];
+                }
             break;
         }
-        case PK_RANK1F: {                        // the same items in the fragment order of k_rank1b (rank1_frag_index)
-            const int c = int(i % cin); long long r = i / cin;
-            const int co = int(r % cout); r /= cout;
-            const int o = int(r % 3), t = int(r / 3);
-            const int kh = d.col_varying ? o : t, kw = d.col_varying ? t : o;
-            dst[rank1_frag_index(cin, t, o, co, c)] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + kh * 3 + kw];
-            break;
-        }
-        case PK_RANK1_BWD: {                     // dst [(tap*cin + c)*(3*cout) + j*cout + co]
-            const int co = int(i % cout); long long r = i / cout;
-            const int j = int(r % 3); r /= 3;
-            const int c = int(r % cin), tap = int(r / cin);
-            const int dr = d.col_varying ? j : 2 - tap, dc = d.col_varying ? 2 - tap : j;
-            dst[i] = W[((size_t)co * ctot + d.slot * cin + c) * 9 + dr * 3 + dc];
+        case PK_RANK1_BWD: {                     // dst [(tap*cin + c)*(3*cout) + j*cout + co]; item = (c, co), co fastest
+            const int co = int(i % cout), c = int(i / cout);
+            const float* src = W + ((size_t)co * ctot + d.slot * cin + c) * 9;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int dr = d.col_varying ? j : 2 - tap, dc = d.col_varying ? 2 - tap : j;
+                    dst[((size_t)tap * cin + c) * (3 * cout) + j * cout + co] = src[dr * 3 + dc];
+                }
             break;
         }
     }
@@ -200,16 +227,17 @@ struct Plan {
         for (int p = 0; p < 3; ++p) {
             const size_t w = flat_of(prefix + ".conv_" + kP[p] + ".weight");
             add(PK_COPY, flat_of(prefix + ".conv_" + kP[p] + ".bias"), cw.bias[p], cout);
-            add(PK_DENSE, w, cw.dense[p], (long long)taps * cout * cin, cout, ctot, cin, taps);
+            // the per-step repack writes only the images this process's kernels read (S3D_WINO / S3D_CONV_IMPL are fixed per
+            // process): with the mixed kernel active the F(2x2) images — and the dense [tap][cout][cin] images of the 3x3
+            // convolutions, which only the direct and the naive kernels read — would be rewritten for nobody
+            const bool fwd24 = k == 3 && cw.wino24s[p] && conv_wino24_channels(cin, cout);
+            const bool bwd24 = k == 3 && cw.wino24s[p] && cout % 32 == 0 && conv_wino24_channels(cout, cin);
+            if (!fwd24 || conv_use_naive()) add(PK_DENSE, w, cw.dense[p], (long long)cout * cin, cout, ctot, cin, taps);
             wt.dense_T[p] = talloc(size_t(taps) * cout * cin);
-            add(PK_DENSE_T, w, wt.dense_T[p], (long long)taps * cout * cin, cout, ctot, cin, taps, 0, 0, 1);
+            if (!bwd24 || conv_use_naive()) add(PK_DENSE_T, w, wt.dense_T[p], (long long)cout * cin, cout, ctot, cin, taps, 0, 0, 1);
             if (k == 3) {
-                // the per-step repack writes only the images this process's kernels read (S3D_WINO is fixed per process): with
-                // the mixed kernel active the F(2x2) images would be rewritten for nobody
-                const bool fwd24 = cw.wino24s[p] && conv_wino24_channels(cin, cout);
-                const bool bwd24 = cw.wino24s[p] && cout % 32 == 0 && conv_wino24_channels(cout, cin);
                 if (!fwd24) add(PK_WINO, w, cw.wino[p], (long long)cout * cin, cout, ctot, cin, 9);
-                if (cw.wino24s[p]) add(PK_WINO24S, w, cw.wino24s[p], (long long)cout * cin, cout, ctot, cin, 9);
+                if (cw.wino24s[p]) add(PK_WINO24S, w, cw.wino24s[p], (long long)((cout + 15) / 16) * (cin / 16) * 64, cout, ctot, cin, 9);
                 if (!bwd24) {      // transposed operator: cin outputs (padded to 32) x cout inputs
                     wt.wino_T[p] = talloc(size_t((cin + 31) / 32) * (cout / 8) * 16 * 256);
                     wt.has_wino_T = true;
@@ -217,18 +245,18 @@ struct Plan {
                 } else {           // dgrad through k_conv_wino24s: K = cout in 32-channel chunks
                     wt.wino24s_T[p] = talloc(wino24_packed_floats(cin, cout));
                     wt.has_wino24s_T = true;
-                    add(PK_WINO24S_T, w, wt.wino24s_T[p], (long long)cout * cin, cout, ctot, cin, 9, 0, 0, 1);
+                    add(PK_WINO24S_T, w, wt.wino24s_T[p], (long long)((cin + 15) / 16) * (cout / 16) * 64, cout, ctot, cin, 9, 0, 0, 1);
                 }
             }
             if (!cw.rollout) continue;
             const bool a_is_col = (p == 0);
             for (int slot = 1; slot <= 2; ++slot) {
                 const bool colv = (slot == 1) ? a_is_col : !a_is_col;
-                add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)3 * 3 * cout * cin, cout, ctot, cin, 9, slot, colv);
-                if (colv ? cw.rcol_f[p] : cw.rrow_f[p]) add(PK_RANK1F, w, colv ? cw.rcol_f[p] : cw.rrow_f[p], (long long)3 * 3 * cout * cin, cout, ctot, cin, 9, slot, colv);
+                add(PK_RANK1, w, colv ? cw.rcol[p] : cw.rrow[p], (long long)cout * cin, cout, ctot, cin, 9, slot, colv);
+                if (colv ? cw.rcol_f[p] : cw.rrow_f[p]) add(PK_RANK1F, w, colv ? cw.rcol_f[p] : cw.rrow_f[p], (long long)cout * cin, cout, ctot, cin, 9, slot, colv);
                 const size_t off = talloc(size_t(3) * cin * 3 * cout);
                 (colv ? wt.rcol_T[p] : wt.rrow_T[p]) = off;
-                add(PK_RANK1_BWD, w, off, (long long)3 * cin * 3 * cout, cout, ctot, cin, 9, slot, colv, 1);
+                add(PK_RANK1_BWD, w, off, (long long)cin * cout, cout, ctot, cin, 9, slot, colv, 1);
             }
         }
     }
