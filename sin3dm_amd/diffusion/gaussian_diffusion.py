@@ -407,7 +407,7 @@ class GaussianDiffusion:
         out = model.forward_train(x_t, self._model_timesteps(t), H, W, D)
         target = self._training_target(x_start, x_t, t, noise).contiguous().float()
         mse = _mse_terms(out, target, H, W, D)
-        wgt = (weights.to(out.device, th.float32) / out.shape[0])[:, None].expand(-1, 3).contiguous()
+        wgt = (weights.to(out.device, th.float32)[:, None].expand(-1, 3) / out.shape[0]).contiguous()      # [N, 3]: one kernel (the quotient of a broadcast view is already dense)
         g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out, **({"marks": grad_marks} if grad_marks else {}))
         terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2]}
         terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]       # the reference's order (:851), as training_losses
