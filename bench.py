@@ -49,7 +49,13 @@ CONFIGS = {
     "c5": ((256, 256, 128), 1, "ddpm", "", 1000, "DDPM-1000 triplane samples/sec @(256,256,128) retarget",
            "BASELINE configs[4] (diffusion side): retargeted (H,W,D)=(256,256,128) triplane (--resize 2 2 1), 128-ch UNet, "
            "DDPM-1000, batch 1; a step = 1 denoising step"),
+    # the diffusion stage of train.py: the only config whose N > 1 path has a collective (one flat-gradient all-reduce per step)
+    "c4": ((92, 128, 92), 4, "train", "", 1, "diffusion training samples/sec (towerruins-size triplane, 64-ch UNet), batch 4 per GPU",
+           "BASELINE configs[3] (diffusion stage) per-GPU share: TrainLoop.run_step on a (H,W,D)=(92,128,92) triplane, 64-ch "
+           "TriplaneUNetModelSmall, batch 4 per GPU, data-parallel; a step = q_sample + forward + backward + gradient all-reduce "
+           "(RCCL, N > 1) + AdamW/EMA + per-step weight repack"),
 }
+MC_OF = {"c4": 64}                   # model_channels per config (default MC)
 
 
 def f_dense_per_step(mc, H, W, D, mult=(1, 2)):
@@ -354,23 +360,42 @@ def worker(args):
             clock = ClockSampler(ident.get("pci_bus_id"))            # (a child process; it is sampling by the time the model is built)
         if world > 1:
             dist.init_process_group("nccl", device_id=dev)
-        model = TriplaneUNetModelSmall(12, MC, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
-        model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0))
-        model.to(dev).eval()
-        diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True, timestep_respacing=respacing)
-        assert diffusion.num_timesteps == steps_per_sample
+        mc = MC_OF.get(args.config, MC)
+        model = TriplaneUNetModelSmall(12, mc, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
+        model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0))
         kw = dict(H=H, W=W, D=D)
         torch.manual_seed(1000 + rank)
         state = {"x": None}
-        loop = diffusion.ddim_sample_loop_progressive if sampler_kind == "ddim" else diffusion.p_sample_loop_progressive
+        if sampler_kind == "train":
+            # TrainLoop.run_step (src/diffusion/train_util.py:163-247) on one fixed synthetic batch, as tools/bench_train.py drives it
+            from sin3dm_amd.diffusion.train_util import TrainLoop
+            model.to(dev)
+            diffusion = create_gaussian_diffusion(steps=T_STEPS, predict_xstart=True)
+            x0 = torch.from_numpy(T.synthetic_noise((12, H + D, W + D), 400)).clamp(-1, 1).to(dev)
+            batch = x0.unsqueeze(0).expand(BATCH, -1, -1, -1)
 
-        def sampler():          # the public sampling loop, sample after sample (src/sample.py:38 calls p_sample_loop)
-            while True:
-                for out in loop(model, (BATCH, 12, H + D, W + D), model_kwargs=kw):
-                    state["x"] = out["sample"]
-                    yield
-        gen = sampler()
-        step = lambda: next(gen)
+            def data():
+                while True:
+                    yield batch, dict(kw)
+            tl = TrainLoop(model=model, diffusion=diffusion, data=data(), batch_size=BATCH, microbatch=-1, lr=5e-4, ema_rate=0.9999,
+                           log_interval=10 ** 9, save_interval=10 ** 9, resume_checkpoint=False, lr_anneal_steps=25000)
+
+            def step():
+                tl.run_step(batch, dict(kw)); tl.step += 1
+                state["x"] = model.flat_parameters
+        else:
+            model.to(dev).eval()
+            diffusion = create_gaussian_diffusion(steps=T_STEPS, noise_schedule="linear", predict_xstart=True, timestep_respacing=respacing)
+            assert diffusion.num_timesteps == steps_per_sample
+            loop = diffusion.ddim_sample_loop_progressive if sampler_kind == "ddim" else diffusion.p_sample_loop_progressive
+
+            def sampler():          # the public sampling loop, sample after sample (src/sample.py:38 calls p_sample_loop)
+                while True:
+                    for out in loop(model, (BATCH, 12, H + D, W + D), model_kwargs=kw):
+                        state["x"] = out["sample"]
+                        yield
+            gen = sampler()
+            step = lambda: next(gen)
         sync = torch.cuda.synchronize
 
     def barrier():
@@ -425,7 +450,8 @@ def worker(args):
 
     ms_step = dt / args.steps * 1e3
     value = world * BATCH * args.steps / steps_per_sample / dt
-    fd = f_dense_per_step(MC, H, W, D) * BATCH
+    training = sampler_kind == "train"
+    fd = f_dense_per_step(MC_OF.get(args.config, MC), H, W, D) * BATCH * (3 if training else 1)      # (training: forward + dgrad + wgrad as the reference executes them)
     switches = s3d_switches()
     roof = None
     if prof is not None and prof.launches[0] > 0:
@@ -459,7 +485,8 @@ def worker(args):
                 "hbm_gbs": round(traffic / avg_s / 1e9, 1) if traffic else None,
                 "hbm_frac_of_8TBs": round(traffic / avg_s / 8e12, 4) if traffic else None,
                 "kernel": "the dense 3x3 TriplaneConv kernel (own-channel part of the rollout convolution), as reported by the "
-                          "library for the timed launches: " + model.profile_kernel(0),
+                          "library for the timed launches" + (" (the forward AND input-gradient convolutions of the training step: the same "
+                          "kernel on the operator and on its transpose)" if training else "") + ": " + model.profile_kernel(0),
                 "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(prof.launches[0]),
                 "flops_per_launch_avg": prof.flops[0] / prof.launches[0],
                 "mfma_flops_per_launch_avg": prof.mfma_flops[0] / prof.launches[0],
@@ -475,10 +502,12 @@ def worker(args):
     line = {"metric": metric, "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)",
+            "data": ("synthetic (seeded random weights; one fixed x0 batch per rank; numpy timestep sampler, device noise)" if training else
+                     "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)"),
             "config": {"workload": workload, "name": args.config,
                        "steps_per_sample": steps_per_sample, "batch_per_gpu": BATCH,
-                       "parallelism": f"{world} independent samples" if BATCH == 1 else f"{world} x {BATCH} independent samples",
+                       "parallelism": (f"dp{world}: one flat-gradient all-reduce per step" if training else
+                                       f"{world} independent samples" if BATCH == 1 else f"{world} x {BATCH} independent samples"),
                        "prewarm_steps": args.prewarm},
             "f_dense_gflop_per_step": round(fd / 1e9, 2),
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),

@@ -115,6 +115,7 @@ struct s3d_unet {
     int prof_every = 0;
     long fwd_count = 0;
     bool prof_now = false;
+    bool prof_train = false;          // the last training forward was a profiled one: its backward pass times its dgrad convolutions too
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int64_t prof_forwards = 0;

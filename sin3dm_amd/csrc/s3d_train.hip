@@ -56,7 +56,7 @@ struct Bwd {
                     J.wgt_wino24s = cw.k == 3 && wt.has_wino24s_T ? m->tdev(wt.wino24s_T[p]) : nullptr;
                     J.res = res ? res->p[p] : nullptr; J.out = d_a->p[p]; J.h = g.h[p]; J.w = g.w[p];
                 }
-                S3D_TRY(launch_conv(cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));
+                S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));      // (events only inside a profiled step)
             }
         }
         // (2) row / column sums of dy -> bias gradient, mean-slot gradients
@@ -376,7 +376,14 @@ int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, int B, i
             S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
         }
     }
+    // (s3d_unet_profile: every n-th training forward has its convolution launches bracketed by HIP events like the inference
+    // forward's — bench.py --config c4 reads them; the flag stays up through the matching backward pass: its dgrad launches count)
+    m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
+    ++m->fwd_count;
+    if (m->prof_now) ++m->prof_forwards;
+    m->prof_train = m->prof_now;
     rc = run_forward(m, x, t, B, H, W, D, out, st, &m->tape);
+    m->prof_now = false;
     if (rc) m->tape.valid = false;
     return rc;
 }
@@ -393,7 +400,10 @@ int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void
     m->tape.valid = false;                    // the tape is consumed: gradient buffers reuse no forward memory, but one backward per forward
     hipEvent_t marks[2] = {nullptr, nullptr};
     for (int k = 0; k < n_events; ++k) marks[k] = static_cast<hipEvent_t>(events[k]);
-    return run_backward(m, d_out, grads, static_cast<hipStream_t>(stream), marks, n_events);
+    m->prof_now = m->prof_train;
+    const int rc_b = run_backward(m, d_out, grads, static_cast<hipStream_t>(stream), marks, n_events);
+    m->prof_now = m->prof_train = false;
+    return rc_b;
 }
 
 int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, const int64_t* t, int B,

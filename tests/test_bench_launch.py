@@ -95,6 +95,12 @@ def test_config_c3_line_over_two_ranks():
     r = _run("--gpus", "1", "--config", "c5")
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["config"]["name"] == "c5" and "(256,256,128)" in line["metric"]
+    # configs[3]'s diffusion stage: the one workload whose N > 1 path carries a collective (the flat-gradient all-reduce)
+    r = _run("--gpus", "2", "--config", "c4")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["config"]["name"] == "c4" and line["config"]["batch_per_gpu"] == 4 and line["config"]["steps_per_sample"] == 1
+    assert "training" in line["metric"] and "configs[3]" in line["config"]["workload"] and line["config"]["parallelism"].startswith("dp2")
 
 
 def test_launcher_stops_its_ranks_when_it_is_terminated(tmp_path):

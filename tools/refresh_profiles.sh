@@ -43,7 +43,7 @@ python3 bench.py 2>/dev/null | tail -1 > $OUT/${R}_bench.json
 python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench_driver_flags.json
 # 5. the other BASELINE configs through bench.py (each line with its own roofline), the small ones through tools/bench_configs.py,
 #    training, decode
-{ for C in c3 c5; do python3 bench.py --config $C --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; done
+{ for C in c3 c5 c4; do python3 bench.py --config $C --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; done
   python3 tools/bench_configs.py "C1 " 2>/dev/null | grep "^{"; python3 tools/bench_configs.py "64-ch" 2>/dev/null | grep "^{"; } > $OUT/${R}_other_configs.txt
 { python3 tools/bench_train.py --steps 50 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
 { python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
