@@ -545,10 +545,10 @@ __global__ __launch_bounds__(256) void k_rank1(ConvArgs args) {
 // meet as ((q0 + q1) + q2) + q3, the variants are (u0 + u1) + u2, u1 + u2, u0 + u1, u1.
 // cin must be a multiple of 128 (whole chunks); slices as in k_rank1.
 constexpr int kR1bLdsFloats = 4 * 48 * 64;                 // the reduction image; the vector tile (34 x (slice channels + 4)) sits in the same bytes
-__global__ __launch_bounds__(256) void k_rank1b(ConvArgs args, int total_blocks) {
+__global__ __launch_bounds__(256) void k_rank1b(ConvArgs args) {
     extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
     int bid = blockIdx.x;
-    if ((total_blocks & 7) == 0) bid = (bid & 7) * (total_blocks >> 3) + (bid >> 3);     // consecutive logical ids share an XCD
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * int(gridDim.x >> 3) + (bid >> 3);        // consecutive logical ids share an XCD
     int j = 0;
 #pragma unroll
     for (int k = 1; k < kMaxConvJobs; ++k) j += (k < args.njobs && bid >= args.job[k].block_begin) ? 1 : 0;
@@ -705,7 +705,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         }
         if (!blocks) return 0;
         conv_note_kernel("k_rank1b (three-tap rollout tables, fragment-order weights)");
-        hipLaunchKernelGGL(k_rank1b, dim3(blocks), dim3(256), kR1bLdsFloats * sizeof(float), st, a, blocks);
+        hipLaunchKernelGGL(k_rank1b, dim3(blocks), dim3(256), kR1bLdsFloats * sizeof(float), st, a);
         S3D_HIP(hipGetLastError());
         return 0;
     }
