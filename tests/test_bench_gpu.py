@@ -1,0 +1,37 @@
+"""GPU: bench.py's real (not dry-run) worker for the scored config and for the training config, a few steps each: the JSON line
+keeps the driver's contract, the roofline is measured from the library's own HIP events, and nothing under oracle/ is touched
+when the CPU baseline is switched off."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(*extra):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "4", "--warmup", "1", "--prewarm", "4",
+                        "--profile-every", "1", "--no-cpu-baseline", "--traffic", "off", *extra],
+                       cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("config,launches_per_step,kernel", [("c2", 8, "k_conv_wino24"), ("c4", 16, "k_conv_wino24")])
+def test_bench_line_contract_and_live_roofline(config, launches_per_step, kernel):
+    """c2: BASELINE configs[1] (the scored one; 8 TriplaneConv 3x3 launches per denoising step, unet_triplane.py:27-58);
+    c4: TrainLoop.run_step (train_util.py:163-247) — its 8 forward and 8 input-gradient launches are all timed."""
+    d = _line("--config", config)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["name"] == config and d["value"] > 0 and d["ms_per_step"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and 0.05 < r["frac"] < 1.0
+    assert r["launches_timed"] == 4 * launches_per_step and kernel in r["kernel"]
+    assert r["conv3x3_ms_per_step"] <= d["ms_per_step"] * 1.05          # (events on every step cost a little)
+    assert "cpu_baseline" not in d
