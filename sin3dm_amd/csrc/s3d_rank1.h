@@ -20,11 +20,10 @@ constexpr int kR1LdsFloats = (34 + 2 * 32) * kR1Ld;       // A tile (34 rows) + 
 
 // ------------------------------------------------------------------ stage A: th.mean over one axis of the activated planes
 // (src/diffusion/unet_triplane.py:38-46): add the tile partials in index order and divide by the axis length.
-// item = (position, channel quad) of vector v = blockIdx.y of sample blockIdx.z; four adjacent lanes share an item: lane k
-// takes partials k, k+4, ... and the four sums meet by two xor-shuffles ((0+1)+(2+3): the same order in every launch).
-// The launch is a pure latency chain (1.6 us of dispatch + index arithmetic + one round of loads + a store), so the index
-// arithmetic is 32-bit on wave-uniform scalars and a lane's (up to four) partials are requested together (round 4: 5.0 -> see
-// profiles/r04_small_kernels.txt; sums and their order unchanged).
+// item = (position, channel quad) of vector v = blockIdx.y of sample blockIdx.z, one thread each.  At batch 1 the launch is a
+// pure latency chain (dispatch + one cold round of loads + a store: 4.9 us whatever the index arithmetic costs — a 64-bit
+// version with a search over the six vectors measured the same); at batch 8 it is bound by the 19 MB of partials per sample it
+// reads (14.3 -> 13.4 us per call with all sixteen loads of an item in flight in one thread instead of four lanes of four).
 __device__ __forceinline__ void means_finalize_thread(const MeanFinArgs& a, int v, int b, int gthread) {
     // one thread per item, all of its partials requested together; the sums are formed as the four-lane form formed them —
     // s_k = p_k + p_{k+4} + p_{k+8} + ... in order, then (s0 + s1) + (s2 + s3) — so the bits are those of every earlier round
