@@ -65,10 +65,13 @@ def test_leaf_ops(tag, C):
 
 def test_conv_edge_shapes(oracle):
     """ragged tiles, 1-pixel planes (edge variant 3), Cout not a multiple of the N tile, and a Cout that is not a
-    multiple of 4 (the Winograd epilogue moves channel quads: such a layer takes the direct kernel)."""
+    multiple of 4 (the Winograd epilogue moves channel quads: such a layer takes the direct kernel); TriplaneConv with rollout
+    (unet_triplane.py:31-60) against the C oracle's literal dense concat."""
     from sin3dm_amd import ops
+    # (the 128- and 256-channel cases go through k_rank1b — whole 128-channel chunks of own channels: a Cout that is not a multiple
+    #  of its 32-channel groups, positions that are not a multiple of its 32-position tiles, batch 2 / 3, one and two chunks)
     for (B, C, H, W, D, cout) in ((1, 32, 1, 1, 1, 32), (2, 32, 1, 37, 2, 24), (1, 64, 17, 3, 33, 72), (1, 32, 40, 9, 1, 64),
-                                  (1, 32, 9, 12, 5, 30)):
+                                  (1, 32, 9, 12, 5, 30), (2, 128, 9, 12, 5, 40), (3, 256, 33, 20, 17, 96), (1, 128, 1, 35, 2, 32)):
         fm = [T.synthetic_noise(s, 11 + i) for i, s in enumerate(((B, C, H, W), (B, C, H, D), (B, C, W, D)))]
         sd = {}
         for p in T.PLANES:
