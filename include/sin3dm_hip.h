@@ -96,7 +96,10 @@ S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film
  * matrix cores really multiply for them (Winograd F(2x2,3x3): 4/9 of the direct count, F(2x4,3x3): 1/3, F(4x4,3x3): 1/4).
  * s3d_unet_profile_kernel: names of the kernels the timed launches of class cls actually dispatched since profiling was switched
  * on (" + "-joined when a class used more than one, e.g. both blockings of the mixed Winograd kernel; "" if none):
- * bench.py labels its roofline line with it instead of deriving a name from environment switches. */
+ * bench.py labels its roofline line with it instead of deriving a name from environment switches.
+ * s3d_unet_profile_classes: which launch classes of a profiled forward are bracketed (bit 0: 3x3, bit 1: 1x1, bit 2: rank-1;
+ * default 7).  An event pair costs the step ~3 us (38 pairs' worth per profiled step with all classes): bench.py brackets only
+ * the dominant class inside its timed region and the other two in a short pass of its own afterwards. */
 typedef struct {
     double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */
     double flops[3];
@@ -105,6 +108,7 @@ typedef struct {
     double mfma_flops[3];
 } s3d_profile;
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
+S3D_API int s3d_unet_profile_classes(s3d_unet* m, int mask);
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
 S3D_API const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls);
 /* ------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ SIGNATURES = {
     "s3d_unet_forward_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
     "s3d_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "s3d_unet_profile_classes": (C.c_int, [C.c_void_p, C.c_int]),
     "s3d_unet_profile_read": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "s3d_unet_profile_kernel": (C.c_char_p, [C.c_void_p, C.c_int]),
     "s3d_sampler_step": (C.c_int, [C.POINTER(SamplerArgs), C.c_void_p]),

@@ -115,6 +115,7 @@ struct s3d_unet {
     int prof_every = 0;
     long fwd_count = 0;
     bool prof_now = false;
+    int prof_mask = 7;                // launch classes (bit 0: 3x3, 1: 1x1, 2: rank-1) whose launches are bracketed in a profiled forward
     bool prof_train = false;          // the last training forward was a profiled one: its backward pass times its dgrad convolutions too
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -133,7 +134,7 @@ struct s3d_unet {
         return e;
     }
     int timed_conv(int cls, ConvKind kind, ConvArgs& ca, hipStream_t st) {
-        if (!prof_now) return launch_conv(kind, ca, st);
+        if (!prof_now || !((prof_mask >> cls) & 1)) return launch_conv(kind, ca, st);
         // algorithmic flops of the layer (direct-convolution count); the Winograd path executes 4/9 of them on the MFMA
         int taps = kind == CONV_3x3 ? 9 : (kind == CONV_1x1 ? 1 : (kind == CONV_1x3_VEC ? 3 : (kind == CONV_1x3_ROLL ? 9 : 25)));
         double pix = 0;
@@ -149,7 +150,7 @@ struct s3d_unet {
     }
     template <class F>
     int timed_launch(int cls, double flops, double mfma_flops, hipStream_t st, F fn) {
-        if (!prof_now) return fn();
+        if (!prof_now || !((prof_mask >> cls) & 1)) return fn();
         ProfRec r{cls, prof_event(), prof_event(), flops, mfma_flops};
         if (r.e0) (void)hipEventRecord(r.e0, st);
         int rc = fn();

@@ -497,7 +497,14 @@ int s3d_unet_profile(s3d_unet* m, int every) {
     S3D_CHECK(m && every >= 0, S3D_ERR_INVALID, "unet_profile: bad argument");
     m->prof_every = every;
     m->fwd_count = 0;
-    if (every > 0) for (auto& k : m->prof_kernel) k.clear();          // a new measurement names its own kernels
+    if (every > 0)                                                    // a new measurement names its own kernels (of the classes it brackets)
+        for (int c = 0; c < 3; ++c) if ((m->prof_mask >> c) & 1) m->prof_kernel[c].clear();
+    return 0;
+}
+
+int s3d_unet_profile_classes(s3d_unet* m, int mask) {
+    S3D_CHECK(m && mask >= 0 && mask <= 7, S3D_ERR_INVALID, "unet_profile_classes: bad argument");
+    m->prof_mask = mask;
     return 0;
 }
 

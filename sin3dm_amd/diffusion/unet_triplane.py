@@ -256,9 +256,11 @@ class _TriplaneUNetBase(nn.Module):
                 pass
 
     # ------------------------------------------------------------------ live kernel timing (bench.py)
-    def profile(self, every):
-        """Record HIP events around the convolution launches of every `every`-th forward (0 = off)."""
+    def profile(self, every, classes=7):
+        """Record HIP events around the convolution launches of every `every`-th forward (0 = off); classes: bit mask of the
+        launch classes that are bracketed (1: 3x3, 2: 1x1, 4: rank-1 tables)."""
         lib = self._ensure_handle()
+        _lib.check(lib.s3d_unet_profile_classes(self._handle, int(classes)))
         _lib.check(lib.s3d_unet_profile(self._handle, int(every)))
 
     def profile_read(self, into=None):
