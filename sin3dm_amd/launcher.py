@@ -8,7 +8,12 @@ children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1
   * an overall deadline (S3D_LAUNCH_TIMEOUT seconds, default 3600) bounds a hung collective the same way;
   * the children never outlive the parent's watch: they run in their own sessions (process groups), the poll loop sits in a
     try/finally that stops every group, and SIGTERM / SIGINT / SIGHUP to the parent (a harness `timeout`, a cancelled gpurun
-    call, Ctrl-C) are turned into that same clean-up instead of leaving N ranks inside an RCCL collective with their GPUs held;
+    call, Ctrl-C) are turned into that same clean-up instead of leaving N ranks inside an RCCL collective with their GPUs held.
+    The FIRST such signal is only recorded (the poll loop sees the flag) and every later one is ignored, so the clean-up —
+    SIGTERM, grace period, SIGKILL, the waits — cannot be cut short by a second delivery (GNU `timeout` signals the pid and
+    then the group; a double Ctrl-C does the same).  Children are started with these signals blocked, so none can arrive
+    between `Popen` and the book-keeping that makes the child stoppable.  Should the launcher itself be SIGKILLed, every rank
+    carries a parent-death signal (prctl PR_SET_PDEATHSIG = SIGKILL, set between fork and exec) and dies with it;
   * rank 0's stdout is drained by a thread (no pipe dead-lock) and its last JSON line is relayed.
 
 The reference is single-process (src/utils/dist_util.py:29-42 is commented out); this is the launch side of SURVEY.md §8e.
@@ -67,8 +72,37 @@ def _group_alive(p):
         return False
 
 
-class _Interrupted(Exception):
-    pass
+_PR_SET_PDEATHSIG = 1
+
+
+def _libc():
+    try:
+        import ctypes
+        return ctypes.CDLL(None, use_errno=True)
+    except OSError:
+        return None
+
+
+def _rank_preexec(libc, parent_pid, blocked):
+    die = _die_with_parent(libc, parent_pid)
+
+    def hook():
+        if blocked:
+            signal.pthread_sigmask(signal.SIG_UNBLOCK, blocked)      # the launcher blocked them around the fork: the rank must not inherit that
+        die()
+    return hook
+
+
+def _die_with_parent(libc, parent_pid):
+    """preexec hook of a rank (runs between fork and exec): SIGKILL me when the launcher goes away — the ranks lead their own
+    sessions, so neither the terminal's SIGHUP nor a group kill of the launcher reaches them otherwise."""
+    def hook():
+        if libc is None:
+            return
+        libc.prctl(_PR_SET_PDEATHSIG, int(signal.SIGKILL), 0, 0, 0)
+        if os.getppid() != parent_pid:        # the launcher died before the prctl took effect
+            os._exit(1)
+    return hook
 
 
 def spawn_ranks(script, argv, n, timeout=None, poll_s=0.1, out=sys.stdout, err=sys.stderr, module=False, relay_json=True) -> int:
@@ -84,21 +118,36 @@ def spawn_ranks(script, argv, n, timeout=None, poll_s=0.1, out=sys.stdout, err=s
     failed, why = None, None
     t0 = time.time()
 
+    got = []                              # the first stop signal's name; later ones are swallowed (see the module text)
+
     def on_signal(signum, frame):
-        raise _Interrupted(signal.Signals(signum).name)
+        if not got:
+            got.append(signal.Signals(signum).name)
 
     handled = [sg for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP) if threading.current_thread() is threading.main_thread()]
     previous = {sg: signal.signal(sg, on_signal) for sg in handled}
     reader = None
+    libc, me = _libc(), os.getpid()
     try:
         for r in range(n):
+            if got:
+                break
             env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
             cmd = [sys.executable] + (["-m", script] if module else [os.path.abspath(script)]) + list(argv)
             stdout = None if not relay_json else (subprocess.PIPE if r == 0 else subprocess.DEVNULL)
-            procs.append(subprocess.Popen(cmd, env=env, stdout=stdout, text=True, start_new_session=True))
-        reader = threading.Thread(target=lambda: chunks.extend(procs[0].stdout) if relay_json else None, daemon=True)
-        reader.start()
-        while True:
+            # a stop signal must not land between the fork and the append that makes the child stoppable: block, start, note, unblock
+            # (the child gets an empty mask back from subprocess: restore_signals / its own exec)
+            old = signal.pthread_sigmask(signal.SIG_BLOCK, handled) if handled else None
+            try:
+                procs.append(subprocess.Popen(cmd, env=env, stdout=stdout, text=True, start_new_session=True,
+                                              preexec_fn=_rank_preexec(libc, me, handled)))
+            finally:
+                if old is not None:
+                    signal.pthread_sigmask(signal.SIG_SETMASK, old)
+        if not got:
+            reader = threading.Thread(target=lambda: chunks.extend(procs[0].stdout) if relay_json else None, daemon=True)
+            reader.start()
+        while not got:
             rcs = [p.poll() for p in procs]
             bad = [i for i, rc in enumerate(rcs) if rc not in (None, 0)]
             if bad:
@@ -110,9 +159,9 @@ def spawn_ranks(script, argv, n, timeout=None, poll_s=0.1, out=sys.stdout, err=s
                 failed, why = [i for i, rc in enumerate(rcs) if rc is None], f"no result after {timeout:.0f} s"
                 break
             time.sleep(poll_s)
-    except _Interrupted as e:
-        failed, why = list(range(len(procs))), f"the launcher received {e}"
-    except KeyboardInterrupt:
+        if got:
+            failed, why = list(range(len(procs))), f"the launcher received {got[0]}"
+    except KeyboardInterrupt:             # (only when this is not the main thread's handler: e.g. raised by a caller's own handler)
         failed, why = list(range(len(procs))), "the launcher was interrupted"
     finally:
         # whatever ended the watch — a failed rank, the deadline, a signal, an exception in this function — no rank survives it

@@ -133,3 +133,65 @@ def test_launcher_stops_its_ranks_when_it_is_terminated(tmp_path):
         except ProcessLookupError:
             alive = False
         assert not alive, f"rank process {pid} outlived its launcher"
+
+
+def _launch_two_ranks(tmp_path, rank_body):
+    import time
+    child = tmp_path / "rank.py"
+    child.write_text(rank_body)
+    parent = tmp_path / "parent.py"
+    parent.write_text(
+        "import sys\n"
+        f"sys.path.insert(0, {REPO!r})\n"
+        "from sin3dm_amd.launcher import spawn_ranks\n"
+        f"sys.exit(spawn_ranks({str(child)!r}, [{str(tmp_path / 'pid')!r}], 2, timeout=500))\n")
+    p = subprocess.Popen([sys.executable, str(parent)], stderr=subprocess.PIPE, text=True)
+    t0 = time.time()
+    while not all(os.path.exists(f"{tmp_path}/pid.{r}") and open(f"{tmp_path}/pid.{r}").read() for r in (0, 1)):
+        assert time.time() - t0 < 60 and p.poll() is None
+        time.sleep(0.1)
+    return p, [int(open(f"{tmp_path}/pid.{r}").read()) for r in (0, 1)]
+
+
+def _alive(pid):
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    try:                                      # a zombie waiting for its (dead) parent's wait() is not a live rank
+        return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+    except OSError:
+        return False
+
+
+def test_second_signal_cannot_cut_the_clean_up_short(tmp_path):
+    """GNU `timeout` signals the launcher's pid and then its process group, a double Ctrl-C does the same: the second delivery
+    used to raise inside the clean-up and abort the SIGKILL escalation.  Ranks that IGNORE SIGTERM need that
+    escalation; a second and third SIGTERM arrive while the launcher waits out their grace period."""
+    import signal
+    import time
+    p, pids = _launch_two_ranks(tmp_path, "import os, signal, sys, time\nsignal.signal(signal.SIGTERM, signal.SIG_IGN)\n"
+                                          "open(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    p.send_signal(signal.SIGTERM)
+    time.sleep(0.5)
+    p.send_signal(signal.SIGTERM)
+    time.sleep(0.5)
+    p.send_signal(signal.SIGINT)
+    _, err = p.communicate(timeout=60)
+    assert p.returncode == 1 and "SIGTERM" in err and "Traceback" not in err, err
+    time.sleep(0.5)
+    assert not any(_alive(pid) for pid in pids), "a rank that ignores SIGTERM outlived an interrupted clean-up"
+
+
+def test_ranks_die_with_a_killed_launcher(tmp_path):
+    """SIGKILL to the launcher leaves it no chance to clean up; the ranks lead their own sessions, so nothing else reaches
+    them: each carries PR_SET_PDEATHSIG = SIGKILL."""
+    import signal
+    import time
+    p, pids = _launch_two_ranks(tmp_path, "import os, sys, time\nopen(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    p.send_signal(signal.SIGKILL)
+    p.communicate(timeout=60)
+    t0 = time.time()
+    while any(_alive(pid) for pid in pids) and time.time() - t0 < 10:
+        time.sleep(0.1)
+    assert not any(_alive(pid) for pid in pids), "ranks outlived a SIGKILLed launcher"
