@@ -231,7 +231,10 @@ class ClockSampler:
         import subprocess
         self._p = None
         try:
-            self._p = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, bdf or ""], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+            # (never under the profiler this process may run under: its preloaded tool library would initialise the GPU in the
+            # child and write trace files of its own next to ours)
+            env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "LD_PRELOAD", "HSA_TOOLS_LIB"))}
+            self._p = subprocess.Popen([sys.executable, "-c", _SAMPLER_CODE, bdf or ""], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
         except Exception:
             self._p = None
         self._t0 = self._t1 = None
@@ -285,6 +288,7 @@ def measure_traffic_in_run(config):
         return None, "this process is itself being profiled"
     tot = {}
     tmp = tempfile.mkdtemp(prefix="s3d_pmc_")
+    t_start = time.time()
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
@@ -297,11 +301,12 @@ def measure_traffic_in_run(config):
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {r.stderr[-200:]!r}"
             agg = {}
-            for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] != counter or "k_conv_wino" not in row["Kernel_Name"]:
-                    continue
-                a = agg.setdefault("dom", [0.0, 0])
-                a[0] += float(row["Counter_Value"]); a[1] += 1
+            for f in files:                                     # (every process of the pass writes a file: take the rows, not a file)
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter or "k_conv_wino" not in row["Kernel_Name"]:
+                        continue
+                    a = agg.setdefault("dom", [0.0, 0])
+                    a[0] += float(row["Counter_Value"]); a[1] += 1
             if "dom" not in agg:
                 return None, f"no k_conv_wino launches in the {counter} pass"
             tot[counter] = agg["dom"][0] / agg["dom"][1]
@@ -313,7 +318,32 @@ def measure_traffic_in_run(config):
     bytes_per_launch = int(2 * tot["FETCH_SIZE"] * 1024 + tot["WRITE_SIZE"] * 1024)
     return bytes_per_launch, ("measured_in_run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this command (separate passes, "
                               "--kernel-trace only, 6 steps each), per-launch mean over the k_conv_wino24* launches, read side x2 "
-                              "(gfx950 FETCH_SIZE correction)")
+                              f"(gfx950 FETCH_SIZE correction); the two passes took {time.time() - t_start:.1f} s before the benchmark touched the GPU")
+
+
+def measure_chains(torch, model, diffusion, shape, kw, chains, rounds):
+    """The same workload as `chains` independent batch-1 sample chains in flight at once on one GPU (one HIP stream + one
+    workspace lane of the SAME model handle each, steps issued round-robin from this host thread:
+    GaussianDiffusion.sample_loop_chains_progressive) — what `python -m sin3dm_amd.sample` does with several batch-1 samples per
+    GPU.  Reported beside the headline, never as it: BASELINE configs[1] is ONE batch-1 chain."""
+    it = diffusion.sample_loop_chains_progressive(model, shape, 10 ** 9, chains=chains, model_kwargs=kw)
+    with torch.no_grad():
+        for _ in range(40):
+            next(it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(rounds):
+            cur = next(it)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert all(torch.isfinite(o["sample"]).all() for _, o in cur.values())
+    it.close()
+    n = len(cur)
+    return {"chains": n, "rounds_timed": rounds, "value": n * shape[0] * rounds / T_STEPS / dt, "unit": "samples/s",
+            "ms_per_step_per_sample": dt / (n * rounds) * 1e3, "per_chain_latency_ms": dt / rounds * 1e3,
+            "note": f"{n} independent batch-1 DDPM chains on {n} HIP streams / workspace lanes of one model handle, same process, measured "
+                    "right after the timed region; per-sample results are bit-identical to single-chain runs "
+                    "(tests/test_hip_chains.py); the headline value / ms_per_step above are ONE chain"}
 
 
 # ------------------------------------------------------------------------------------------------ worker
@@ -328,6 +358,7 @@ def worker(args):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     (H, W, D), BATCH, sampler_kind, respacing, steps_per_sample, metric, workload = CONFIGS[args.config]
     clock = None
+    chains2 = None
 
     ident = {"device_index": None, "pci_bus_id": None, "uuid": None, "name": "cpu (dry run)"}
     if args.dry_run:
@@ -364,7 +395,8 @@ def worker(args):
         model = TriplaneUNetModelSmall(12, mc, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
         model.load_state_dict(T.synthetic_state_dict(T.unet_param_shapes(model_channels=mc), 0))
         kw = dict(H=H, W=W, D=D)
-        torch.manual_seed(1000 + rank)
+        from sin3dm_amd import parallel
+        torch.manual_seed(parallel.sample_seed(1000, rank))          # rank r's first sample is sample index r (parallel.shard_indices): ONE seed convention
         state = {"x": None}
         if sampler_kind == "train":
             # TrainLoop.run_step (src/diffusion/train_util.py:163-247) on one fixed synthetic batch, as tools/bench_train.py drives it
@@ -435,6 +467,8 @@ def worker(args):
             prof.mfma_flops[cls] = side.mfma_flops[cls] * scale; prof.launches[cls] = int(side.launches[cls] * scale)
         model.profile(0)
         assert torch.isfinite(state["x"]).all()
+        if args.config == "c2" and world == 1 and args.chains > 1:
+            chains2 = measure_chains(torch, model, diffusion, (BATCH, 12, H + D, W + D), kw, args.chains, max(args.steps, 200))
 
     # every rank reports who it was and what it measured: the line shows N distinct devices, not just a world size
     mine = dict(ident, rank=rank, ms_per_step=round(dt / args.steps * 1e3, 4))
@@ -514,7 +548,7 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": ("synthetic (seeded random weights; one fixed x0 batch per rank; numpy timestep sampler, device noise)" if training else
-                     "synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; device RNG per step)"),
+                     f"synthetic (seeded random weights incl. zero-init convs; N(0,1) x_T; eps from the device RNG, one randn launch per {max(1, (48 << 20) // (4 * BATCH * 12 * (H + D) * (W + D)))} step(s))"),
             "config": {"workload": workload, "name": args.config,
                        "steps_per_sample": steps_per_sample, "batch_per_gpu": BATCH,
                        "parallelism": (f"dp{world}: one flat-gradient all-reduce per step" if training else
@@ -522,7 +556,7 @@ def worker(args):
                        "prewarm_steps": args.prewarm},
             "f_dense_gflop_per_step": round(fd / 1e9, 2),
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
-            "roofline": roof, "s3d_switches": switches,
+            "roofline": roof, "chains2": chains2, "s3d_switches": switches,
             "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks], "devices_verified_distinct": bool(verifiable) if world > 1 else None,
             "rccl_world_size": backend_world if world > 1 else None, "dist_backend": backend if world > 1 else None}
     if args.dry_run:
@@ -550,6 +584,7 @@ def main():
     ap.add_argument("--prewarm", type=int, default=PREWARM, help="untimed steps before --warmup (a fresh box needs them to reach steady clocks)")
     ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
                     help="auto: measure roofline.traffic in this run with two rocprofv3 --pmc child passes (N = 1 only)")
+    ap.add_argument("--chains", type=int, default=2, help="also report the c2 workload as this many independent chains in flight (field `chains2`; 0/1 = off)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-early", action="store_true", help=argparse.SUPPRESS)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define S3D_ABI_VERSION 3
+#define S3D_ABI_VERSION 4
 #define S3D_API __attribute__((visibility("default")))
 
 typedef enum {
@@ -85,6 +85,19 @@ S3D_API int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B,
  * internal events — issue the calls of a handle from ONE stream at a time, and make a stream that consumes a film table
  * produced on another stream wait for it (the Python mirror records an event with each cached table and does so). */
 S3D_API int s3d_unet_film_width(const s3d_unet* m);
+
+/* Workspace lanes: several INDEPENDENT sample chains through one handle, each on its own HIP stream (hardware queue).  The
+ * reference makes N samples by batching them (src/sample.py:33-38); at small batch a denoising step is a chain of one-round,
+ * latency-bound launches, and a second independent chain fills what the first leaves idle (no event edge is needed between
+ * independent samples).  The packed weights are shared; everything a forward WRITES — the activation workspace, s3d_unet_film's
+ * scratch, the measured-shape key — exists once per lane.  s3d_unet_select_lane(m, k) makes lane k (0 <= k < S3D_MAX_LANES;
+ * created on first use; lane 0 always exists and is selected at creation) the target of the following inference calls on this
+ * handle (s3d_unet_forward / _film / _forward_film / _step_film): one stream per lane at a time, calls of different lanes may
+ * be in flight on different streams together.  Still ONE host thread per handle.  Training (s3d_unet_forward_train /
+ * _backward) runs on lane 0; a weight update (s3d_unet_set_param, s3d_unet_repack) must not overlap ANY lane's work in flight. */
+#define S3D_MAX_LANES 16
+S3D_API int s3d_unet_select_lane(s3d_unet* m, int lane);
+S3D_API int s3d_unet_current_lane(const s3d_unet* m);
 S3D_API int s3d_unet_film(s3d_unet* m, const float* t, int n, float* film, void* stream);
 S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film, int film_stride, int B, int H, int W, int D,
                           float* out, void* stream);

@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(_HERE, "libsin3dm_hip.so")
 c_fp = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 TAB_ROWS = ("sqrt_recip", "sqrt_recipm1", "coef1", "coef2", "logvar", "acp", "acp_prev")
 STEP_DDPM, STEP_DDIM, STEP_MEAN_ONLY = 0, 1, 2
 MEAN_START_X, MEAN_EPSILON = 0, 1
 ERR_INVALID, ERR_MISSING, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4
+MAX_LANES = 16
 
 
 class UNetCfg(C.Structure):
@@ -64,6 +65,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     "s3d_unet_film_width": (C.c_int, [C.c_void_p]),
     "s3d_unet_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "s3d_unet_select_lane": (C.c_int, [C.c_void_p, C.c_int]),
+    "s3d_unet_current_lane": (C.c_int, [C.c_void_p]),
     "s3d_unet_forward_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p]),
     "s3d_unet_profile": (C.c_int, [C.c_void_p, C.c_int]),

@@ -94,6 +94,23 @@ struct s3d_unet {
     DevBuf film_ws;                                      // s3d_unet_film: the two hidden vectors of the timestep MLP
     long long inf_key[4] = {-1, -1, -1, -1};             // (B,H,W,D) of the last measured inference forward ...
     size_t inf_high = 0;                                 // ... and the workspace it needs
+    // Workspace lanes (s3d_unet_select_lane): independent sample chains on different HIP streams through ONE handle — the weights
+    // are shared, everything a forward writes (the activation arena, the timestep MLP's scratch, the measured-shape key) exists
+    // once per lane.  The fields above ARE the selected lane; the others are parked here.
+    struct LaneState {
+        DevBuf arena_buf, film_ws;
+        size_t off = 0, high = 0, inf_high = 0;
+        long long inf_key[4] = {-1, -1, -1, -1};
+    };
+    std::vector<std::unique_ptr<LaneState>> lanes;       // lanes[k] holds lane k's state while another lane is selected
+    int cur_lane = 0;
+    void swap_lane(LaneState& L) {
+        std::swap(arena.buf.p, L.arena_buf.p); std::swap(arena.buf.cap, L.arena_buf.cap);
+        std::swap(arena.off, L.off); std::swap(arena.high, L.high);
+        std::swap(film_ws.p, L.film_ws.p); std::swap(film_ws.cap, L.film_ws.cap);
+        std::swap(inf_high, L.inf_high);
+        for (int k = 0; k < 4; ++k) std::swap(inf_key[k], L.inf_key[k]);
+    }
 
     // training tier: caller-owned flat master parameters (reference layouts, specs order, tightly packed), the
     // device-side repack plan and the activation tape of the last forward_train

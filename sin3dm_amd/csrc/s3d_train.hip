@@ -354,6 +354,7 @@ int s3d_unet_repack(s3d_unet* m, void* stream) {
 int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream) {
     S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "forward_train: null argument");
     S3D_CHECK(m->flat, S3D_ERR_INVALID, "forward_train: call s3d_unet_train_attach first");
+    S3D_CHECK(m->cur_lane == 0, S3D_ERR_INVALID, "forward_train: training runs on workspace lane 0 (lane %d is selected)", m->cur_lane);
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "forward_train: B,H,W,D must be >= 1");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // measure forward + backward together: the workspace must not move between the two.  Pure host work that depends

@@ -423,6 +423,20 @@ int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, 
 
 int s3d_unet_film_width(const s3d_unet* m) { return m ? m->film_total : S3D_ERR_INVALID; }
 
+int s3d_unet_select_lane(s3d_unet* m, int lane) {
+    S3D_CHECK(m && lane >= 0 && lane < S3D_MAX_LANES, S3D_ERR_INVALID, "unet_select_lane: lane must be in [0, %d)", S3D_MAX_LANES);
+    if (lane == m->cur_lane) return 0;
+    S3D_CHECK(!m->tape.valid, S3D_ERR_INVALID, "unet_select_lane: a forward_train is waiting for its backward (training runs on lane 0)");
+    const size_t need = size_t(std::max(lane, m->cur_lane)) + 1;
+    while (m->lanes.size() < need) m->lanes.emplace_back(new s3d_unet::LaneState());
+    m->swap_lane(*m->lanes[m->cur_lane]);          // park the selected lane ...
+    m->swap_lane(*m->lanes[lane]);                 // ... and bring the requested one in
+    m->cur_lane = lane;
+    return 0;
+}
+
+int s3d_unet_current_lane(const s3d_unet* m) { return m ? m->cur_lane : S3D_ERR_INVALID; }
+
 int s3d_unet_film(s3d_unet* m, const float* t, int n, float* film, void* stream) {
     S3D_CHECK(m && t && film && n >= 1, S3D_ERR_INVALID, "unet_film: bad argument");
     if (!m->packed) S3D_TRY(pack_all(m));

@@ -208,8 +208,8 @@ class GaussianDiffusion:
         if noise is not None:
             assert noise.shape == x.shape and noise.is_contiguous()
         elif mode == _lib.STEP_DDPM or (mode == _lib.STEP_DDIM):
-            # the reference draws randn_like on every step, t == 0 and eta == 0 included (:431, :591):
-            # keep the generator stream identical
+            # the reference draws randn_like on every step, t == 0 and eta == 0 included (:431, :591); the single-step API does
+            # the same (one randn_like per call).  The loops hand in `noise` from their own chunked draws (see _loop)
             noise = self._noise(x).contiguous()
         if y0 is not None and mask is not None:
             assert y0.shape == x.shape and mask.shape == x.shape
@@ -266,18 +266,41 @@ class GaussianDiffusion:
     # that happened to contain one, profiles/r04_bench_driver_flags.json)
     _NOISE_AHEAD_BYTES = 48 << 20
 
+    @staticmethod
+    def _randn(shape, device, generator, lead=None):
+        """N(0,1) of `shape` = [B, ...] (lead: k such tensors, [k, B, ...]).  generator: None (the device's default generator, one
+        call), a torch.Generator (one call on it), or a sequence of B generators — sample b's values then come from generator b
+        alone, in calls whose size does not depend on B: a sample's noise is the same whatever it is batched with."""
+        pre = () if lead is None else (int(lead),)
+        if generator is None or isinstance(generator, th.Generator):
+            return th.randn(pre + tuple(shape), device=device, generator=generator)
+        assert len(generator) == shape[0], "one generator per batch element"
+        per = [th.randn(pre + tuple(shape[1:]), device=device, generator=g) for g in generator]
+        return per[0].unsqueeze(len(pre)) if len(per) == 1 else th.stack(per, dim=len(pre))
+
     def _loop(self, mode, model, shape, noise, device, progress, clip_denoised=True, denoised_fn=None, cond_fn=None,
-              model_kwargs=None, **kw):
+              model_kwargs=None, generator=None, **kw):
         """Shared body of p_sample_loop_progressive / ddim_sample_loop_progressive (:488-536, 687-734).  Every step is ONE call
         into the library when the denoiser is the HIP UNet (`_step(fuse=True)`); the per-step eps comes from the device
         generator like the reference's randn_like on a GPU, drawn for many steps at a time (`noise_fn`, if set, is asked every
-        step instead).  The single-step API (p_sample / ddim_sample) keeps the forward + sampler-kernel pair."""
+        step instead).  The single-step API (p_sample / ddim_sample) keeps the forward + sampler-kernel pair.
+
+        RNG stream: ONE randn call per chunk of steps consumes the generator differently from one randn_like per step (the
+        Philox offset of a call depends on its size), so for a given seed the loops' default noise is not the sequence a manual
+        p_sample loop — or the reference on a GPU — would draw; seeded runs are reproducible, `_NOISE_AHEAD_BYTES = 0` restores
+        per-step draws, `noise_fn` replaces the source altogether.
+        generator (an extension of the reference's signature): x_T and every eps come from it instead of the device's default
+        generator — a torch.Generator, or one per batch element (`_randn`); with per-element generators the chunk length is
+        fixed per SAMPLE, so a sample's whole trajectory depends on its generator only: not on the batch it is in, not on the
+        chain / stream / GPU it runs on (sample_loop_chains, sin3dm_amd.sample)."""
         if cond_fn is not None:
             raise NotImplementedError("cond_fn guidance is out of scope (no caller in the reference)")
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
-        img = noise if noise is not None else th.randn(*shape, device=device)
+        if generator is not None and not isinstance(generator, th.Generator):
+            generator = list(generator)
+        img = noise if noise is not None else self._randn(shape, device, generator)
         indices = list(range(self.num_timesteps))[::-1]
         if progress:
             from tqdm.auto import tqdm
@@ -289,7 +312,7 @@ class GaussianDiffusion:
             prepare(model, shape[0], device)         # per-schedule caches (timestep map, FiLM tables) in one go
         ahead, ahead_k = None, 0
         per_step = 4
-        for d in shape:
+        for d in (shape if generator is None or isinstance(generator, th.Generator) else shape[1:]):     # (per-element generators: per SAMPLE)
             per_step *= int(d)
         chunk = max(1, min(self.num_timesteps, self._NOISE_AHEAD_BYTES // max(per_step, 1)))
         for n, i in enumerate(indices):
@@ -297,7 +320,7 @@ class GaussianDiffusion:
             eps = None
             if self.noise_fn is None:
                 if ahead is None or ahead_k == ahead.shape[0]:
-                    ahead = th.randn((min(chunk, self.num_timesteps - n),) + tuple(shape), device=device)
+                    ahead = self._randn(shape, device, generator, lead=min(chunk, self.num_timesteps - n))
                     ahead_k = 0
                 eps = ahead[ahead_k]
                 ahead_k += 1
@@ -309,40 +332,116 @@ class GaussianDiffusion:
             img = out["sample"]
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                                  model_kwargs=None, device=None, progress=False):
-        """Generator over the per-step dicts of p_sample (:488-536)."""
+                                  model_kwargs=None, device=None, progress=False, generator=None):
+        """Generator over the per-step dicts of p_sample (:488-536).  `generator`: see _loop."""
         yield from self._loop(_lib.STEP_DDPM, model, shape, noise, device, progress, clip_denoised=clip_denoised,
-                              denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs)
+                              denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, generator=generator)
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
-                      model_kwargs=None, device=None, progress=False):
+                      model_kwargs=None, device=None, progress=False, generator=None):
         """Full ancestral sampling run, returns the final sample (:442-486)."""
         final = None
         for final in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                     denoised_fn=denoised_fn, cond_fn=cond_fn,
-                                                    model_kwargs=model_kwargs, device=device, progress=progress):
+                                                    model_kwargs=model_kwargs, device=device, progress=progress,
+                                                    generator=generator):
             pass
         return final["sample"]
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                                      cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0, y0=None,
-                                     mask=None, is_mask_t0=False):
-        """Generator over the per-step dicts of ddim_sample (:687-734)."""
+                                     mask=None, is_mask_t0=False, generator=None):
+        """Generator over the per-step dicts of ddim_sample (:687-734).  `generator`: see _loop."""
         yield from self._loop(_lib.STEP_DDIM, model, shape, noise, device, progress, clip_denoised=clip_denoised,
-                              denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta, y0=y0,
-                              mask=mask, is_mask_t0=is_mask_t0)
+                              denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, generator=generator,
+                              eta=eta, y0=y0, mask=mask, is_mask_t0=is_mask_t0)
 
     def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                          model_kwargs=None, device=None, progress=False, eta=0.0, y0=None, mask=None,
-                         is_mask_t0=False):
+                         is_mask_t0=False, generator=None):
         """Full DDIM run, returns the final sample (:640-685)."""
         final = None
         for final in self.ddim_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                        denoised_fn=denoised_fn, cond_fn=cond_fn,
                                                        model_kwargs=model_kwargs, device=device, progress=progress,
-                                                       eta=eta, y0=y0, mask=mask, is_mask_t0=is_mask_t0):
+                                                       eta=eta, y0=y0, mask=mask, is_mask_t0=is_mask_t0, generator=generator):
             pass
         return final["sample"]
+
+    # ------------------------------------------------------------------ several independent runs at once
+    def sample_loop_chains_progressive(self, model, shape, n_runs, chains=2, ddim=False, generators=None, noises=None, device=None,
+                                       streams=None, **loop_kw):
+        """`n_runs` independent p_sample_loop (ddim=False) / ddim_sample_loop (ddim=True) runs of batch shape `shape`, up to
+        `chains` of them in flight at once: chain c owns HIP stream c and workspace lane c of the denoiser (`model.lane`), its
+        steps are issued round-robin with the other chains' from this one host thread.  The reference produces many samples by
+        batching them or one batch after the other (src/sample.py:33-47); at small batch a step is a chain of one-round,
+        latency-bound launches and a second independent chain fills what the first leaves idle — independent runs need no event
+        edges (measured: profiles/r05_two_chains.txt).  generators[r] / noises[r]: run r's `generator` / x_T (see _loop); with a
+        generator per run every result is bit-identical to the same run alone on the current stream.
+        A generator: yields {chain: (run, that run's latest step dict)} after every ROUND (each chain in flight advanced by one
+        step; the tensors live on their chain's stream) and returns the list of final samples, ordered by run, valid on the
+        caller's current stream.  chains <= 1, or a denoiser without lanes: the runs follow each other on the current stream."""
+        import collections
+        import contextlib
+        if device is None:
+            device = next(model.parameters()).device
+        loop = self.ddim_sample_loop_progressive if ddim else self.p_sample_loop_progressive
+        n_runs = int(n_runs)
+        nch = max(1, min(int(chains), n_runs, _lib.MAX_LANES))
+        lane = getattr(model, "lane", None)
+        if lane is None or nch <= 1:
+            nch, lane = 1, (lambda c: contextlib.nullcontext())
+        own = None
+        if streams is None:
+            if nch > 1:
+                prep = getattr(self, "_prepare_loop", None)
+                if prep is not None:
+                    prep(model, shape[0], device)             # host-side schedule caches are built once, ahead of every chain
+                main = th.cuda.current_stream(device)
+                own = [th.cuda.Stream(device=device) for _ in range(nch)]
+                for s in own:
+                    s.wait_stream(main)                       # whatever produced the inputs (noises, weights) comes first
+                streams = [th.cuda.stream(s) for s in own]
+            else:
+                streams = [contextlib.nullcontext()]
+        assert len(streams) >= nch
+        next_run = 0
+        active = {}
+        results = {}
+        while next_run < n_runs or active:
+            for c in range(nch):
+                if c not in active:
+                    if next_run >= n_runs:
+                        continue
+                    r, next_run = next_run, next_run + 1
+                    active[c] = [r, loop(model, shape, noise=noises[r] if noises is not None else None, device=device,
+                                         generator=generators[r] if generators is not None else None, **loop_kw), None]
+                with streams[c], lane(c):
+                    try:
+                        active[c][2] = next(active[c][1])
+                    except StopIteration:
+                        results[active[c][0]] = active[c][2]["sample"]
+                        del active[c]
+            if active:
+                yield {c: (a[0], a[2]) for c, a in active.items()}
+        if own is not None:
+            main = th.cuda.current_stream(device)
+            for s in own:
+                main.wait_stream(s)
+            for x in results.values():
+                x.record_stream(main)
+        return [results[r] for r in range(n_runs)]
+
+    def sample_loop_chains(self, model, shape, n_runs, chains=2, ddim=False, generators=None, noises=None, device=None,
+                           streams=None, **loop_kw):
+        """The final samples of sample_loop_chains_progressive (a list ordered by run)."""
+        it = self.sample_loop_chains_progressive(model, shape, n_runs, chains=chains, ddim=ddim, generators=generators,
+                                                 noises=noises, device=device, streams=streams, **loop_kw)
+        while True:
+            try:
+                next(it)
+            except StopIteration as e:
+                return e.value
 
     # ------------------------------------------------------------------ training (SURVEY.md §8f rank 1)
     def _train_tables(self, device):

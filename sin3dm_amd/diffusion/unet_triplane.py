@@ -70,6 +70,7 @@ class _TriplaneUNetBase(nn.Module):
         self._plist = None
         self._film_cache = {}       # host-known timestep values -> FiLM table (dropped whenever the parameters change)
         self._film_sched = None     # the last schedule announced by a sampling loop (prepare_timesteps)
+        self._lane = 0              # workspace lane the inference calls go to (see lane())
         self._flat = None           # training: flat master parameters on the device (see _ensure_flat)
         self._flat_layout = None    # [(name, offset, numel, shape)]
         self._flat_dirty = False
@@ -140,6 +141,21 @@ class _TriplaneUNetBase(nn.Module):
                                                   host.dim()))
             self._synced = stamp
         return lib
+
+    # ------------------------------------------------------------------ workspace lanes (independent sample chains)
+    def lane(self, k):
+        """Context manager: the inference calls inside go to workspace lane `k` of the HIP handle (s3d_unet_select_lane).
+        Independent sample chains — one lane and one HIP stream each — share this module and its packed weights; what a
+        forward writes (activations, the timestep MLP's scratch, the cached FiLM tables) exists once per lane, so chains need no
+        event edges between them (GaussianDiffusion.sample_loop_chains drives them).  One host thread; lane 0 is the default."""
+        return _LaneCtx(self, int(k))
+
+    def _select_lane(self, k):
+        if not 0 <= k < _lib.MAX_LANES:
+            raise AssertionError(f"lane must be in [0, {_lib.MAX_LANES})")
+        lib = self._ensure_handle()
+        _lib.check(lib.s3d_unet_select_lane(self._handle, k))
+        self._lane = k
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)      # .to(), .cuda(), .float(): the parameter storage moves
@@ -335,7 +351,7 @@ class _TriplaneUNetBase(nn.Module):
         middle of a loop refills the cache in one go."""
         self._film_sched = (tuple(values), t_dev)
         lib = self._ensure_handle()
-        dkey = str(t_dev.device)
+        dkey = (str(t_dev.device), self._lane)
         width = lib.s3d_unet_film_width(self._handle)
         t = t_dev.to(th.float32).contiguous()
         film = th.empty((len(values), width), device=t.device, dtype=th.float32)
@@ -363,7 +379,7 @@ class _TriplaneUNetBase(nn.Module):
     def _film_for(self, lib, hv, t):
         """(device FiLM table, row stride) for host-known timestep values: one row when the batch shares a value."""
         same = all(v == hv[0] for v in hv)
-        key = (str(t.device), hv[0] if same else hv)
+        key = ((str(t.device), self._lane), hv[0] if same else hv)
         hit = self._film_cache.get(key)
         if hit is None and same and self._film_sched is not None and hv[0] in self._film_sched[0] \
                 and str(self._film_sched[1].device) == str(t.device):
@@ -392,6 +408,22 @@ class _TriplaneUNetBase(nn.Module):
         t = timesteps.to(device=h.device, dtype=th.float32).contiguous()
         out = th.empty((B, self.out_channels, Hc, Wc), device=h.device, dtype=th.float32)
         return h, t, out
+
+
+class _LaneCtx:
+    def __init__(self, model, k):
+        self.model, self.k, self.prev = model, k, 0
+
+    def __enter__(self):
+        self.prev = self.model._lane
+        if self.k != self.prev:
+            self.model._select_lane(self.k)
+        return self.model
+
+    def __exit__(self, *exc):
+        if self.model._lane != self.prev:
+            self.model._select_lane(self.prev)
+        return False
 
 
 class _UNetFn(th.autograd.Function):

@@ -35,7 +35,8 @@ def init(backend=None, device=None, timeout_s=None):
 
 def launch_token():
     """A string every rank of ONE launch derives identically and two launches do not share: the rendezvous port plus the
-    launcher's pid (torchrun's run id when it provides one)."""
+    launcher's pid (torchrun's run id when it provides one).  The pid makes it a SINGLE-NODE token (ranks on another node have
+    another launcher): sin3dm_amd.train refuses multi-node launches instead of waiting for a name nobody writes."""
     return "%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "run"), os.environ.get("MASTER_PORT", "0"), os.getppid())
 
 

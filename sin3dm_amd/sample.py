@@ -42,19 +42,39 @@ def sample_diffusion(args, rank=0, world=1, base_seed=1000):
 
     paths = []
     mine = parallel.shard_indices(args.n_samples, rank, world)
-    for idx in parallel.batches(mine, args.diff_batch_size):
-        # x_T per sample from its own seed, so the outputs do not depend on the number of GPUs
-        noise = torch.stack([torch.randn(C, H + D, W + D, device=dev,
-                                         generator=torch.Generator(device=dev).manual_seed(parallel.sample_seed(base_seed, i)))
-                             for i in idx])
-        samples = sample_fn(model, list(noise.shape), noise=noise, progress=rank == 0,
-                            model_kwargs={"H": H, "W": W, "D": D})
+    groups = list(parallel.batches(mine, args.diff_batch_size))
+    # x_T and every step's eps of sample i come from ITS generator (seed = base + i): a sample does not depend on the batch it
+    # is in, the chain it runs on or the number of GPUs
+    gens = [[torch.Generator(device=dev).manual_seed(parallel.sample_seed(base_seed, i)) for i in idx] for idx in groups]
+    kw = {"H": H, "W": W, "D": D}
+    nch = sample_chains(len(groups), args.diff_batch_size)
+    full = [g for g in range(len(groups)) if len(groups[g]) == args.diff_batch_size]
+    outs = {}
+    if nch > 1 and len(full) > 1:
+        # several batches of equal shape on this GPU: up to `nch` of them in flight as independent chains (one stream + one
+        # workspace lane each) instead of one after the other (src/sample.py:33-47)
+        res = diffusion.sample_loop_chains(model, [args.diff_batch_size, C, H + D, W + D], len(full), chains=nch,
+                                           ddim=bool(args.use_ddim), generators=[gens[g] for g in full], device=dev, model_kwargs=kw)
+        outs = dict(zip(full, res))
+    for g, idx in enumerate(groups):
+        samples = outs[g] if g in outs else sample_fn(model, [len(idx), C, H + D, W + D], progress=rank == 0, model_kwargs=kw,
+                                                      generator=gens[g])
         xy, xz, yz = (t.detach().cpu().numpy() for t in decompose_featmaps(samples, (H, W, D)))
         for j, i in enumerate(idx):
             path = os.path.join(result_dir, f"{i:03d}", "feat.npz")
             save_triplane_data(path, xy[j], xz[j], yz[j])
             paths.append(path)
     return paths
+
+
+def sample_chains(n_batches, batch):
+    """How many of a rank's batches run at once as independent chains (GaussianDiffusion.sample_loop_chains).  S3D_SAMPLE_CHAINS
+    sets it (1 = off).  Default: chains pay where a step's launches are a round or two of blocks each — measured on one MI355X
+    at 128^3 (profiles/r05_two_chains.txt) — so three at batch 1, two at batch 2, none from batch 4 on."""
+    env = os.environ.get("S3D_SAMPLE_CHAINS")
+    if env:
+        return max(1, min(int(env), n_batches))
+    return max(1, min(3 if batch == 1 else 2 if batch == 2 else 1, n_batches))
 
 
 def decode(args, paths):

@@ -76,16 +76,30 @@ def main(argv=None, confirm=input):
     seed_all(0 + rank)                               # per-rank timestep / noise streams; weights are broadcast from rank 0
     dist_util.setup_dist(local if world > 1 else args.gpu_id)
     # stage 1 belongs to one process and takes minutes: no process group yet, the other ranks wait for its marker file
+    if world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) != world:
+        # the marker's name contains the launcher's pid (what makes it unique per launch), which differs from node to node
+        raise SystemExit("sin3dm_amd.train: the stage-1 hand-off is a marker file named per launcher: one node only "
+                         f"(WORLD_SIZE={world}, LOCAL_WORLD_SIZE={os.environ.get('LOCAL_WORLD_SIZE')})")
+    if args.only_enc and rank != 0:
+        return                                       # stage 1 is rank 0's alone and nothing follows it: no marker, no wait
     marker = stage1_marker(args.tag)
     if rank == 0:
+        if world > 1:                                # markers of launches that died between writing and removing theirs
+            import glob
+            for stale in glob.glob(os.path.join(args.tag, ".stage1_done_*")):
+                if stale != marker:
+                    try:
+                        os.remove(stale)
+                    except OSError:
+                        pass
         if args.enc_log is None:
             train_ae(args)
+        if args.only_enc:
+            return
         if world > 1:
             open(marker, "w").close()                # the experiment directory + encoding exist: everyone may read them
     else:
         parallel.wait_for_file(marker, what="rank 0's auto-encoder stage")
-    if args.only_enc:
-        return
     parallel.init(device=dist_util.dev())
     parallel.barrier()
     if rank == 0 and world > 1:

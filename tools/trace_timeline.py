@@ -2,7 +2,10 @@
 """One step's kernel timeline from a rocprofv3 --kernel-trace CSV: start offset, duration and the idle gap before each
 kernel, for the LAST complete step in the trace (a step ends with the output head, which applies the sampler update in the loops).
 
-    python tools/trace_timeline.py <kernel_trace.csv> [marker-substring=k_out_head]
+    python tools/trace_timeline.py <kernel_trace.csv> [marker-substring=k_out_head] [avg-steps=0]
+
+avg-steps = N > 0: after the single step, the MEAN duration and MEAN gap of every launch position over the last N complete steps
+of equal launch count, and where the process's copy kernels (__amd_rocclr_copyBuffer) fall: inside those steps or before them.
 """
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -24,3 +27,27 @@ for s, e, n, g in ev[a:b]:
     tot_gap += max(gap, 0); tot_busy += (e - s) / 1e3
     prev_end = max(prev_end, e)
 print(f"step span {(ev[b - 1][1] - ev[a - 1][1]) / 1e3:.1f} us, kernels {b - a}, sum of durations {tot_busy:.1f} us, sum of positive gaps {tot_gap:.1f} us")
+
+navg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if navg > 0:
+    L = b - a
+    steps = [(ends[k] + 1, ends[k + 1] + 1) for k in range(len(ends) - 1) if ends[k + 1] - ends[k] == L][-navg - 1:-1]
+    if steps:
+        dur = [0.0] * L; gap = [0.0] * L; gmax = [0.0] * L
+        for (x, y) in steps:
+            pe = ev[x - 1][1]
+            for j in range(L):
+                s_, e_, _, _ = ev[x + j]
+                g_ = (s_ - pe) / 1e3
+                dur[j] += (e_ - s_) / 1e3; gap[j] += max(g_, 0.0); gmax[j] = max(gmax[j], g_)
+                pe = max(pe, e_)
+        n = len(steps)
+        print(f"\nmean over the last {n} steps of {L} launches: position, mean dur_us, mean gap_us (max), kernel")
+        for j in range(L):
+            flag = "  <-- gap" if gap[j] / n > 1.0 else ""
+            print(f"{j:3d} {dur[j] / n:8.1f} {gap[j] / n:7.2f} ({gmax[j]:5.1f})  {ev[a + j][2]}{flag}")
+        print(f"mean step: sum of durations {sum(dur) / n:.1f} us, sum of positive gaps {sum(gap) / n:.2f} us")
+        t_first = ev[steps[0][0]][0]
+        copies = [e for e in ev if "copyBuffer" in e[2]]
+        inside = [e for e in copies if e[0] >= t_first]
+        print(f"copy kernels in the whole trace: {len(copies)}; inside those {n} steps: {len(inside)} (the rest precede them: parameter uploads at model load)")

@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--hwd", type=int, nargs=3, default=[128, 128, 128])
     ap.add_argument("--mc", type=int, default=128)
     ap.add_argument("--one-handle", action="store_true", help="chains share ONE model object via lanes (the product form)")
+    ap.add_argument("--chains-batched", type=int, nargs="*", default=[], help="also run this many chains of each --batches size")
     ap.add_argument("--trace-steps", type=int, default=0)
     args = ap.parse_args()
 
@@ -61,10 +62,13 @@ def main():
 
     def chain(i, batch):
         diffusion = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True, timestep_respacing="")
-        m = model(i)
+        m = model(0 if args.one_handle else i)
         while True:
             for out in diffusion.p_sample_loop_progressive(m, (batch, 12, H + D, W + D), model_kwargs=kw):
                 yield out
+
+    import contextlib
+    lane = (lambda i: model(0).lane(i)) if args.one_handle else (lambda i: contextlib.nullcontext())
 
     def spin(stream, us):
         if us <= 0:
@@ -79,7 +83,7 @@ def main():
         with torch.no_grad():
             for _ in range(warmup):
                 for i in range(n):
-                    with torch.cuda.stream(streams[i]):
+                    with torch.cuda.stream(streams[i]), lane(i):
                         last[i] = next(gens[i])
             torch.cuda.synchronize()
             for i in range(1, n):
@@ -92,7 +96,7 @@ def main():
             th0 = time.perf_counter()
             for _ in range(steps):
                 for i in range(n):
-                    with torch.cuda.stream(streams[i]):
+                    with torch.cuda.stream(streams[i]), lane(i):
                         last[i] = next(gens[i])
             host_issue = time.perf_counter() - th0
             for i in range(n):
@@ -125,6 +129,10 @@ def main():
         r = run(1, b, max(20, args.steps // b), max(10, args.warmup // b))
         r["vs_one_chain"] = round(r["sample_steps_per_s"] / base, 4) if base else None
         print(json.dumps(dict(r, env=env, form="one chain, batched (the reference's way, src/sample.py:33-38)")), flush=True)
+        for n in args.chains_batched:
+            r = run(n, b, max(20, args.steps // b), max(10, args.warmup // b), args.stagger * 850.0 * b / n)
+            r["vs_one_chain"] = round(r["sample_steps_per_s"] / base, 4) if base else None
+            print(json.dumps(dict(r, env=env, form=f"{n} chains of batch {b}")), flush=True)
     return 0
 
 
