@@ -141,8 +141,8 @@ def test_sample_cli_chains_write_the_same_files(tmp_path):
         else:
             os.environ["S3D_SAMPLE_CHAINS"] = env
         try:
-            args = sample_args(["--tag", tag, "--n_samples", "4", "--output", name, "--use_ddim", "True", "--timestep_respacing", "10",
-                                "--diff_batch_size", str(bs)])
+            args = sample_args(["--tag", tag, "--n_samples", "4", "--output", name, "--use_ddim", "True", "--timestep_respacing", "10"])
+            args.diff_batch_size = bs                  # (the reference's sample.py reads it from the experiment's diffusion args, src/sample.py:33)
             paths = sample.sample_diffusion(args)
         finally:
             os.environ.pop("S3D_SAMPLE_CHAINS", None)
