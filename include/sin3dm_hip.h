@@ -256,15 +256,22 @@ S3D_API int s3d_unet_backward(s3d_unet* m, const float* d_out, float* grads, voi
  * emb_layers.* are final when the call's work is. */
 S3D_API int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void* stream, void** events, int n_events);
 
-/* q_sample (:189-207): x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise; tables fp32 [T] on the device, t int64 [B] */
-S3D_API int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
-                               const int64_t* t, int B, int64_t per_sample, float* x_t, void* stream);
-/* terms[b][p] = mean((target_p - out_p)^2) over plane p of the composed maps (:838-845); workspace: 96*B floats */
-S3D_API int s3d_train_mse_terms(const float* model_out, const float* target, int B, int C, int H, int W, int D,
-                                float* workspace, float* terms, void* stream);
-/* d_out = d( sum_{b,p} weight[b][p] * terms[b][p] ) / d model_out ; weight: [B][3] on the device */
-S3D_API int s3d_train_mse_grad(const float* model_out, const float* target, const float* weight, int B, int C, int H,
-                               int W, int D, float* d_out, void* stream);
+/* q_sample (:189-207): x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise; tables fp32 [T] on the device, t int64 [B].
+ * x0_batch_stride: elements between the batch rows of x0 — per_sample, or 0 when the batch is ONE training triplane expanded
+ * (what the reference's data iterator yields, src/utils/triplane_util.py:64-69): no materialised copy of the batch is needed. */
+S3D_API int s3d_train_q_sample(const float* x0, int64_t x0_batch_stride, const float* noise, const float* sqrt_ac,
+                               const float* sqrt_1mac, const int64_t* t, int B, int64_t per_sample, float* x_t, void* stream);
+/* terms[b][0..2] = mean((target_p - out_p)^2) over plane p = xy, xz, yz of the composed maps (:838-845), terms[b][3] =
+ * (xy + xz) + yz, the reference's terms["loss"] in its order (:851); terms: [B][4]; workspace: 96*B floats;
+ * target_batch_stride: C*(H+D)*(W+D), or 0 for one target shared by the batch */
+S3D_API int s3d_train_mse_terms(const float* model_out, const float* target, int64_t target_batch_stride, int B, int C, int H,
+                                int W, int D, float* workspace, float* terms, void* stream);
+/* d_out = d( sum_{b,p} w[b][p] * terms[b][p] ) / d model_out with w[b][p] = weight[b][weight_cols == 3 ? p : 0] /
+ * weight_divisor; weight: [B][weight_cols] on the device, weight_cols 1 or 3 (the trainer's loss = mean_b(weights[b] *
+ * loss[b]) is weight_cols 1, weight_divisor B: train_util.py:229) */
+S3D_API int s3d_train_mse_grad(const float* model_out, const float* target, int64_t target_batch_stride, const float* weight,
+                               int weight_cols, float weight_divisor, int B, int C, int H, int W, int D, float* d_out,
+                               void* stream);
 /* torch.optim.AdamW step `step` (1-based) on the flat vectors, then update_ema (src/diffusion/nn.py:55-65) of up to
  * 4 EMA copies (device pointers in a host array). */
 S3D_API int s3d_train_adamw_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* const* ema,

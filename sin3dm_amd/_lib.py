@@ -129,12 +129,12 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p]),
     "s3d_unet_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "s3d_unet_backward_marked": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
-    "s3d_train_q_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
+    "s3d_train_q_sample": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int64,
                                      C.c_void_p, C.c_void_p]),
-    "s3d_train_mse_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+    "s3d_train_mse_terms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
-    "s3d_train_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                     C.c_void_p, C.c_void_p]),
+    "s3d_train_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "s3d_train_adamw_ema": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), c_fp, C.c_int,
                                       C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                       C.c_void_p]),

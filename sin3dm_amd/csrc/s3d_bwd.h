@@ -39,7 +39,8 @@ struct DeferredTail {
     struct Bias { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
     std::vector<Red> red;
     std::vector<Bias> bias;
-    int flush(hipStream_t st);
+    // st_red: the stream the partial-sum kernels were enqueued on (the reductions follow them); st: the pass's main stream
+    int flush(hipStream_t st, hipStream_t st_red = nullptr);
 };
 // tail != null: the reduction launch is queued there instead of being enqueued behind the partial kernel
 int launch_wgrad(const WgradArgs& w, hipStream_t st, DeferredTail* tail = nullptr);
@@ -84,11 +85,13 @@ int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, in
 int launch_linear_bwd_w_multi(const float* dy, int dy_stride, const float* in, int B, int I, int in_mode, int nseg, const int* seg_begin,
                               float* const* dW, float* const* db, hipStream_t st);
 
+// x0_bs / tgt_bs: elements between the batch rows of x0 / tgt (0: one row shared by the batch; < 0: dense)
 int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
-                    float* xt, hipStream_t st);
+                    float* xt, hipStream_t st, long long x0_bs = -1);
 constexpr int kMseWsFloats = 3 * 32;     // per sample
-int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st);
-int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st);
+int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st, long long tgt_bs = -1);
+int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st,
+                    long long tgt_bs = -1, int wcols = 3, float wdiv = 1.0f);
 int launch_adamw_ema(float* p, const float* g, float* m, float* v, float* const* ema, const float* ema_rate, int n_ema, long long n,
                      float lr, float b1, float b2, float eps, float wd, int step, hipStream_t st);
 

@@ -604,7 +604,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedMultiArgs m) {
     if (J.wino) wgrad_wino_reduce_block(J.r, bx, p);
     else wgrad_reduce_block(J.r, bx, p);
 }
-int DeferredTail::flush(hipStream_t st) {
+int DeferredTail::flush(hipStream_t st, hipStream_t st_red) {
+    if (!st_red) st_red = st;
     for (size_t i0 = 0; i0 < red.size(); i0 += kTailJobs) {
         RedMultiArgs m;
         m.njobs = int(std::min(red.size() - i0, size_t(kTailJobs)));
@@ -621,7 +622,7 @@ int DeferredTail::flush(hipStream_t st) {
             blocks += J.bx * r.nplanes;
         }
         m.begin[m.njobs] = blocks;
-        if (blocks) { hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, st, m); S3D_HIP(hipGetLastError()); }
+        if (blocks) { hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, st_red, m); S3D_HIP(hipGetLastError()); }
     }
     red.clear();
     for (size_t i0 = 0; i0 < bias.size(); i0 += kTailJobs) {
@@ -1366,19 +1367,23 @@ int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, in
 
 // ------------------------------------------------------------------ diffusion training elementwise pieces
 // q_sample (src/diffusion/gaussian_diffusion.py:189-207): x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps
+// (x0 rows are x0_bs elements apart: 0 for the single training triplane expanded to a batch, utils/triplane_util.py:64-69)
 __global__ void k_q_sample(const float* __restrict__ x0, const float* __restrict__ eps, const float* __restrict__ sa,
                            const float* __restrict__ sb, const int64_t* __restrict__ t, long long per, int B,
-                           float* __restrict__ xt) {
+                           float* __restrict__ xt, long long x0_bs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per * B) return;
     const int b = int(i / per);
-    xt[i] = sa[t[b]] * x0[i] + sb[t[b]] * eps[i];
+    xt[i] = sa[t[b]] * x0[b * x0_bs + (i - b * per)] + sb[t[b]] * eps[i];
 }
 // per-plane mean squared error of the composed maps (:838-851) and its gradient:
 // terms[b][p] = mean over the plane's C*h*w elements of (target - out)^2 ; d_out = 2 (out - target) * wgt[b][p] / n_p
 // (zero in the unused DxD corner).  Deterministic two-stage sum.
 constexpr int kMseChunks = 32;
-struct MseArgs { const float* out; const float* tgt; float* part; float* terms; const float* wgt; float* dout; int B, C, H, W, D; };
+// tgt rows are tgt_bs elements apart (0: one target for the whole batch); terms [B][4]: xy, xz, yz and (xy + xz) + yz — the
+// reference's terms["loss"] in its order (:851); wgt [B][wcols] (wcols 1: per sample, 3: per sample and plane) divided by wdiv
+struct MseArgs { const float* out; const float* tgt; float* part; float* terms; const float* wgt; float* dout; int B, C, H, W, D;
+                 long long tgt_bs; int wcols; float wdiv; };
 __global__ __launch_bounds__(256) void k_mse_partials(MseArgs a) {
     __shared__ double red[256];
     const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
@@ -1390,7 +1395,8 @@ __global__ __launch_bounds__(256) void k_mse_partials(MseArgs a) {
         const int c = int(i % w); long long r = i / w;
         const int rr = int(r % h), ch = int(r / h);
         const size_t k = composed_index(p, a.H, a.W, a.D, a.C, b, ch, rr, c);
-        const float d = a.tgt[k] - a.out[k];
+        const size_t k0 = composed_index(p, a.H, a.W, a.D, a.C, 0, ch, rr, c);
+        const float d = a.tgt[size_t(b) * a.tgt_bs + k0] - a.out[k];
         s += double(d * d);
     }
     red[threadIdx.x] = s;
@@ -1399,13 +1405,17 @@ __global__ __launch_bounds__(256) void k_mse_partials(MseArgs a) {
     if (threadIdx.x == 0) a.part[(size_t(b) * 3 + p) * kMseChunks + chunk] = float(red[0]);
 }
 __global__ void k_mse_finalize(MseArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.B * 3) return;
-    const int p = idx % 3;
-    const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
-    double s = 0;
-    for (int k = 0; k < kMseChunks; ++k) s += a.part[size_t(idx) * kMseChunks + k];
-    a.terms[idx] = float(s / (double(a.C) * h * w));
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    float t3[3];
+    for (int p = 0; p < 3; ++p) {
+        const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
+        double s = 0;
+        for (int k = 0; k < kMseChunks; ++k) s += a.part[(size_t(b) * 3 + p) * kMseChunks + k];
+        t3[p] = float(s / (double(a.C) * h * w));
+        a.terms[b * 4 + p] = t3[p];
+    }
+    a.terms[b * 4 + 3] = (t3[0] + t3[1]) + t3[2];
 }
 __global__ void k_mse_grad(MseArgs a) {
     const long long per = (long long)a.C * (a.H + a.D) * (a.W + a.D);
@@ -1417,29 +1427,33 @@ __global__ void k_mse_grad(MseArgs a) {
     if (!(Y >= a.H && X >= a.W)) {
         const int p = Y >= a.H ? 2 : (X >= a.W ? 1 : 0);
         const int h = p == 2 ? a.W : a.H, w = p == 0 ? a.W : a.D;
-        g = 2.0f * (a.out[i] - a.tgt[i]) * a.wgt[b * 3 + p] / float((long long)a.C * h * w);
+        const float wv = a.wgt[b * a.wcols + (a.wcols == 3 ? p : 0)] / a.wdiv;
+        g = 2.0f * (a.out[i] - a.tgt[(long long)b * a.tgt_bs + (i - (long long)b * per)]) * wv / float((long long)a.C * h * w);
     }
     a.dout[i] = g;
 }
 int launch_q_sample(const float* x0, const float* eps, const float* sa, const float* sb, const int64_t* t, long long per, int B,
-                    float* xt, hipStream_t st) {
+                    float* xt, hipStream_t st, long long x0_bs) {
     const long long n = per * B;
     if (!n) return 0;
-    hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, eps, sa, sb, t, per, B, xt);
+    hipLaunchKernelGGL(k_q_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x0, eps, sa, sb, t, per, B, xt, x0_bs < 0 ? per : x0_bs);
     S3D_HIP(hipGetLastError());
     return 0;
 }
-int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st) {
-    MseArgs a{out, tgt, ws, terms, nullptr, nullptr, B, C, H, W, D};
+int launch_mse_terms(const float* out, const float* tgt, int B, int C, int H, int W, int D, float* ws, float* terms, hipStream_t st, long long tgt_bs) {
+    const long long per = (long long)C * (H + D) * (W + D);
+    MseArgs a{out, tgt, ws, terms, nullptr, nullptr, B, C, H, W, D, tgt_bs < 0 ? per : tgt_bs, 3, 1.0f};
     if (!B) return 0;
     hipLaunchKernelGGL(k_mse_partials, dim3(kMseChunks, 3, B), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_mse_finalize, dim3(cdiv(B * 3, 64)), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_mse_finalize, dim3(cdiv(B, 64)), dim3(64), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
-int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st) {
-    MseArgs a{out, tgt, nullptr, nullptr, wgt, dout, B, C, H, W, D};
+int launch_mse_grad(const float* out, const float* tgt, const float* wgt, int B, int C, int H, int W, int D, float* dout, hipStream_t st,
+                    long long tgt_bs, int wcols, float wdiv) {
+    const long long per = (long long)C * (H + D) * (W + D);
+    MseArgs a{out, tgt, nullptr, nullptr, wgt, dout, B, C, H, W, D, tgt_bs < 0 ? per : tgt_bs, wcols, wdiv};
     const long long n = (long long)B * C * (H + D) * (W + D);
     if (!n) return 0;
     hipLaunchKernelGGL(k_mse_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);

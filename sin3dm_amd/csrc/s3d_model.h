@@ -126,6 +126,10 @@ struct s3d_unet {
     std::vector<ResBlockWT> in_blocks_t, out_blocks_t;
     Tape tape;
     const float* tdev(size_t off) const { return static_cast<const float*>(tbuf.p) + off; }
+    // backward pass: the weight-gradient launches (no consumer before the optimizer) run on a handle-owned side stream beside the
+    // chain that carries the input gradients (s3d_train.hip: Bwd::fork / join)
+    hipStream_t bwd_side = nullptr;
+    std::vector<hipEvent_t> bwd_events;
 
     // optional live timing of the convolution launches (s3d_unet_profile)
     struct ProfRec { int cls; hipEvent_t e0, e1; double flops, mfma_flops; };
@@ -177,6 +181,8 @@ struct s3d_unet {
         return rc;
     }
     ~s3d_unet() {
+        for (auto e : bwd_events) (void)hipEventDestroy(e);
+        if (bwd_side) (void)hipStreamDestroy(bwd_side);
         for (auto& r : prof_recs) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
         for (auto e : prof_pool) (void)hipEventDestroy(e);
     }

@@ -20,6 +20,37 @@ struct Bwd {
     float* grads;                 // flat, same layout as the parameters
     float* dfilm = nullptr;       // [B][film_total]
     DeferredTail tail;            // the pass's split-K reductions and bias gradients, run in batches (before each progress mark)
+    // Weight gradients have no consumer inside the pass: they go to a side stream (`sst`; == st when S3D_BWD_SIDE=0) and run
+    // beside the main chain (dgrad -> edge sums -> mean-vector gradients -> GroupNorm backward -> next dgrad), whose many
+    // one-round launches leave the matrix cores idle.  fork(): the side stream waits for what the main stream has enqueued so
+    // far (one event, no cost to the main chain beyond the record); join(): the main stream waits for the side stream (before a
+    // progress mark and at the end of the pass).  Same kernels on the same operands: the gradients are bit-identical.
+    hipStream_t sst = nullptr;
+    size_t ev_next = 0;
+    int fork() {
+        if (sst == st) return 0;
+        if (ev_next == m->bwd_events.size()) {
+            hipEvent_t e = nullptr;
+            S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->bwd_events.push_back(e);
+        }
+        hipEvent_t e = m->bwd_events[ev_next++];
+        S3D_HIP(hipEventRecord(e, st));
+        S3D_HIP(hipStreamWaitEvent(sst, e, 0));
+        return 0;
+    }
+    int join() {
+        if (sst == st) return 0;
+        if (ev_next == m->bwd_events.size()) {
+            hipEvent_t e = nullptr;
+            S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->bwd_events.push_back(e);
+        }
+        hipEvent_t e = m->bwd_events[ev_next++];
+        S3D_HIP(hipEventRecord(e, sst));
+        S3D_HIP(hipStreamWaitEvent(st, e, 0));
+        return 0;
+    }
     Arena& ar() { return m->arena; }
     bool meas() { return m->arena.measuring; }
 
@@ -44,6 +75,7 @@ struct Bwd {
         const Geo& g = dy.g;
         const int cin = cw.cin, cout = cw.cout, taps = cw.k * cw.k;
         const bool roll = cw.rollout && nt && nt->roll;
+        bool forked = false;
         // (1) dgrad of the own channels
         if (d_a) {
             *d_a = alloc_tri(cin, g);
@@ -90,7 +122,9 @@ struct Bwd {
                     sw.rowvec[p] = rowvec[p]; sw.colvec[p] = colvec[p]; sw.R[p] = R[p]; sw.Cs[p] = Cs[p]; sw.dW[p] = dW[p];
                 }
                 sw.g = g; sw.B = B; sw.C = cin; sw.cout = cout;
-                S3D_TRY(launch_slot_wgrad(sw, st));
+                S3D_TRY(fork());                                  // (the edge sums — and dy before them — are enqueued)
+                forked = true;
+                S3D_TRY(launch_slot_wgrad(sw, sst));
                 // gradients of the six mean vectors: 1-D transposed convolutions of the edge sums (k_rank1)
                 ConvArgs ca; memset(&ca, 0, sizeof ca);
                 ca.B = B; ca.cin = 3 * cout; ca.cout = cin; ca.njobs = 6;
@@ -117,7 +151,10 @@ struct Bwd {
             w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps));
             w.dW[p] = dW[p];
         }
-        if (!meas()) S3D_TRY(launch_wgrad(w, st, &tail));
+        if (!meas()) {
+            if (!forked) S3D_TRY(fork());
+            S3D_TRY(launch_wgrad(w, sst, &tail));
+        }
         return 0;
     }
 
@@ -174,6 +211,12 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
     Bwd b{m, B, st, grads};
     Arena& ar = m->arena;
     const bool meas = ar.measuring;
+    static const bool side_on = !(getenv("S3D_BWD_SIDE") && strcmp(getenv("S3D_BWD_SIDE"), "0") == 0);
+    b.sst = st;
+    if (!meas && side_on) {
+        if (!m->bwd_side) S3D_HIP(hipStreamCreateWithFlags(&m->bwd_side, hipStreamNonBlocking));
+        b.sst = m->bwd_side;
+    }
     b.dfilm = ar.alloc<float>(size_t(B) * m->film_total);
 
     // ---- out head: GN -> SiLU -> 1x1 conv -> compose
@@ -225,8 +268,8 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         d_h = d_prev;
     }
 
-    if (!meas) S3D_TRY(b.tail.flush(st));             // (the output blocks' weight / bias gradients are final at mark 0)
-    if (!meas && n_marks > 0 && marks[0]) S3D_HIP(hipEventRecord(marks[0], st));
+    if (!meas) S3D_TRY(b.tail.flush(st, b.sst));      // (the output blocks' weight / bias gradients are final at mark 0)
+    if (!meas && n_marks > 0 && marks[0]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[0], st)); }
 
     // ---- input blocks, deepest to first
     Tri d_x;                                        // gradient of the current level's resblock input
@@ -263,8 +306,8 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         }
     }
 
-    if (!meas) S3D_TRY(b.tail.flush(st));             // (... the input blocks' at mark 1; the per-sample bias sums feed the timestep MLP below)
-    if (!meas && n_marks > 1 && marks[1]) S3D_HIP(hipEventRecord(marks[1], st));
+    if (!meas) S3D_TRY(b.tail.flush(st, b.sst));      // (... the input blocks' at mark 1; the per-sample bias sums feed the timestep MLP below)
+    if (!meas && n_marks > 1 && marks[1]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[1], st)); }
 
     // ---- timestep MLP: film = Lf(silu(emb)), emb = L2(silu(pre1)), pre1 = L0(temb(t))
     {
@@ -301,6 +344,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
                                       nullptr, st));
         }
     }
+    if (!meas) S3D_TRY(b.join());                     // every gradient of the pass is final in stream order of `st`
     return 0;
 }
 
@@ -407,22 +451,27 @@ int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void
     return rc_b;
 }
 
-int s3d_train_q_sample(const float* x0, const float* noise, const float* sqrt_ac, const float* sqrt_1mac, const int64_t* t, int B,
-                       int64_t per_sample, float* x_t, void* stream) {
+int s3d_train_q_sample(const float* x0, int64_t x0_batch_stride, const float* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                       const int64_t* t, int B, int64_t per_sample, float* x_t, void* stream) {
     S3D_CHECK(x0 && noise && sqrt_ac && sqrt_1mac && t && x_t, S3D_ERR_INVALID, "q_sample: null argument");
-    return launch_q_sample(x0, noise, sqrt_ac, sqrt_1mac, t, per_sample, B, x_t, static_cast<hipStream_t>(stream));
+    S3D_CHECK(x0_batch_stride == 0 || x0_batch_stride == per_sample, S3D_ERR_INVALID, "q_sample: x0_batch_stride must be 0 or per_sample");
+    return launch_q_sample(x0, noise, sqrt_ac, sqrt_1mac, t, per_sample, B, x_t, static_cast<hipStream_t>(stream), x0_batch_stride);
 }
 
-int s3d_train_mse_terms(const float* model_out, const float* target, int B, int C, int H, int W, int D, float* workspace,
-                        float* terms, void* stream) {
+int s3d_train_mse_terms(const float* model_out, const float* target, int64_t target_batch_stride, int B, int C, int H, int W, int D,
+                        float* workspace, float* terms, void* stream) {
     S3D_CHECK(model_out && target && workspace && terms, S3D_ERR_INVALID, "mse_terms: null argument");
-    return launch_mse_terms(model_out, target, B, C, H, W, D, workspace, terms, static_cast<hipStream_t>(stream));
+    S3D_CHECK(target_batch_stride == 0 || target_batch_stride == (int64_t)C * (H + D) * (W + D), S3D_ERR_INVALID, "mse_terms: target_batch_stride must be 0 or C*(H+D)*(W+D)");
+    return launch_mse_terms(model_out, target, B, C, H, W, D, workspace, terms, static_cast<hipStream_t>(stream), target_batch_stride);
 }
 
-int s3d_train_mse_grad(const float* model_out, const float* target, const float* weight, int B, int C, int H, int W, int D,
-                       float* d_out, void* stream) {
+int s3d_train_mse_grad(const float* model_out, const float* target, int64_t target_batch_stride, const float* weight, int weight_cols,
+                       float weight_divisor, int B, int C, int H, int W, int D, float* d_out, void* stream) {
     S3D_CHECK(model_out && target && weight && d_out, S3D_ERR_INVALID, "mse_grad: null argument");
-    return launch_mse_grad(model_out, target, weight, B, C, H, W, D, d_out, static_cast<hipStream_t>(stream));
+    S3D_CHECK(weight_cols == 1 || weight_cols == 3, S3D_ERR_INVALID, "mse_grad: weight_cols must be 1 or 3");
+    S3D_CHECK(target_batch_stride == 0 || target_batch_stride == (int64_t)C * (H + D) * (W + D), S3D_ERR_INVALID, "mse_grad: target_batch_stride must be 0 or C*(H+D)*(W+D)");
+    return launch_mse_grad(model_out, target, weight, B, C, H, W, D, d_out, static_cast<hipStream_t>(stream), target_batch_stride,
+                           weight_cols, weight_divisor);
 }
 
 int s3d_train_adamw_ema(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* const* ema,

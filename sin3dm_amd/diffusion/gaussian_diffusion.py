@@ -454,15 +454,17 @@ class GaussianDiffusion:
         return tab
 
     def q_sample_hip(self, x_start, t, noise):
-        """q_sample (:189-207) as one kernel: the coefficient gather happens on the device."""
+        """q_sample (:189-207) as one kernel: the coefficient gather happens on the device.  x_start may be one triplane
+        expanded to a batch (batch stride 0 — what the reference's data iterator yields): it is read in place."""
         _lib.require_gpu(x_start)
-        x0, eps = x_start.contiguous().float(), noise.contiguous().float()
+        x0, bs = _batch_rows(x_start)
+        eps = noise.contiguous().float()
         tab = self._train_tables(x0.device)
         t64 = t.to(device=x0.device, dtype=th.int64).contiguous()
-        x_t = th.empty_like(x0)
+        x_t = th.empty(x_start.shape, device=x0.device, dtype=th.float32)
         with th.cuda.device(x0.device):
-            _lib.check(_lib.load().s3d_train_q_sample(_lib.ptr(x0), _lib.ptr(eps), _lib.ptr(tab[0]), _lib.ptr(tab[1]),
-                                                      _lib.ptr(t64), x0.shape[0], x0[0].numel(), _lib.ptr(x_t),
+            _lib.check(_lib.load().s3d_train_q_sample(_lib.ptr(x0), bs, _lib.ptr(eps), _lib.ptr(tab[0]), _lib.ptr(tab[1]),
+                                                      _lib.ptr(t64), x_t.shape[0], x_t[0].numel(), _lib.ptr(x_t),
                                                       _lib.stream_ptr()))
         return x_t
 
@@ -488,7 +490,7 @@ class GaussianDiffusion:
             noise = th.randn_like(x_start)
         x_t = self.q_sample_hip(x_start, t, noise)
         model_output = model(x_t, self._scale_timesteps(t), **model_kwargs)
-        target = self._training_target(x_start, x_t, t, noise).contiguous().float()
+        target = self._training_target(x_start, x_t, t, noise)
         assert model_output.shape == target.shape == x_start.shape
         H, W, D = model_kwargs["H"], model_kwargs["W"], model_kwargs["D"]
         mse = _TriplaneMSE.apply(model_output, target, int(H), int(W), int(D))       # [N, 3]
@@ -498,37 +500,54 @@ class GaussianDiffusion:
 
     def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None, grad_marks=None):
         """Fast path of TrainLoop.forward_backward (train_util.py:205-236) without an autograd graph:
-        loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`)."""
+        loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`).
+        Torch launches nothing here besides the noise draw: the batch is read where it lies (an expanded triplane included),
+        the per-sample loss — (xy + xz) + yz, the reference's order (:851) — is the fourth column of the terms kernel, the
+        weights / N of the mean are applied inside the gradient kernel."""
         if noise is None:
-            noise = th.randn_like(x_start)
+            noise = th.randn(x_start.shape, device=x_start.device, dtype=th.float32)
         H, W, D = (int(model_kwargs[k]) for k in "HWD")
         x_t = self.q_sample_hip(x_start, t, noise)
         out = model.forward_train(x_t, self._model_timesteps(t), H, W, D)
-        target = self._training_target(x_start, x_t, t, noise).contiguous().float()
-        mse = _mse_terms(out, target, H, W, D)
-        wgt = (weights.to(out.device, th.float32)[:, None].expand(-1, 3) / out.shape[0]).contiguous()      # [N, 3]: one kernel (the quotient of a broadcast view is already dense)
-        g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D), out=grad_out, **({"marks": grad_marks} if grad_marks else {}))
-        terms = {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2]}
-        terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]       # the reference's order (:851), as training_losses
-        return terms, g
+        target = self._training_target(x_start, x_t, t, noise)
+        mse = _mse_terms(out, target, H, W, D)                                          # [N, 4]
+        wgt = weights.to(out.device, th.float32).contiguous()                            # [N]
+        g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D, divisor=float(out.shape[0])), out=grad_out,
+                                **({"marks": grad_marks} if grad_marks else {}))
+        return {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2], "loss": mse[:, 3]}, g
+
+
+def _batch_rows(x):
+    """(fp32 tensor whose data pointer is row 0, elements between batch rows) of a [B, ...] tensor: dense, or 0 for one row
+    expanded to a batch; anything else is materialised."""
+    x = x.float()
+    per = x[0].numel() if x.shape[0] else 0
+    if x.dim() >= 2 and x.shape[0] and x[0].is_contiguous() and (x.stride(0) == per or (x.stride(0) == 0) or x.shape[0] == 1):
+        return x, (per if x.shape[0] == 1 else int(x.stride(0)))
+    return x.contiguous(), per
 
 
 def _mse_terms(out, target, H, W, D):
+    """[B, 4]: the per-plane mean squared errors and their sum (xy + xz) + yz."""
     B, Cc = out.shape[:2]
-    terms = th.empty((B, 3), device=out.device, dtype=th.float32)
+    tgt, bs = _batch_rows(target)
+    terms = th.empty((B, 4), device=out.device, dtype=th.float32)
     ws = th.empty(96 * B, device=out.device, dtype=th.float32)
     with th.cuda.device(out.device):
-        _lib.check(_lib.load().s3d_train_mse_terms(_lib.ptr(out), _lib.ptr(target), B, Cc, H, W, D, _lib.ptr(ws),
+        _lib.check(_lib.load().s3d_train_mse_terms(_lib.ptr(out), _lib.ptr(tgt), bs, B, Cc, H, W, D, _lib.ptr(ws),
                                                    _lib.ptr(terms), _lib.stream_ptr()))
     return terms
 
 
-def _mse_grad(out, target, wgt, H, W, D):
+def _mse_grad(out, target, wgt, H, W, D, divisor=1.0):
+    """wgt: [B] (per sample) or [B, 3] (per sample and plane), divided by `divisor` inside the kernel."""
     B, Cc = out.shape[:2]
+    tgt, bs = _batch_rows(target)
+    cols = 1 if wgt.dim() == 1 else int(wgt.shape[1])
     d_out = th.empty_like(out)
     with th.cuda.device(out.device):
-        _lib.check(_lib.load().s3d_train_mse_grad(_lib.ptr(out), _lib.ptr(target), _lib.ptr(wgt), B, Cc, H, W, D,
-                                                  _lib.ptr(d_out), _lib.stream_ptr()))
+        _lib.check(_lib.load().s3d_train_mse_grad(_lib.ptr(out), _lib.ptr(tgt), bs, _lib.ptr(wgt), cols, float(divisor), B, Cc,
+                                                  H, W, D, _lib.ptr(d_out), _lib.stream_ptr()))
     return d_out
 
 
@@ -540,7 +559,7 @@ class _TriplaneMSE(th.autograd.Function):
         out = out.contiguous().float()
         ctx.save_for_backward(out, target)
         ctx.hwd = (H, W, D)
-        return _mse_terms(out, target, H, W, D)
+        return _mse_terms(out, target, H, W, D)[:, :3].contiguous()
 
     @staticmethod
     def backward(ctx, g):

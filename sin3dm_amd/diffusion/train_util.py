@@ -103,6 +103,7 @@ class TrainLoop:
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.global_batch = self.batch_size * self.world
         self._kvs = {}
+        self._pending_losses = []
         self._t_last = None
 
         if resume_checkpoint:
@@ -180,7 +181,8 @@ class TrainLoop:
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
         if self.step % 10 == 0:
-            self.log_loss_dict(t, {k: v * weights for k, v in losses.items()})
+            # the values stay on the device until they are printed (dumpkvs): reading them here would drain the GPU queue
+            self._pending_losses.append((t, weights, losses))
 
     def _anneal_lr(self):
         if not self.lr_anneal_steps:
@@ -211,6 +213,9 @@ class TrainLoop:
                 self.logkv(f"{key}_q{quartile}", float(sub_loss))
 
     def dumpkvs(self):
+        for t, weights, losses in self._pending_losses:           # (in step order: a later step's value of a key replaces an earlier one's, as before)
+            self.log_loss_dict(t, {k: v * weights for k, v in losses.items()})
+        self._pending_losses = []
         now = time.time()
         if self._t_last is not None:
             self.logkv("sec_per_step", (now - self._t_last) / max(self.log_interval, 1))

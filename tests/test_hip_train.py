@@ -424,3 +424,46 @@ def test_backward_progress_marks_and_overlapped_exchange_groups():
         assert bool((out.index_select(0, idx[k]) == POISON).all()), f"a kernel wrote a gradient range of group {k} after its mark"
     for b, e in groups[2]:                               # the late group (timestep linears) is final at the end of the pass
         assert torch.equal(out[b:e], g_plain[b:e])
+
+
+def _flat_grad_digest(expand):
+    """sha256 of the flat gradient + loss terms of one graph-free training step at a size whose backward pass is GPU-bound."""
+    import hashlib
+    import torch
+    m = _model(64)
+    diffusion = _diffusion()
+    H, W, D, B = 48, 64, 40, 3
+    dev = torch.device("cuda:0")
+    x1 = torch.from_numpy(T.synthetic_noise((12, H + D, W + D), 410)).clamp(-1, 1).to(dev)
+    x0 = x1.unsqueeze(0).expand(B, -1, -1, -1) if expand else x1.unsqueeze(0).repeat(B, 1, 1, 1)
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 411)).to(dev)
+    t = torch.tensor([700, 3, 250], device=dev)
+    w = torch.tensor([1.0, 0.5, 2.0], device=dev)
+    h = hashlib.sha256()
+    for _ in range(3):                                   # (the side stream's hand-offs must hold when passes follow each other)
+        terms, g = diffusion.training_losses_and_grads(m, x0, t, w, dict(H=H, W=W, D=D), noise=noise)
+        torch.cuda.synchronize()
+        h.update(g.cpu().numpy().tobytes())
+        for k in ("mse_xy", "mse_xz", "mse_yz", "loss"):
+            h.update(terms[k].cpu().numpy().tobytes())
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    assert torch.equal(terms["loss"], (terms["mse_xy"] + terms["mse_xz"]) + terms["mse_yz"])
+    return h.hexdigest()
+
+
+def test_weight_gradients_on_the_side_stream_change_no_bit():
+    """The backward pass enqueues every weight-gradient launch (k_wgrad_wino / k_wgrad_mfma / k_slot_wgrad and their split-K
+    reductions) on a handle-owned side stream beside the chain of input gradients; S3D_BWD_SIDE=0 keeps them in line.  Same
+    kernels on the same operands: identical gradients, pass after pass.  Also: the single training triplane expanded to a batch
+    (batch stride 0, utils/triplane_util.py:64-69) is read in place and gives the bits of the materialised batch."""
+    import os, subprocess, sys
+    here = _flat_grad_digest(expand=True)
+    assert here == _flat_grad_digest(expand=False)
+    code = ("import sys; sys.path.insert(0, 'tests')\n"
+            "import test_hip_train as tt\n"
+            "print('DIGEST', tt._flat_grad_digest(expand=True))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_BWD_SIDE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    inline = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+    assert inline == here

@@ -291,41 +291,76 @@ import os, sys, time
 sys.path.insert(0, os.environ["S3D_REPO"])
 from sin3dm_amd import parallel, train
 rank = int(os.environ["RANK"])
+only_enc = os.environ["ONLY_ENC"] == "1"
 calls = []
 def slow_stage1(args):                                    # stands in for ShapeAutoEncoder.train (minutes on a real shape)
     time.sleep(float(os.environ["FAKE_STAGE1_S"]))
     calls.append("ae")
     open(os.path.join(args.tag, "encoding", "feat.npz"), "wb").close()
 train.train_ae = slow_stage1
+train.train_diffusion = lambda args, rank=0: calls.append("diffusion")      # stage 2 needs a GPU: what is under test comes before it
+train.dist_util.dev = lambda: None
+# the process group is created after stage 1, with a timeout SHORTER than stage 1 took: had the ranks been parked in a
+# collective (or in the rendezvous) during stage 1, this would have expired
+real_init = parallel.init
+parallel.init = lambda device=None: real_init(backend="gloo", timeout_s=float(os.environ["FAKE_STAGE1_S"]) * 0.75)
 t0 = time.time()
-train.main(["--tag", os.environ["EXP"], "--data_path", "unused.npz", "--only_enc"], confirm=lambda q: "y")
+train.main(["--tag", os.environ["EXP"], "--data_path", "unused.npz"] + (["--only_enc"] if only_enc else []), confirm=lambda q: "y")
 waited = time.time() - t0
-assert os.path.exists(os.path.join(os.environ["EXP"], "encoding", "feat.npz"))       # every rank returns AFTER stage 1
-assert (calls == ["ae"]) == (rank == 0)
-# the process group is created only now, with a timeout SHORTER than stage 1 took: had the ranks been parked in a collective
-# (or in the rendezvous) during stage 1, this would have expired
-parallel.init(backend="gloo", timeout_s=float(os.environ["FAKE_STAGE1_S"]) * 0.75)
-parallel.barrier()
+if only_enc:
+    assert calls == (["ae"] if rank == 0 else [])         # nothing follows stage 1: the other ranks neither wait nor run anything
+else:
+    assert os.path.exists(os.path.join(os.environ["EXP"], "encoding", "feat.npz"))       # every rank comes out AFTER stage 1
+    assert calls == (["ae", "diffusion"] if rank == 0 else ["diffusion"])
 print("RESULT %d %.2f" % (rank, waited))
 """
 
 
-def test_train_cli_ranks_wait_for_stage1_outside_any_collective(tmp_path):
-    """python -m sin3dm_amd.train on N ranks: rank 0 runs the auto-encoder stage (src/train.py:8-29) before torch.distributed is
-    initialised; the other ranks wait for its marker file — not in a barrier whose watchdog would abort the job when stage 1
-    outlasts the collective timeout (25 000 iterations x 6.3 ms is already 160 s)."""
+def _run_stage1(tmp_path, only_enc, nproc_env=None):
     script = tmp_path / "stage1_worker.py"
     script.write_text(STAGE1_WORKER)
     exp = tmp_path / "EXP"
     env = dict(os.environ, S3D_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2", EXP=str(exp),
-               FAKE_STAGE1_S="4")
+               FAKE_STAGE1_S="4", ONLY_ENC="1" if only_enc else "0")
+    env.pop("LOCAL_WORLD_SIZE", None)
+    env.update(nproc_env or {})
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=180) for p in procs]
+    return exp, procs, outs
+
+
+def test_train_cli_ranks_wait_for_stage1_outside_any_collective(tmp_path):
+    """python -m sin3dm_amd.train on N ranks: rank 0 runs the auto-encoder stage (src/train.py:8-29) before torch.distributed is
+    initialised; the other ranks wait for its marker file — not in a barrier whose watchdog would abort the job when stage 1
+    outlasts the collective timeout (25 000 iterations x 6.3 ms is already 160 s).  The marker is removed once every
+    rank is past its wait, and a stale one of an earlier launch is cleared by rank 0."""
+    os.makedirs(tmp_path / "EXP")
+    stale = tmp_path / "EXP" / ".stage1_done_run_1_1"
+    stale.write_text("")
+    exp, procs, outs = _run_stage1(tmp_path, only_enc=False)
     for p, (o, err) in zip(procs, outs):
         assert p.returncode == 0, err[-3000:]
     waits = {int(l.split()[1]): float(l.split()[2]) for o, _ in outs for l in o.splitlines() if l.startswith("RESULT ")}
     assert waits[0] >= 4.0 and waits[1] >= 3.0, waits            # rank 1 really waited for rank 0's stage
-    assert any(f.startswith(".stage1_done_") for f in os.listdir(exp))
+    assert not [f for f in os.listdir(exp) if f.startswith(".stage1_done_")], os.listdir(exp)
+
+
+def test_train_cli_only_enc_leaves_no_marker_and_parks_nobody(tmp_path):
+    """--only_enc on N ranks: stage 1 is rank 0's alone and nothing follows it — the other ranks return at once, no marker file is
+    written (it used to stay behind for ever: ADVICE r4)."""
+    exp, procs, outs = _run_stage1(tmp_path, only_enc=True)
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode == 0, err[-3000:]
+    waits = {int(l.split()[1]): float(l.split()[2]) for o, _ in outs for l in o.splitlines() if l.startswith("RESULT ")}
+    assert waits[0] >= 4.0 and waits[1] < 3.0, waits
+    assert not [f for f in os.listdir(exp) if f.startswith(".stage1_done_")]
+
+
+def test_train_cli_refuses_a_multi_node_launch(tmp_path):
+    """The marker's name contains the launcher's pid: ranks of another node would wait for a name nobody writes.  Fail fast."""
+    exp, procs, outs = _run_stage1(tmp_path, only_enc=False, nproc_env={"LOCAL_WORLD_SIZE": "1"})
+    for p, (o, err) in zip(procs, outs):
+        assert p.returncode != 0 and "one node only" in err
