@@ -37,6 +37,27 @@ typedef enum {
 } s3d_status;
 
 S3D_API int s3d_abi_version(void);
+
+/* Process-wide options: which of several kernel forms the library launches.  Every form is parity-tested (tests/test_hip_parity.py,
+ * test_hip_train.py run the golden vectors under each); "bit-identical" forms differ in launch shape only.  name: with or without
+ * the "S3D_" prefix; value: a decimal integer ("naive" / anything else for CONV_IMPL), "" or NULL = back to the library's own choice.
+ * Until s3d_set_option is called for an option, the environment variable S3D_<NAME> (read once, at the option's first use) supplies
+ * its value — the way earlier rounds selected forms; the call is the documented way.  Options are read at every launch; set them
+ * before creating handles: a training handle's repack plan (s3d_unet_train_attach) keeps only the weight images of the forms
+ * selected THEN current.
+ *   WINO          24 (default) mixed Winograd F(2x4,3x3) | 4, 2: F(2x2) | 0: direct MFMA convolution          (rounding differs)
+ *   WINO24W       unset: by launch size | 0 never | 1 always the 64-output-channel block                    (bit-identical)
+ *   VCAT          0: materialise upsample + concat in the output blocks (default: virtual concat)            (rounding differs)
+ *   WGRAD_WINO    0: direct 3x3 weight gradient (default: Winograd)                                          (rounding differs)
+ *   RANK1_SLICES  0: one K slice of the rollout tables (default: two from 256 channels)                      (rounding differs)
+ *   RANK1_BATCH   0: k_rank1, one sample per block (default: k_rank1b / two-sample blocks)                   (bit-identical)
+ *   CONV_IMPL     "naive": one-thread-per-output reference kernels (tests)                                   (rounding differs)
+ *   CONV1X1_T     unset: by launch size | 0 never | 1 always the transposed-accumulator 1x1 epilogue         (bit-identical)
+ *   GN_FUSED      unset: by launch size | 0: GroupNorm partials added ahead of the consumer | 1: inside it   (bit-identical)
+ *   BWD_SIDE      0: the backward pass's weight-gradient launches stay on the caller's stream (default: a side stream) (bit-identical)
+ * s3d_get_option: the current value, -1 when unset. */
+S3D_API int s3d_set_option(const char* name, const char* value);
+S3D_API int s3d_get_option(const char* name, int* value);
 S3D_API const char* s3d_last_error(void);
 /* number of visible HIP devices, or a negative s3d_status: lets the shim fail loudly without torch */
 S3D_API int s3d_device_count(void);

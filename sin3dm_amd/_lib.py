@@ -56,6 +56,8 @@ SIGNATURES = {
     "s3d_abi_version": (C.c_int, []),
     "s3d_last_error": (C.c_char_p, []),
     "s3d_device_count": (C.c_int, []),
+    "s3d_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "s3d_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "s3d_unet_create": (C.c_int, [C.POINTER(UNetCfg), C.POINTER(C.c_void_p)]),
     "s3d_unet_destroy": (None, [C.c_void_p]),
     "s3d_unet_num_params": (C.c_int, [C.c_void_p]),
@@ -194,6 +196,17 @@ def require_gpu(t=None):
     if not torch.cuda.is_available():
         raise Sin3DMHipError("sin3dm_amd needs a visible MI355X (torch.cuda.is_available() is False); "
                              "there is no CPU fallback")
+
+
+def set_option(name, value):
+    """Select a kernel form process-wide (include/sin3dm_hip.h: s3d_set_option); value None = the library's own choice."""
+    check(load().s3d_set_option(str(name).encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(load().s3d_get_option(str(name).encode(), C.byref(v)))
+    return None if v.value == -1 else v.value
 
 
 def stream_ptr():

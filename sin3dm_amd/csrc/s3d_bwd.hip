@@ -567,8 +567,7 @@ __device__ __forceinline__ void wgrad_wino_reduce_block(const Args& a, int bx, i
 }
 __global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) { wgrad_wino_reduce_block(a, blockIdx.x, blockIdx.y); }
 static bool wgrad_use_wino() {
-    static const bool on = !(getenv("S3D_WGRAD_WINO") && atoi(getenv("S3D_WGRAD_WINO")) == 0);
-    return on;
+    return opt_on(OPT_WGRAD_WINO);
 }
 
 struct WgRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, taps, cin_store; };
@@ -651,7 +650,7 @@ static bool wgrad_1x1_wide(int cin, int cout) {
     return 4 * wide <= 5 * narrow;
 }
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps) {
-    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int cus = device_cus();
     long long tiles = 0;
     int planes = 0;
     if (taps == 9 && wgrad_use_wino()) {

@@ -85,6 +85,18 @@ struct Arena {                        // bump allocator over one DevBuf; two-pas
 
 int upload(DevBuf& dst, const void* host, size_t bytes);
 
+// ------------------------------------------------------------------ process-wide options (s3d_set_option / environment)
+// Every kernel-form switch of the library.  Value = what s3d_set_option last stored; before that the environment variable
+// S3D_<NAME> (read once, at the first query of that option); before that the default (kOptUnset for the choices the library
+// makes by launch size).  Queries are a table read: cheap enough for every launch.
+enum Opt { OPT_WINO = 0, OPT_WINO24W, OPT_VCAT, OPT_WGRAD_WINO, OPT_RANK1_SLICES, OPT_RANK1_BATCH, OPT_CONV_IMPL, OPT_CONV1X1_T,
+           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_COUNT };
+constexpr int kOptUnset = -1;
+int opt(Opt o);                       // kOptUnset when neither set nor in the environment
+inline bool opt_on(Opt o) { return opt(o) != 0; }      // switches that default to on: anything but an explicit 0
+// compute units of the CURRENT device (cached per device index: one process may drive several)
+int device_cus();
+
 // ------------------------------------------------------------------ plane geometry
 // The three planes of a triplane: xy[H,W], xz[H,D], yz[W,D]  (src/utils/triplane_util.py:20-25)
 struct Geo {

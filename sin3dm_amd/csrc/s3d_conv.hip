@@ -653,13 +653,11 @@ bool rank1b_takes(const ConvArgs& a) {
     for (int j = 0; j < a.njobs; ++j) if (!a.job[j].wgt_r1f) return false;
     const int nchunks = a.cin / kR1Chunk, maxch = a.r1_slices > 1 ? (nchunks + 1) / 2 : nchunks;
     if (34 * (maxch * kR1Chunk + 4) > kR1bLdsFloats) return false;     // the vector tile must fit the reduction image's 48 KB
-    static const bool on = !(getenv("S3D_RANK1_BATCH") && atoi(getenv("S3D_RANK1_BATCH")) == 0);
-    return on;
+    return opt_on(OPT_RANK1_BATCH);
 }
 
 int conv_rank1_slices(int cin) {
-    static const bool on = !(getenv("S3D_RANK1_SLICES") && atoi(getenv("S3D_RANK1_SLICES")) == 0);
-    return on && cin >= 2 * kR1Chunk && cin % kR1Chunk == 0 ? 2 : 1;
+    return opt_on(OPT_RANK1_SLICES) && cin >= 2 * kR1Chunk && cin % kR1Chunk == 0 ? 2 : 1;
 }
 
 // S3D_CONV_IMPL=naive counterpart of the ROLL3 form: one thread per table entry, plain loops over the same weight image
@@ -710,7 +708,7 @@ int launch_rank1(ConvArgs& a, hipStream_t st, bool roll3) {
         return 0;
     }
     // other widths: k_rank1, two samples per block from batch 2 on (S3D_RANK1_BATCH=0: one): same sums per sample, the weight tiles staged half as often
-    static const bool pair_ok = !(getenv("S3D_RANK1_BATCH") && atoi(getenv("S3D_RANK1_BATCH")) == 0);
+    const bool pair_ok = opt_on(OPT_RANK1_BATCH);
     const int ns = roll3 && pair_ok && a.B >= 2 ? 2 : 1;
     int blocks = 0;
     for (int j = 0; j < a.njobs; ++j) {
@@ -758,12 +756,7 @@ void conv_note_kernel(const char* name) { t_last_kernel = name; }
 const char* conv_last_kernel() { return t_last_kernel; }
 
 bool conv_use_naive() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("S3D_CONV_IMPL");
-        v = (e && strcmp(e, "naive") == 0) ? 1 : 0;
-    }
-    return v == 1;
+    return opt(OPT_CONV_IMPL) == 1;
 }
 
 static void kind_taps(ConvKind kind, int& KH, int& KW) {
@@ -847,7 +840,7 @@ int launch_conv(ConvKind kind, ConvArgs& a, hipStream_t st) {
                 // partials, channel quads — of at least four rounds of blocks: batch 8 0.383 -> 0.357 ms/step, the auto-encoder
                 // iteration 6.31 -> 6.26 ms; the one-round launches of the batch-1 step are a latency chain either way
                 // (0.0693 -> 0.0714 ms/step) and keep the 4-byte epilogue.  S3D_CONV1X1_T=0 never / =1 always (tests).
-                static const int tr_mode = getenv("S3D_CONV1X1_T") ? atoi(getenv("S3D_CONV1X1_T")) : -1;
+                const int tr_mode = opt(OPT_CONV1X1_T);
                 bool plain = tr_mode != 0 && a.cout % 4 == 0;
                 long long blocks = 0;
                 for (int j = 0; j < a.njobs; ++j) {

@@ -672,8 +672,8 @@ bool gn_act_can_add_parts(const GnPartials& part, int C) {
 // Who adds them: the consumer's own blocks (S3D_GN_FUSED=1: always) when the launch is at most two rounds of blocks — one
 // dependent launch less on a latency-bound step —, k_gn_finalize_as ahead of it (S3D_GN_FUSED=0: always) otherwise.  Same bits.
 bool gn_parts_in_consumer(long long consumer_blocks) {
-    static const int mode = getenv("S3D_GN_FUSED") ? atoi(getenv("S3D_GN_FUSED")) : -1;
-    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    const int mode = opt(OPT_GN_FUSED);
+    const int cus = device_cus();
     return mode < 0 ? consumer_blocks <= 6LL * cus : mode != 0;          // two rounds of three blocks per CU (1536 on an MI355X)
 }
 int gn_act_threads(int C) { int cq, pl; thread_shape(C, cq, pl); return cq * std::min(pl, kActCols); }

@@ -211,7 +211,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
     Bwd b{m, B, st, grads};
     Arena& ar = m->arena;
     const bool meas = ar.measuring;
-    static const bool side_on = !(getenv("S3D_BWD_SIDE") && strcmp(getenv("S3D_BWD_SIDE"), "0") == 0);
+    const bool side_on = opt_on(OPT_BWD_SIDE);
     b.sst = st;
     if (!meas && side_on) {
         if (!m->bwd_side) S3D_HIP(hipStreamCreateWithFlags(&m->bwd_side, hipStreamNonBlocking));

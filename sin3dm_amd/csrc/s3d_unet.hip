@@ -300,7 +300,7 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
             const Geo up = h.g.twice();
             {
                 const ResBlockW& rb = m->out_blocks[oi];
-                static const bool vcat_on = !(getenv("S3D_VCAT") && strcmp(getenv("S3D_VCAT"), "0") == 0);
+                const bool vcat_on = opt_on(OPT_VCAT);
                 const int Cc = h.C + sk.C;
                 if (vcat_on && !tape && up == sk.g && sk.part.p && rb.has_skip && rb.c_up == h.C && rb.skip_a.dense[0] &&
                     gn_subgroup(Cc) == gn_subgroup(sk.C) && sk.part.nsub == sk.C / gn_subgroup(Cc) && h.C % gn_subgroup(Cc) == 0) {

@@ -619,12 +619,9 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino4(ConvArgs args) {
 
 // ------------------------------------------------------------------ host side
 static int wino_variant() {          // 24: mixed F(2x4,3x3) (s3d_wino24.hip), 4: F(2x2) one frequency row per wave, 2: two rows per wave, 0: direct kernel
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("S3D_WINO");
-        v = e ? atoi(e) : kDefaultWino;
-        if (v != 0 && v != 2 && v != 24) v = 4;
-    }
+    int v = opt(OPT_WINO);
+    if (v == kOptUnset) v = kDefaultWino;
+    if (v != 0 && v != 2 && v != 24) v = 4;
     return v;
 }
 double wino_exec_fraction() { return 4.0 / 9.0; }      // F(2x2,3x3): 16 multiplies per 2x2 outputs instead of 36

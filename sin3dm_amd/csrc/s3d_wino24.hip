@@ -874,19 +874,15 @@ static int wino24s_layout(ConvArgs& a, int cout_per_block, const char* who) {
 // step, 136 -> 127 us — and from 3 rounds on at K = 128 (a tie below); it loses on the one-round half-resolution launches of
 // the batch-1 step (384 blocks on 512 slots) and at K = 64 (the k-loop is too short to amortise the 64-channel epilogue).
 // S3D_WINO24W=0: never; =1: every launch whose cout is a multiple of 64.
-static int conv_cus() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    return cus > 0 ? cus : 256;
-}
+static int conv_cus() { return device_cus(); }
 static bool takes_wide(const ConvArgs& a) {
-    static const int mode = getenv("S3D_WINO24W") ? atoi(getenv("S3D_WINO24W")) : -1;
+    const int mode = opt(OPT_WINO24W);
     if (mode == 0 || a.cout % 64 != 0) return false;
     if (mode == 1) return true;
     if (a.cin < 128) return false;
     long long blocks = 0;
     for (int j = 0; j < a.njobs; ++j) blocks += (long long)((a.job[j].w + C_TW - 1) / C_TW) * ((a.job[j].h + C_TH - 1) / C_TH) * (a.cout / 64) * a.B;
-    static const int cus = conv_cus();
+    const int cus = conv_cus();
     return blocks >= (long long)(a.cin >= 256 ? 3 : 6) * cus;
 }
 

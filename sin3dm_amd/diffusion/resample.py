@@ -43,6 +43,12 @@ class UniformSampler(ScheduleSampler):
         return self._weights
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# OUTSIDE the hot-path scope (OUT OF SCOPE): everything below this line.  It exists only
+# because the reference's CLI accepts `--schedule_sampler loss-second-moment` (src/diffusion/resample.py:17-21) and
+# create_named_schedule_sampler must not fail on a flag the reference takes; nothing on the measured path uses it (the default and
+# every benchmark / parity test run UniformSampler), it has no kernel, and no parity claim is made for it.
+# ---------------------------------------------------------------------------------------------------------------------------
 class LossAwareSampler(ScheduleSampler):
     def update_with_local_losses(self, local_ts, local_losses):
         """Share this rank's (t, loss) pairs with every rank, then update the history identically everywhere."""

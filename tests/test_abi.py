@@ -124,3 +124,35 @@ def test_host_mapped_timesteps_equal_the_tensor_path(orig, respacing):
         wrapped(torch.zeros(2), HostTimesteps(torch.tensor([i, i]), (i, i)))
         assert torch.equal(torch.as_tensor(seen["ts"]).float(), via_tensor[i].expand(2)), (i, seen["ts"], via_tensor[i])
         assert seen["ts"].host_values == (float(via_tensor[i]),) * 2
+
+
+def test_options_through_the_abi_and_environment_fallback():
+    """s3d_set_option / s3d_get_option: the documented way to select kernel forms (the S3D_* environment variables are only the
+    fallback until the first call for an option); unknown names are rejected with a message."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            f"sys.path.insert(0, {REPO!r})\n"
+            "os.environ['S3D_WINO'] = '4'; os.environ['S3D_CONV_IMPL'] = 'naive'\n"
+            "from sin3dm_amd import _lib\n"
+            "assert _lib.get_option('WINO') == 4 and _lib.get_option('S3D_CONV_IMPL') == 1        # environment, read at first use\n"
+            "assert _lib.get_option('WINO24W') is None and _lib.get_option('BWD_SIDE') is None     # unset: the library chooses\n"
+            "_lib.set_option('S3D_WINO', 24); _lib.set_option('WINO24W', '1'); _lib.set_option('CONV_IMPL', 'mfma')\n"
+            "assert _lib.get_option('WINO') == 24 and _lib.get_option('WINO24W') == 1 and _lib.get_option('CONV_IMPL') == 0\n"
+            "_lib.set_option('WINO24W', None)\n"
+            "assert _lib.get_option('WINO24W') is None\n"
+            "os.environ['S3D_GN_FUSED'] = '1'; _lib.set_option('GN_FUSED', 0)                      # a call beats the environment\n"
+            "assert _lib.get_option('GN_FUSED') == 0\n"
+            "try:\n"
+            "    _lib.set_option('NO_SUCH_OPTION', 1)\n"
+            "    raise SystemExit('accepted an unknown option')\n"
+            "except AssertionError as e:\n"
+            "    assert 'NO_SUCH_OPTION' in str(e)\n"
+            "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                       env={k: v for k, v in os.environ.items() if not k.startswith("S3D_")})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    names = re.findall(r"^ \*   ([A-Z][A-Z0-9_]+)  ", open(os.path.join(REPO, "include", "sin3dm_hip.h")).read(), flags=re.M)
+    assert len(names) == 10                                  # every documented option exists
+    for n in names:
+        _lib.get_option(n)

@@ -187,6 +187,32 @@ def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, va
         assert np.array_equal(a, b), (mc, B, hwd, float(np.abs(a - b).max()))
 
 
+def test_forms_selected_through_the_abi_in_one_process():
+    """s3d_set_option (the documented boundary; the environment variables are its fallback) switches a form between two
+    launches of ONE process: both blockings of the mixed Winograd kernel and both GroupNorm-statistics forms give the same bits,
+    the library names the kernel that ran, and clearing the option returns the choice to the library."""
+    from sin3dm_amd import _lib
+    mc, B, hwd = R1_CASES[2]
+    try:
+        _lib.set_option("WINO24W", 0)
+        a, name_a = _r1_forward(mc, B, hwd, 72)
+        _lib.set_option("WINO24W", 1)
+        b, name_b = _r1_forward(mc, B, hwd, 72)
+        assert "k_conv_wino24s" in name_a and "k_conv_wino24w" in name_b and "k_conv_wino24s" not in name_b
+        assert np.array_equal(a, b)
+        _lib.set_option("GN_FUSED", 0)
+        c, _ = _r1_forward(mc, B, hwd, 72)
+        _lib.set_option("GN_FUSED", 1)
+        d, _ = _r1_forward(mc, B, hwd, 72)
+        assert np.array_equal(a, c) and np.array_equal(a, d)
+    finally:
+        _lib.set_option("WINO24W", None)
+        _lib.set_option("GN_FUSED", None)
+    assert _lib.get_option("WINO24W") is None
+    e, _ = _r1_forward(mc, B, hwd, 72)
+    assert np.array_equal(a, e)
+
+
 def test_groupnorm_statistics_forms_are_bit_identical(tmp_path):
     """GroupNorm32 statistics (nn.py:17-19, 93-100) of a convolution output are the sum of its epilogue's partial records.  Small
     launches add them in the CONSUMER's own blocks (k_gn_act, k_out_head_px: one dependent launch less), launches of many rounds
