@@ -39,8 +39,7 @@ struct DeferredTail {
     struct Bias { const float* R[3]; float* dbias[3]; float* per_sample; int per_sample_stride; int h[3]; int B, C; };
     std::vector<Red> red;
     std::vector<Bias> bias;
-    // st_red: the stream the partial-sum kernels were enqueued on (the reductions follow them); st: the pass's main stream
-    int flush(hipStream_t st, hipStream_t st_red = nullptr);
+    int flush(hipStream_t st);
 };
 // tail != null: the reduction launch is queued there instead of being enqueued behind the partial kernel
 int launch_wgrad(const WgradArgs& w, hipStream_t st, DeferredTail* tail = nullptr);

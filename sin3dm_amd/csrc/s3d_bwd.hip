@@ -603,8 +603,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_multi(RedMultiArgs m) {
     if (J.wino) wgrad_wino_reduce_block(J.r, bx, p);
     else wgrad_reduce_block(J.r, bx, p);
 }
-int DeferredTail::flush(hipStream_t st, hipStream_t st_red) {
-    if (!st_red) st_red = st;
+int DeferredTail::flush(hipStream_t st) {
     for (size_t i0 = 0; i0 < red.size(); i0 += kTailJobs) {
         RedMultiArgs m;
         m.njobs = int(std::min(red.size() - i0, size_t(kTailJobs)));
@@ -621,7 +620,7 @@ int DeferredTail::flush(hipStream_t st, hipStream_t st_red) {
             blocks += J.bx * r.nplanes;
         }
         m.begin[m.njobs] = blocks;
-        if (blocks) { hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, st_red, m); S3D_HIP(hipGetLastError()); }
+        if (blocks) { hipLaunchKernelGGL(k_wgrad_reduce_multi, dim3(blocks), dim3(256), 0, st, m); S3D_HIP(hipGetLastError()); }
     }
     red.clear();
     for (size_t i0 = 0; i0 < bias.size(); i0 += kTailJobs) {

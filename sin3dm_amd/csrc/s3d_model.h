@@ -128,7 +128,7 @@ struct s3d_unet {
     const float* tdev(size_t off) const { return static_cast<const float*>(tbuf.p) + off; }
     // backward pass: the weight-gradient launches (no consumer before the optimizer) run on a handle-owned side stream beside the
     // chain that carries the input gradients (s3d_train.hip: Bwd::fork / join)
-    hipStream_t bwd_side = nullptr;
+    hipStream_t bwd_side = nullptr;       // weight gradients (low priority: they only have to be done by the end of the pass)
     std::vector<hipEvent_t> bwd_events;
 
     // optional live timing of the convolution launches (s3d_unet_profile)

@@ -20,37 +20,29 @@ struct Bwd {
     float* grads;                 // flat, same layout as the parameters
     float* dfilm = nullptr;       // [B][film_total]
     DeferredTail tail;            // the pass's split-K reductions and bias gradients, run in batches (before each progress mark)
-    // Weight gradients have no consumer inside the pass: they go to a side stream (`sst`; == st when S3D_BWD_SIDE=0) and run
-    // beside the main chain (dgrad -> edge sums -> mean-vector gradients -> GroupNorm backward -> next dgrad), whose many
-    // one-round launches leave the matrix cores idle.  fork(): the side stream waits for what the main stream has enqueued so
-    // far (one event, no cost to the main chain beyond the record); join(): the main stream waits for the side stream (before a
-    // progress mark and at the end of the pass).  Same kernels on the same operands: the gradients are bit-identical.
-    hipStream_t sst = nullptr;
+    // Weight gradients (k_wgrad_wino / k_wgrad_mfma / k_slot_wgrad, their split-K reductions, the bias sums, in_conv's outer
+    // products) have no consumer before the optimizer: they go to a handle-owned low-priority side stream `sw` (BWD_SIDE=0: the
+    // caller's stream) and run beside the chain that carries the input gradients (dgrad -> edge sums -> mean-vector gradients ->
+    // GroupNorm backward -> next dgrad), whose many one-round launches leave the matrix cores idle.  edge(a, b): stream b waits for
+    // what has been enqueued on a so far (one event; the main chain only ever pays the record).  Same kernels on the same
+    // operands: bit-identical gradients.  Measured (profiles/r05_train_step.txt): 3.21 -> 2.98 ms/step; a SECOND side stream for
+    // each layer's edge sums -> mean-vector gradients beside its dgrad convolution (joined before the GroupNorm backward) lost
+    // 1 % to the eight joins it puts on the main chain and is not kept.
+    hipStream_t sw = nullptr;
     size_t ev_next = 0;
-    int fork() {
-        if (sst == st) return 0;
+    int edge(hipStream_t from, hipStream_t to) {
+        if (from == to) return 0;
         if (ev_next == m->bwd_events.size()) {
             hipEvent_t e = nullptr;
             S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             m->bwd_events.push_back(e);
         }
         hipEvent_t e = m->bwd_events[ev_next++];
-        S3D_HIP(hipEventRecord(e, st));
-        S3D_HIP(hipStreamWaitEvent(sst, e, 0));
+        S3D_HIP(hipEventRecord(e, from));
+        S3D_HIP(hipStreamWaitEvent(to, e, 0));
         return 0;
     }
-    int join() {
-        if (sst == st) return 0;
-        if (ev_next == m->bwd_events.size()) {
-            hipEvent_t e = nullptr;
-            S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            m->bwd_events.push_back(e);
-        }
-        hipEvent_t e = m->bwd_events[ev_next++];
-        S3D_HIP(hipEventRecord(e, sst));
-        S3D_HIP(hipStreamWaitEvent(st, e, 0));
-        return 0;
-    }
+    int join() { return edge(sw, st); }                   // the caller's stream waits for the side stream
     Arena& ar() { return m->arena; }
     bool meas() { return m->arena.measuring; }
 
@@ -75,7 +67,6 @@ struct Bwd {
         const Geo& g = dy.g;
         const int cin = cw.cin, cout = cw.cout, taps = cw.k * cw.k;
         const bool roll = cw.rollout && nt && nt->roll;
-        bool forked = false;
         // (1) dgrad of the own channels
         if (d_a) {
             *d_a = alloc_tri(cin, g);
@@ -106,6 +97,7 @@ struct Bwd {
         if (!meas()) {
             S3D_TRY(launch_edge_sums(dy, B, R, Cs, st));
             S3D_TRY(launch_bias_grad_deferred(R, g, cout, B, dbias, per_sample_bias, m->film_total, tail));
+            S3D_TRY(edge(st, sw));                        // (the edge sums — and dy before them)
         }
         if (roll) {
             const MeanVecs& mv = nt->mv;
@@ -122,9 +114,7 @@ struct Bwd {
                     sw.rowvec[p] = rowvec[p]; sw.colvec[p] = colvec[p]; sw.R[p] = R[p]; sw.Cs[p] = Cs[p]; sw.dW[p] = dW[p];
                 }
                 sw.g = g; sw.B = B; sw.C = cin; sw.cout = cout;
-                S3D_TRY(fork());                                  // (the edge sums — and dy before them — are enqueued)
-                forked = true;
-                S3D_TRY(launch_slot_wgrad(sw, sst));
+                S3D_TRY(launch_slot_wgrad(sw, this->sw));
                 // gradients of the six mean vectors: 1-D transposed convolutions of the edge sums (k_rank1)
                 ConvArgs ca; memset(&ca, 0, sizeof ca);
                 ca.B = B; ca.cin = 3 * cout; ca.cout = cin; ca.njobs = 6;
@@ -151,10 +141,7 @@ struct Bwd {
             w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps));
             w.dW[p] = dW[p];
         }
-        if (!meas()) {
-            if (!forked) S3D_TRY(fork());
-            S3D_TRY(launch_wgrad(w, sst, &tail));
-        }
+        if (!meas()) S3D_TRY(launch_wgrad(w, this->sw, &tail));
         return 0;
     }
 
@@ -211,11 +198,14 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
     Bwd b{m, B, st, grads};
     Arena& ar = m->arena;
     const bool meas = ar.measuring;
-    const bool side_on = opt_on(OPT_BWD_SIDE);
-    b.sst = st;
-    if (!meas && side_on) {
-        if (!m->bwd_side) S3D_HIP(hipStreamCreateWithFlags(&m->bwd_side, hipStreamNonBlocking));
-        b.sst = m->bwd_side;
+    b.sw = st;
+    if (!meas && opt_on(OPT_BWD_SIDE)) {
+        if (!m->bwd_side) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            S3D_HIP(hipStreamCreateWithPriority(&m->bwd_side, hipStreamNonBlocking, least));
+        }
+        b.sw = m->bwd_side;
     }
     b.dfilm = ar.alloc<float>(size_t(B) * m->film_total);
 
@@ -268,7 +258,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         d_h = d_prev;
     }
 
-    if (!meas) S3D_TRY(b.tail.flush(st, b.sst));      // (the output blocks' weight / bias gradients are final at mark 0)
+    if (!meas) { S3D_TRY(b.edge(st, b.sw)); S3D_TRY(b.tail.flush(b.sw)); }      // (the output blocks' weight / bias gradients are final at mark 0; the bias sums read the main chain's edge sums)
     if (!meas && n_marks > 0 && marks[0]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[0], st)); }
 
     // ---- input blocks, deepest to first
@@ -302,11 +292,13 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
             }
             so.ssum = nullptr; so.vsum = vsum; so.ws = ws;
             so.H = T.H; so.W = T.W; so.D = T.D; so.C = d_x.C; so.B = B;
-            S3D_TRY(launch_small_outer(so, st));
+            S3D_TRY(b.edge(st, b.sw));                    // d_x is final; nothing inside the pass reads in_conv's gradients
+            S3D_TRY(launch_small_outer(so, b.sw));
         }
     }
 
-    if (!meas) S3D_TRY(b.tail.flush(st, b.sst));      // (... the input blocks' at mark 1; the per-sample bias sums feed the timestep MLP below)
+    if (!meas) { S3D_TRY(b.edge(st, b.sw)); S3D_TRY(b.tail.flush(b.sw)); }      // (... the input blocks' at mark 1)
+    if (!meas && c.use_scale_shift_norm == 0) S3D_TRY(b.join());      // h + emb_out: the per-sample bias sums (side stream) are the FiLM gradient the timestep MLP below reads
     if (!meas && n_marks > 1 && marks[1]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[1], st)); }
 
     // ---- timestep MLP: film = Lf(silu(emb)), emb = L2(silu(pre1)), pre1 = L0(temb(t))

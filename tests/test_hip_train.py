@@ -453,7 +453,7 @@ def _flat_grad_digest(expand):
 
 def test_weight_gradients_on_the_side_stream_change_no_bit():
     """The backward pass enqueues every weight-gradient launch (k_wgrad_wino / k_wgrad_mfma / k_slot_wgrad and their split-K
-    reductions) on a handle-owned side stream beside the chain of input gradients; S3D_BWD_SIDE=0 keeps them in line.  Same
+    reductions, the bias sums, in_conv's outer products) on a handle-owned side stream; S3D_BWD_SIDE=0 keeps them in line.  Same
     kernels on the same operands: identical gradients, pass after pass.  Also: the single training triplane expanded to a batch
     (batch stride 0, utils/triplane_util.py:64-69) is read in place and gives the bits of the materialised batch."""
     import os, subprocess, sys
@@ -463,7 +463,8 @@ def test_weight_gradients_on_the_side_stream_change_no_bit():
             "import test_hip_train as tt\n"
             "print('DIGEST', tt._flat_grad_digest(expand=True))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_BWD_SIDE="0"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    inline = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
-    assert inline == here
+    for mode in ("0",):                                  # everything in line
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, S3D_BWD_SIDE=mode), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        other = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
+        assert other == here, mode
