@@ -61,6 +61,14 @@ struct s3d_ae {
     EncDesc enc{};
     bool has_volume = false;
     Arena arena;
+    // backward pass: weight-gradient launches (no consumer before the optimizer) on a handle-owned low-priority side stream, beside
+    // the chain of input gradients — as in the denoiser's backward pass (s3d_train.hip: Bwd::edge / join)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;
+    ~s3d_ae() {
+        for (auto e : events) (void)hipEventDestroy(e);
+        if (side) (void)hipStreamDestroy(side);
+    }
     const float* P(size_t off) const { return static_cast<const float*>(pbuf.p) + off; }
     size_t off_of(const std::string& n) const {
         for (size_t i = 0; i < specs.size(); ++i) if (specs[i].name == n) return flat_off[i];
@@ -142,8 +150,22 @@ static int ae_plan(s3d_ae* a) {
 
 struct AeRun {
     s3d_ae* a; hipStream_t st; float* grads;
+    hipStream_t sw = nullptr;             // weight gradients (== st: in line)
+    size_t ev_next = 0;
     Arena& ar() { return a->arena; }
     bool meas() { return a->arena.measuring; }
+    int edge(hipStream_t from, hipStream_t to) {           // `to` waits for what has been enqueued on `from` so far
+        if (from == to || !from || !to) return 0;
+        if (ev_next == a->events.size()) {
+            hipEvent_t e = nullptr;
+            S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            a->events.push_back(e);
+        }
+        hipEvent_t e = a->events[ev_next++];
+        S3D_HIP(hipEventRecord(e, from));
+        S3D_HIP(hipStreamWaitEvent(to, e, 0));
+        return 0;
+    }
     const float* F(size_t off) const { return a->flat + off; }
     float* G(size_t off) const { return grads ? grads + off : reinterpret_cast<float*>(uintptr_t(256)); }
 
@@ -168,7 +190,9 @@ struct AeRun {
         w.ksplit = wgrad_ksplit(g, 1, cin, cout, taps);
         for (int p = 0; p < nplanes; ++p) { w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps)); w.dW[p] = dW[p]; }
         if (meas()) return 0;
-        return launch_wgrad(w, st);
+        hipStream_t on = sw ? sw : st;
+        S3D_TRY(edge(st, on));                             // dy and the activation are final in the order of the caller's stream
+        return launch_wgrad(w, on);
     }
 };
 
@@ -188,6 +212,14 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     Arena& ar = a->arena;
     const bool meas = ar.measuring;
     ar.reset();
+    if (!meas && grads && opt_on(OPT_BWD_SIDE)) {
+        if (!a->side) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            S3D_HIP(hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least));
+        }
+        R.sw = a->side;
+    }
     const int up = a->up, hid = a->hid, CO = a->geo + a->tex, S = 1 + a->TC;
     const Geo g = a->enc.g;
     const long long Np = (N + 63) / 64 * 64;
@@ -287,7 +319,6 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
         float* dH = ar.alloc<float>(size_t(Np) * hid);            // gradient of a hidden activation (reused)
-        float* dP = ar.alloc<float>(size_t(Np) * hid);            // ... of its pre-activation
         float* dCAT = ar.alloc<float>(size_t(Np) * (up + hid));
         float* dXa = ar.alloc<float>(size_t(Np) * up);
         dX0[n] = ar.alloc<float>(size_t(Np) * up);
@@ -302,6 +333,9 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
                                {0, H[n][0], X0[n], up, dXa, dH, hid, 0}};
         for (const Step& s : steps) {
             const int I = N_.I[s.l], O = N_.O[s.l];
+            // gradient of the layer's pre-activation: one buffer per layer — the weight gradient that reads it runs on the side
+            // stream while this chain has moved on
+            float* dP = ar.alloc<float>(size_t(Np) * hid);
             if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws, R.G(N_.f_mb[s.l]), st));
             Geo g1; for (int p = 0; p < 3; ++p) { g1.h[p] = p == 0 ? int(Np / 64) : 0; g1.w[p] = p == 0 ? 64 : 0; }
             float* dy3[3] = {dP, nullptr, nullptr}; float* a3[3] = {s.in, nullptr, nullptr}; float* dw3[3] = {R.G(N_.f_mw[s.l]), nullptr, nullptr};
@@ -374,6 +408,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         S3D_TRY(launch_enc_norm(true, pre, feat, enc_mr, dfeat, dpre, g, CO, st));
         S3D_TRY(launch_enc_wgrad(a->enc, dpre, a->geo, a->tex, ews, R.G(a->f_enc_w[0]), R.G(a->f_enc_b[0]), R.G(a->f_enc_w[1]),
                                  R.G(a->f_enc_b[1]), st));
+        S3D_TRY(R.edge(R.sw, st));                        // every gradient of the pass is final in the order of the caller's stream
     }
     return 0;
 }

@@ -170,3 +170,37 @@ def test_full_size_directional_derivative():
     flat.copy_(base); net.mark_parameters_changed()
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gv) < 5e-2 * abs(gv), (fd, gv, L0, eps)
+
+
+def test_weight_gradients_on_the_side_stream_change_no_bit():
+    """The auto-encoder's backward pass enqueues its weight-gradient launches (the MLPs' k_wgrad_mfma<1>, the plane blocks'
+    k_wgrad_mfma<25> / <1>) on a handle-owned side stream beside the chain of input gradients (one pre-activation-gradient buffer
+    per layer, so the side stream reads what nobody overwrites); BWD_SIDE = 0 keeps them in line.  Selected through
+    s3d_set_option in ONE process: identical gradients and losses, iteration after iteration."""
+    import torch
+    from sin3dm_amd import _lib
+    H, W, D, N = 24, 32, 20, 8192
+    thr = 0.05
+    vol = _volume(H, W, D)
+
+    def run():
+        net = _net()
+        net.reset_aabb(torch.tensor([-0.7, -1.0, -0.45, 0.7, 1.0, 0.45]).cuda())
+        out = []
+        for it in range(3):
+            p, s, c = _batch(50 + it, N, thr)
+            losses, _, grads = net.loss_and_grads(vol, p, s, c, _loss_cfg(thr))
+            torch.cuda.synchronize()
+            out.append((losses.clone(), grads.clone()))
+        return out
+
+    try:
+        _lib.set_option("BWD_SIDE", 0)
+        inline = run()
+        _lib.set_option("BWD_SIDE", None)
+        side = run()
+    finally:
+        _lib.set_option("BWD_SIDE", None)
+    for (la, ga), (lb, gb) in zip(inline, side):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+        assert torch.isfinite(ga).all() and float(ga.abs().max()) > 0
