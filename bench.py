@@ -443,7 +443,9 @@ def worker(args):
         if clock is not None:
             clock.end()
         if not args.dry_run:
-            model.profile(args.profile_every, classes=1)      # inside the timed region only the dominant class: an event pair costs ~3 us
+            # inside the timed region only the dominant class (an event pair costs ~3 us); training: also the 3x3 weight-gradient
+            # launches (class 3, eight per step on the backward pass's side stream)
+            model.profile(args.profile_every, classes=9 if sampler_kind == "train" else 1)
         barrier()
         sync()
         t0 = time.perf_counter()
@@ -538,8 +540,16 @@ def worker(args):
                 "conv3x3_ms_per_step": round(prof.ms[0] / max(prof.forwards, 1), 4),
                 "rank1_ms_per_step": round(prof.ms[2] / max(prof.forwards, 1), 4),
                 "conv1x1_ms_per_step": round(prof.ms[1] / max(prof.forwards, 1), 4),
-                "whole_step_mfma_frac": round((prof.mfma_flops[0] + prof.mfma_flops[1] + prof.mfma_flops[2]) / max(prof.forwards, 1)
+                "whole_step_mfma_frac": round((prof.mfma_flops[0] + prof.mfma_flops[1] + prof.mfma_flops[2] + prof.mfma_flops[3]) / max(prof.forwards, 1)
                                               / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                # training only: the 3x3 weight gradient (k_wgrad_wino: Winograd F(2x2,3x3), 4/9 of the direct count on the matrix
+                # cores).  HIP events on the backward pass's side stream: the launches share the chip with the main chain, so this
+                # is their rate IN the step; S3D_BWD_SIDE=0 gives the kernel alone
+                "wgrad3x3": ({"kernel": model.profile_kernel(3), "launches_timed": int(prof.launches[3]),
+                              "avg_launch_us": round(prof.ms[3] * 1e3 / prof.launches[3], 2),
+                              "achieved": round(prof.mfma_flops[3] / (prof.ms[3] * 1e-3) / 1e12, 2),
+                              "frac": round(prof.mfma_flops[3] / (prof.ms[3] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                              "ms_per_step": round(prof.ms[3] / max(prof.forwards, 1), 4)} if prof.launches[3] > 0 else None),
                 "note": "achieved/frac = flops the matrix cores execute for the launches (Winograd multiplies fewer than the "
                         "direct count) / HIP-event time on the launch stream inside the timed region / 157.3 TF; "
                         "algorithmic_tflops = 2*9*C*Cout per output pixel (own channels only: rank-1 rollout exploited) over the "

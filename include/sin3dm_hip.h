@@ -134,15 +134,18 @@ S3D_API int s3d_unet_forward_film(s3d_unet* m, const float* x, const float* film
  * s3d_unet_profile_classes: which launch classes of a profiled forward are bracketed (bit 0: 3x3, bit 1: 1x1, bit 2: rank-1;
  * default 7).  An event pair costs the step ~3 us (38 pairs' worth per profiled step with all classes): bench.py brackets only
  * the dominant class inside its timed region and the other two in a short pass of its own afterwards. */
+#define S3D_PROF_CLASSES 4
 typedef struct {
-    double ms[3];          /* [0] dense 3x3 (the dominant kernel), [1] 1x1 skip convs, [2] rank-1 rollout vector convs */
-    double flops[3];
-    int64_t launches[3];
+    double ms[S3D_PROF_CLASSES];   /* [0] dense 3x3 (the dominant kernel; training: forward + dgrad), [1] 1x1 skip convs, [2] rank-1
+                                      rollout vector convs, [3] training only: the 3x3 weight-gradient launches (k_wgrad_wino; on the
+                                      backward pass's side stream their time includes sharing the chip with the main chain) */
+    double flops[S3D_PROF_CLASSES];
+    int64_t launches[S3D_PROF_CLASSES];
     int64_t forwards;      /* forwards that were instrumented */
-    double mfma_flops[3];
+    double mfma_flops[S3D_PROF_CLASSES];
 } s3d_profile;
 S3D_API int s3d_unet_profile(s3d_unet* m, int every);
-S3D_API int s3d_unet_profile_classes(s3d_unet* m, int mask);
+S3D_API int s3d_unet_profile_classes(s3d_unet* m, int mask);   /* bit c = class c of s3d_profile */
 S3D_API int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out);
 S3D_API const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls);
 /* ------------------------------------------------------------------------------------------

@@ -36,9 +36,12 @@ class SamplerArgs(C.Structure):
                 ("sample", C.c_void_p), ("pred_xstart", C.c_void_p), ("mean", C.c_void_p)]
 
 
+PROF_CLASSES = 4
+
+
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 3), ("flops", C.c_double * 3), ("launches", C.c_int64 * 3),
-                ("forwards", C.c_int64), ("mfma_flops", C.c_double * 3)]
+    _fields_ = [("ms", C.c_double * PROF_CLASSES), ("flops", C.c_double * PROF_CLASSES), ("launches", C.c_int64 * PROF_CLASSES),
+                ("forwards", C.c_int64), ("mfma_flops", C.c_double * PROF_CLASSES)]
 
 
 class AeLossCfg(C.Structure):

@@ -150,12 +150,13 @@ static int ae_plan(s3d_ae* a) {
 
 struct AeRun {
     s3d_ae* a; hipStream_t st; float* grads;
-    hipStream_t sw = nullptr;             // weight gradients (== st: in line)
+    hipStream_t sw = nullptr;             // weight gradients; `side` says whether it is a stream of its own (the caller's stream may be the null stream)
+    bool side = false;
     size_t ev_next = 0;
     Arena& ar() { return a->arena; }
     bool meas() { return a->arena.measuring; }
     int edge(hipStream_t from, hipStream_t to) {           // `to` waits for what has been enqueued on `from` so far
-        if (from == to || !from || !to) return 0;
+        if (!side || from == to) return 0;
         if (ev_next == a->events.size()) {
             hipEvent_t e = nullptr;
             S3D_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -190,7 +191,7 @@ struct AeRun {
         w.ksplit = wgrad_ksplit(g, 1, cin, cout, taps);
         for (int p = 0; p < nplanes; ++p) { w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps)); w.dW[p] = dW[p]; }
         if (meas()) return 0;
-        hipStream_t on = sw ? sw : st;
+        hipStream_t on = side ? sw : st;
         S3D_TRY(edge(st, on));                             // dy and the activation are final in the order of the caller's stream
         return launch_wgrad(w, on);
     }
@@ -219,6 +220,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             S3D_HIP(hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least));
         }
         R.sw = a->side;
+        R.side = true;
     }
     const int up = a->up, hid = a->hid, CO = a->geo + a->tex, S = 1 + a->TC;
     const Geo g = a->enc.g;
@@ -408,7 +410,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         S3D_TRY(launch_enc_norm(true, pre, feat, enc_mr, dfeat, dpre, g, CO, st));
         S3D_TRY(launch_enc_wgrad(a->enc, dpre, a->geo, a->tex, ews, R.G(a->f_enc_w[0]), R.G(a->f_enc_b[0]), R.G(a->f_enc_w[1]),
                                  R.G(a->f_enc_b[1]), st));
-        S3D_TRY(R.edge(R.sw, st));                        // every gradient of the pass is final in the order of the caller's stream
+        S3D_TRY(R.edge(R.sw, st));                        // every gradient of the pass is final in the order of the caller's stream (no-op in line)
     }
     return 0;
 }

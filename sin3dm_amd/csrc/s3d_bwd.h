@@ -29,6 +29,7 @@ struct WgradArgs {
     int nplanes = 3;     // jobs actually present in dy/a/part/dW
 };
 int wgrad_ksplit(const Geo& g, int B, int cin, int cout, int taps);
+bool wgrad_uses_wino();          // the 3x3 weight gradient goes to k_wgrad_wino (option WGRAD_WINO)
 size_t wgrad_part_floats(int ksplit, int cin, int cout, int taps);
 // The small tail launches of a convolution's backward — the split-K reduction of its weight gradient and the bias gradient from
 // the row sums — have no consumer inside the pass: a DeferredTail collects them (operands live in the pass's arena) and

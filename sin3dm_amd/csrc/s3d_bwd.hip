@@ -566,6 +566,7 @@ __device__ __forceinline__ void wgrad_wino_reduce_block(const Args& a, int bx, i
     for (int f = 0; f < 9; ++f) d[f] = ((S[f] + red[0][f][l]) + red[1][f][l]) + red[2][f][l];
 }
 __global__ __launch_bounds__(256) void k_wgrad_wino_reduce(WgwRedArgs a) { wgrad_wino_reduce_block(a, blockIdx.x, blockIdx.y); }
+bool wgrad_uses_wino() { return opt_on(OPT_WGRAD_WINO); }
 static bool wgrad_use_wino() {
     return opt_on(OPT_WGRAD_WINO);
 }

@@ -182,6 +182,10 @@ struct ConvW {
     size_t wino24s[3] = {0, 0, 0};    // 3x3: G2 g G4^T (mixed F(2x4,3x3)) in the fragment order of k_conv_wino24s / k_conv_wino24w
     int cin = 0, cout = 0, k = 0;
     bool rollout = false;
+    // training handles: the per-step device repack rewrites only the images of the kernel forms selected when the plan was built
+    // (s3d_pack.hip); true = of this 3x3 layer's images only `wino24s` follows the parameters, `dense` / `wino` hold load-time
+    // values.  A launch that would read one of those fails loudly (Fwd::conv) instead of computing with stale weights.
+    bool only24_current = false;
 };
 size_t push(std::vector<float>& stage, const float* src, size_t n);
 // Fragment-order image of the rank-1 weights (k_rank1b, s3d_conv.hip): float index of W[tap][o][co][c] — group g = co / 32 and

@@ -60,6 +60,7 @@ struct ConvWT {
     size_t wino_T[3] = {0, 0, 0};     // the same operator in Winograd fragment order (3x3 only)
     size_t wino24s_T[3] = {0, 0, 0};  // ... and in the mixed F(2x4) order of k_conv_wino24s
     bool has_wino24s_T = false, has_wino_T = false;
+    bool only24_current = false;      // of the transposed 3x3 images only wino24s_T is rewritten per step (see ConvW::only24_current)
     size_t rrow_T[3] = {0, 0, 0};     // [3 taps][cin][3*cout]: d(row-varying mean vector) from the row sums of dy
     size_t rcol_T[3] = {0, 0, 0};
 };
@@ -136,14 +137,14 @@ struct s3d_unet {
     int prof_every = 0;
     long fwd_count = 0;
     bool prof_now = false;
-    int prof_mask = 7;                // launch classes (bit 0: 3x3, 1: 1x1, 2: rank-1) whose launches are bracketed in a profiled forward
+    int prof_mask = 15;               // launch classes (bit 0: 3x3, 1: 1x1, 2: rank-1, 3: 3x3 weight gradient) whose launches are bracketed in a profiled forward
     bool prof_train = false;          // the last training forward was a profiled one: its backward pass times its dgrad convolutions too
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     int64_t prof_forwards = 0;
-    std::string prof_kernel[3];                          // every distinct kernel the timed launches of a class dispatched, " + "-joined
+    std::string prof_kernel[S3D_PROF_CLASSES];                          // every distinct kernel the timed launches of a class dispatched, " + "-joined
     void note_prof_kernel(int cls) {
-        if (cls < 0 || cls >= 3) return;
+        if (cls < 0 || cls >= S3D_PROF_CLASSES) return;
         const std::string n = conv_last_kernel();
         if (n.empty() || prof_kernel[cls].find(n) != std::string::npos) return;
         prof_kernel[cls] += (prof_kernel[cls].empty() ? "" : " + ") + n;
@@ -340,6 +341,9 @@ struct Fwd {
         // the mixed Winograd kernels serve every forward (the tape keeps activations, not conv internals) and, on the transposed
         // image, the backward's dgrad (s3d_train.hip:conv_bwd)
         const bool w24 = cw.k == 3 && cw.wino24s[0] != 0 && conv_wino24_channels(cw.cin, cw.cout);
+        S3D_CHECK(!(cw.only24_current && (!w24 || conv_use_naive())), S3D_ERR_INVALID,
+                  "conv %dx%d %d->%d: the kernel form selected now reads a weight image the training handle's repack plan does not keep "
+                  "current (options changed after s3d_unet_train_attach): attach again", cw.k, cw.k, cw.cin, cw.cout);
         GnPartials part; GnStats gs{nullptr};
         if (want_stats) {
             conv_gn_parts(CONV_3x3, y.g, part.nparts, w24);

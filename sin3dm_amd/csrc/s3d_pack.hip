@@ -221,7 +221,7 @@ struct Plan {
             add(PK_COPY, flat_of(prefix + ".norm_" + kP[p] + ".bias"), nw.beta[p], c);
         }
     }
-    void tconv(const std::string& prefix, const ConvW& cw, ConvWT& wt) {
+    void tconv(const std::string& prefix, ConvW& cw, ConvWT& wt) {
         static const char* kP[3] = {"xy", "xz", "yz"};
         const int cin = cw.cin, cout = cw.cout, k = cw.k, taps = k * k, ctot = cw.rollout ? 3 * cin : cin;
         for (int p = 0; p < 3; ++p) {
@@ -232,6 +232,8 @@ struct Plan {
             // convolutions, which only the direct and the naive kernels read — would be rewritten for nobody
             const bool fwd24 = k == 3 && cw.wino24s[p] && conv_wino24_channels(cin, cout);
             const bool bwd24 = k == 3 && cw.wino24s[p] && cout % 32 == 0 && conv_wino24_channels(cout, cin);
+            // (what is skipped here is recorded: a launch that would read a skipped image fails instead of using stale weights)
+            if (p == 0) { cw.only24_current = fwd24 && !conv_use_naive(); wt.only24_current = bwd24 && !conv_use_naive(); }
             if (!fwd24 || conv_use_naive()) add(PK_DENSE, w, cw.dense[p], (long long)cout * cin, cout, ctot, cin, taps);
             wt.dense_T[p] = talloc(size_t(taps) * cout * cin);
             if (!bwd24 || conv_use_naive()) add(PK_DENSE_T, w, wt.dense_T[p], (long long)cout * cin, cout, ctot, cin, taps, 0, 0, 1);
@@ -278,7 +280,7 @@ int build_pack_plan(s3d_unet* m) {
     P.add(PK_COPY, P.flat_of("time_embed.2.bias"), m->te2_b, ted);
     m->in_blocks_t.assign(m->in_blocks.size(), ResBlockWT());
     m->out_blocks_t.assign(m->out_blocks.size(), ResBlockWT());
-    auto block = [&](const ResBlockW& rb, ResBlockWT& wt) {
+    auto block = [&](ResBlockW& rb, ResBlockWT& wt) {
         const int eo = ssn ? 2 * rb.Cout : rb.Cout;
         P.add(PK_COPY, P.flat_of(rb.prefix + ".emb_layers.1.weight"), m->film_w + size_t(rb.film_off) * ted, (long long)eo * ted);
         P.add(PK_COPY, P.flat_of(rb.prefix + ".emb_layers.1.bias"), m->film_b + rb.film_off, eo);

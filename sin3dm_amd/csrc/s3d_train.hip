@@ -70,6 +70,9 @@ struct Bwd {
         // (1) dgrad of the own channels
         if (d_a) {
             *d_a = alloc_tri(cin, g);
+            S3D_CHECK(!(wt.only24_current && (!conv_use_wino24() || conv_use_naive())), S3D_ERR_INVALID,
+                      "backward of conv %d->%d: the kernel form selected now reads a transposed weight image the repack plan does not "
+                      "keep current (options changed after s3d_unet_train_attach): attach again", cin, cout);
             if (!meas()) {
                 ConvArgs ca; memset(&ca, 0, sizeof ca);
                 ca.B = B; ca.cin = cout; ca.cout = cin; ca.njobs = 3;
@@ -141,7 +144,21 @@ struct Bwd {
             w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps));
             w.dW[p] = dW[p];
         }
-        if (!meas()) S3D_TRY(launch_wgrad(w, this->sw, &tail));
+        if (!meas()) {
+            if (taps == 9) {
+                // s3d_profile class 3: direct count 2*9*cin*cout per pixel; the Winograd F(2x2,3x3) form multiplies 16 instead of 36
+                // per 2x2 tile and channel pair (4/9), the direct form all of them
+                double pix = 0;
+                for (int p = 0; p < 3; ++p) pix += double(g.h[p]) * g.w[p];
+                const double fl = 2.0 * 9 * cin * cout * pix * B;
+                const bool wino = wgrad_uses_wino();
+                hipStream_t on = this->sw;
+                S3D_TRY(m->timed_launch(3, fl, wino ? fl * 4.0 / 9.0 : fl, on, [&] {
+                    conv_note_kernel(wino ? "k_wgrad_wino Winograd F(2x2,3x3) weight gradient" : "k_wgrad_mfma<9> direct weight gradient");
+                    return launch_wgrad(w, on, &tail);
+                }));
+            } else S3D_TRY(launch_wgrad(w, this->sw, &tail));
+        }
         return 0;
     }
 

@@ -512,12 +512,12 @@ int s3d_unet_profile(s3d_unet* m, int every) {
     m->prof_every = every;
     m->fwd_count = 0;
     if (every > 0)                                                    // a new measurement names its own kernels (of the classes it brackets)
-        for (int c = 0; c < 3; ++c) if ((m->prof_mask >> c) & 1) m->prof_kernel[c].clear();
+        for (int c = 0; c < S3D_PROF_CLASSES; ++c) if ((m->prof_mask >> c) & 1) m->prof_kernel[c].clear();
     return 0;
 }
 
 int s3d_unet_profile_classes(s3d_unet* m, int mask) {
-    S3D_CHECK(m && mask >= 0 && mask <= 7, S3D_ERR_INVALID, "unet_profile_classes: bad argument");
+    S3D_CHECK(m && mask >= 0 && mask < (1 << S3D_PROF_CLASSES), S3D_ERR_INVALID, "unet_profile_classes: bad argument");
     m->prof_mask = mask;
     return 0;
 }
@@ -544,7 +544,7 @@ int s3d_unet_profile_read(s3d_unet* m, s3d_profile* out) {
 }
 
 const char* s3d_unet_profile_kernel(const s3d_unet* m, int cls) {
-    return m && cls >= 0 && cls < 3 ? m->prof_kernel[cls].c_str() : "";
+    return m && cls >= 0 && cls < S3D_PROF_CLASSES ? m->prof_kernel[cls].c_str() : "";
 }
 
 }  // extern "C"

@@ -468,3 +468,32 @@ def test_weight_gradients_on_the_side_stream_change_no_bit():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         other = [l.split()[1] for l in r.stdout.splitlines() if l.startswith("DIGEST")][0]
         assert other == here, mode
+
+
+def test_a_form_change_after_attach_fails_instead_of_using_stale_weights():
+    """The per-step device repack of a training handle rewrites only the weight images of the kernel forms selected when the plan
+    was built (with the mixed Winograd kernel: not the dense / F(2x2) images of the 3x3 layers).  Selecting another form
+    afterwards would read load-time weights; the library refuses the launch — and works again once the option is
+    cleared."""
+    import torch
+    from sin3dm_amd import _lib
+    m = _model(32)
+    diffusion = _diffusion()
+    H, W, D, B = 10, 14, 6, 2
+    x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 400)).clamp(-1, 1).cuda()
+    noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 401)).cuda()
+    t = torch.tensor([700, 3], device="cuda")
+    w = torch.ones(B, device="cuda")
+    kw = dict(H=H, W=W, D=D)
+    _, g0 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+    g0 = g0.clone()
+    try:
+        _lib.set_option("WINO", 4)
+        with pytest.raises(AssertionError, match="repack plan"):
+            diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+        with torch.no_grad(), pytest.raises(AssertionError, match="repack plan"):
+            m(x0, t.float(), **kw)
+    finally:
+        _lib.set_option("WINO", None)
+    _, g1 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+    assert torch.equal(g0, g1)
