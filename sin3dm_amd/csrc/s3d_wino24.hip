@@ -886,6 +886,8 @@ static bool takes_wide(const ConvArgs& a) {
     return blocks >= (long long)(a.cin >= 256 ? 3 : 6) * cus;
 }
 
+// (round 5: an XCD owning one half of the channel blocks of a quarter of the tiles instead — half the weight image per L2, every
+// halo fetched twice — measured the same step time and 3 % less traffic on config 3; not kept: profiles/r05_xcd_mapping.txt)
 int launch_conv_wino24_wide(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 64 == 0, S3D_ERR_INVALID, "wino24w conv: bad arguments");
     const int blocks = wino24s_layout(a, 64, "wino24w conv");
