@@ -36,7 +36,7 @@ T_STEPS = 1000
 PREWARM = 150
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, = fp32 vector peak (at the 2400 MHz data-sheet clock)
 PEAK_CLOCK_MHZ = 2400.0
-TRAFFIC_PROFILE = "profiles/r04_pmc_traffic.json"
+TRAFFIC_PROFILE = "profiles/r05_pmc_traffic.json"
 # BASELINE.json workloads a single GPU can run (per-GPU share of the multi-GPU ones): name -> (hwd, batch per GPU, sampler,
 # timestep_respacing, steps per sample, metric, workload text)
 CONFIGS = {

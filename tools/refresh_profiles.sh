@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r04'
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r05'
 # Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
-R=${1:-r04}
+R=${1:-r05}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
@@ -45,8 +45,11 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench_d
 #    training, decode
 { for C in c3 c5 c4; do python3 bench.py --config $C --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; done
   python3 tools/bench_configs.py "C1 " 2>/dev/null | grep "^{"; python3 tools/bench_configs.py "64-ch" 2>/dev/null | grep "^{"; } > $OUT/${R}_other_configs.txt
-{ python3 tools/bench_train.py --steps 50 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{"; } > $OUT/${R}_train_step.txt
-{ python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
+{ echo "## default (weight gradients on the backward pass's side stream)"; python3 tools/bench_train.py --steps 100 --warmup 10 2>/dev/null | grep "^{"; python3 tools/bench_ae_train.py 2>/dev/null | grep "^{";
+  echo "## S3D_BWD_SIDE=0 (everything in line: round 4's launch structure)"; S3D_BWD_SIDE=0 python3 tools/bench_train.py --steps 100 --warmup 10 2>/dev/null | grep "^{"; S3D_BWD_SIDE=0 python3 tools/bench_ae_train.py 2>/dev/null | grep "^{";
+  echo "## bench.py --config c4, S3D_BWD_SIDE=0: the 3x3 weight-gradient kernel alone (roofline.wgrad3x3)"; S3D_BWD_SIDE=0 python3 bench.py --config c4 --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1; } > $OUT/${R}_train_step.txt
+{ python3 tools/bench_decode.py 2>/dev/null | grep -v amdgpu.ids; python3 tools/bench_decode.py --reso 512 --hwd 256 256 128 --aabb-scale 2 2 1 2>/dev/null | grep -v amdgpu.ids;
+  python3 tools/bench_config5.py 2>/dev/null | grep "^{"; python3 tools/bench_end_to_end.py 2>/dev/null | grep "^{"; } > $OUT/${R}_decode_and_isosurface.txt
 # 6. the 3x3 kernels alone (steady state), with phase stamps and one / two / three blocks per CU; clock + power under them
 [ -x tools/ub_wino24 ] && timeout 400 tools/ub_wino24 2>&1 | grep -v "wino4 " > $OUT/${R}_wino_ubench.txt
 [ -x tools/ub_wino24_t ] && timeout 300 tools/ub_wino24_t 0 2 3 4 5 2>&1 | grep -v "wino4 " > $OUT/${R}_wino_ubench_phases.txt
@@ -54,5 +57,13 @@ python3 bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${R}_bench_d
 # 7. config 3's kernel table
 cd /tmp && rm -rf /tmp/p6 && rocprofv3 --kernel-trace -d /tmp/p6 -o t --output-format csv -- python3 $ROOT/bench.py --config c3 --steps 30 --warmup 5 --no-cpu-baseline --profile-every 0 --traffic off > /tmp/p6.log 2>&1
 python3 $ROOT/tools/prof_summary.py $(find /tmp/p6 -name "*kernel_trace.csv" | head -1) 185 > $OUT/${R}_config3_kernel_summary.txt
+# 8. the training step's kernel table, timeline and stream overlap (the only kernel table of the training step used to live in scratch)
+cd /tmp && rm -rf /tmp/p7 && rocprofv3 --kernel-trace --stats -d /tmp/p7 -o t --output-format csv -- python3 $ROOT/tools/bench_train.py --steps 20 --warmup 3 > /tmp/p7.log 2>&1
+{ grep "^{" /tmp/p7.log | cut -c1-220; python3 $ROOT/tools/prof_summary.py $(find /tmp/p7 -name "*kernel_trace.csv" | head -1) 23;
+  echo; echo "(calls/step of __amd_rocclr_copyBuffer counts the parameter uploads at model load — 23 traced steps; inside a step: 2, the timestep / weight vectors)";
+  echo; python3 $ROOT/tools/trace_overlap.py $(find /tmp/p7 -name "*kernel_trace.csv" | head -1) 0.6; } > $OUT/${R}_train_kernel_summary.txt
+python3 $ROOT/tools/trace_timeline.py $(find /tmp/p7 -name "*kernel_trace.csv" | head -1) k_adamw > $OUT/${R}_train_timeline.txt 2>&1
+rm -rf /tmp/p8 && S3D_BWD_SIDE=0 rocprofv3 --kernel-trace --stats -d /tmp/p8 -o t --output-format csv -- python3 $ROOT/tools/bench_train.py --steps 20 --warmup 3 > /tmp/p8.log 2>&1
+{ echo "S3D_BWD_SIDE=0 (every launch on one stream: per-kernel times without sharing the chip)"; grep "^{" /tmp/p8.log | cut -c1-220; python3 $ROOT/tools/prof_summary.py $(find /tmp/p8 -name "*kernel_trace.csv" | head -1) 23; } > $OUT/${R}_train_kernel_summary_inline.txt
 cd $ROOT
 ls -la $OUT
