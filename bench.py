@@ -294,7 +294,7 @@ def measure_traffic_in_run(config):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--profile-every", "0",
-                   "--prewarm", "4", "--traffic", "off", "--config", config]
+                   "--prewarm", "4", "--traffic", "off", "--chains", "0", "--config", config]
             env = dict(os.environ, TMPDIR=tmp)
             r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
