@@ -833,66 +833,35 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partials(GnBwdArgs a) {
         o[i] = s;
     }
 }
-// Round 5: no launch between the two passes.  Until then k_gn_bwd_fin — one block per (sample, plane) — added the chunk partials
-// (A[b][p][c][2], double, chunk order) and wrote the apply pass's per-channel constants; a 6.8-us dependent launch per GroupNorm,
-// 18.6 us once the backward pass's weight gradients share the chip from a side stream (every tiny launch on the main chain pays
-// the co-scheduling).  Now every block of the apply launch adds the partials of its (sample, plane) itself — the same doubles in
-// the same order, hence the same constants and the same bits — and the parameter / FiLM-gradient blocks add what they need.
-struct GnBwdFin { double count[3]; };
-// A1 / A2 of channel ch of (sample b, plane p): the chunk partials in chunk order (double), rounded to float as the stored A was
-__device__ __forceinline__ void gn_bwd_A(const GnBwdArgs& a, int bp, int ch, float& f1, float& f2) {
-    double s1 = 0, s2 = 0;
+// A[b][p][c][2] = sum over chunks (double) ; then group coefficients and the parameter / FiLM gradients
+struct GnBwdFinArgs {
+    const float* part; float* A; float* coef;
+    const float* gamma[3]; const float* beta[3];
+    float* dgamma[3]; float* dbeta[3];
+    const float* film; float* dfilm; int film_stride;    // dfilm [B][film_stride]: dscale at [0,C), dshift at [C,2C)
+    const float* mr;
+    double count[3];
+    int C, B, nchunk, ngroups;
+};
+// One block per (sample, plane): A[c] = the chunk partials added in chunk order (double), then the group coefficients of the
+// apply pass.  (One launch: the sums used to be a launch of their own ahead of a single-block coefficient kernel — 5.0 + 6.3 us
+// of dependent launches per GroupNorm, ten per training step; folding the sums into that single block cost 16.5 us.)  The
+// parameter and FiLM gradients, which add A over samples / planes, moved into extra blocks of the apply launch.
+__global__ __launch_bounds__(256) void k_gn_bwd_fin(GnBwdFinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sA[];          // [C][2]
+    const int C = a.C, G = a.ngroups, cg = C / G;
+    const int bp = blockIdx.x, b = bp / 3, p = bp % 3;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        double s1 = 0, s2 = 0;
 #pragma unroll 8
-    for (int k = 0; k < a.nchunk; ++k) {
-        const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * a.C + ch) * 2);
-        s1 += q.x; s2 += q.y;
+        for (int k = 0; k < a.nchunk; ++k) {
+            const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * C + ch) * 2);
+            s1 += q.x; s2 += q.y;
+        }
+        const float f1 = float(s1), f2 = float(s2);
+        a.A[(size_t(bp) * C + ch) * 2] = f1; a.A[(size_t(bp) * C + ch) * 2 + 1] = f2;
+        sA[2 * ch] = f1; sA[2 * ch + 1] = f2;
     }
-    f1 = float(s1); f2 = float(s2);
-}
-// extra block (plane p, sample b) of the apply launch: dgamma / dbeta of plane p (sum over the batch; b == 0 only) and the FiLM
-// gradients of sample b (sum over the planes, which share emb_out; p == 0 only)
-__device__ __forceinline__ void gn_bwd_param_grads(const GnBwdArgs& a, int p, int b) {
-    const int C = a.C;
-    if (b == 0)
-        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-            double dg = 0, db = 0;
-            for (int bb = 0; bb < a.B; ++bb) {
-                const double sc = a.film ? 1.0 + a.film[size_t(bb) * a.film_stride + ch] : 1.0;
-                float A0, A1;
-                gn_bwd_A(a, bb * 3 + p, ch, A0, A1);
-                db += sc * A0; dg += sc * A1;
-            }
-            a.dgamma[p][ch] = float(dg); a.dbeta[p][ch] = float(db);
-        }
-    if (p == 0 && a.dfilm)
-        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-            double ds = 0, dh = 0;
-            for (int pp = 0; pp < 3; ++pp) {
-                float A0, A1;
-                gn_bwd_A(a, b * 3 + pp, ch, A0, A1);
-                ds += double(a.gamma[pp][ch]) * A1 + double(a.beta[pp][ch]) * A0;
-                dh += A0;
-            }
-            a.dfilm[size_t(b) * a.film_stride + ch] = float(ds);
-            a.dfilm[size_t(b) * a.film_stride + C + ch] = float(dh);
-        }
-}
-// block = (plane, sample, chunk of the plane's pixels); thread = (pixel lane, channel quad): the quad's constants sit in
-// registers and four pixels are in flight per trip
-__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, int nchunk, GnBwdFin fin) {
-    extern __shared__ __attribute__((aligned(16))) float sm_ap[];       // sA [C][2], then coef [C][8]
-    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
-    if (chunk == nchunk) { gn_bwd_param_grads(a, p, b); return; }
-    const int w = a.w[p], h = a.h[p], C = a.C, G = a.ngroups, cg = C / G, bp = b * 3 + p;
-    const int npix = h * w;
-    const int p0 = int((long long)npix * chunk / nchunk), p1 = int((long long)npix * (chunk + 1) / nchunk);
-    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
-    const float4* xs = reinterpret_cast<const float4*>(a.x[p]);
-    const float4* as = reinterpret_cast<const float4*>(a.add[p]);
-    float4* dxs = reinterpret_cast<float4*>(a.dx[p]);
-    float* sA = sm_ap;
-    float* sC = sm_ap + 2 * C;
-    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) gn_bwd_A(a, bp, ch, sA[2 * ch], sA[2 * ch + 1]);
     __syncthreads();
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         double g1 = 0, g2 = 0;
@@ -905,22 +874,60 @@ __global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, int nchunk, G
         // per-channel constants of the apply pass, 8 floats per channel:
         //   xh = x*c0 + c1 ; z = xh*c2 + c3 ; dx = dz*c4 - c5 - xh*c6        (c7 unused)
         const float mean = a.mr[(size_t(bp) * G + g) * 2], rstd = a.mr[(size_t(bp) * G + g) * 2 + 1];
-        const float k1 = float(g1 / fin.count[p]), k2 = float(g2 / fin.count[p]);
+        const float k1 = float(g1 / a.count[p]), k2 = float(g2 / a.count[p]);
         for (int k = 0; k < cg; ++k) {
             const int ch = g * cg + k;
             const float sc = a.film ? 1.0f + a.film[size_t(b) * a.film_stride + ch] : 1.0f;
             const float sh = a.film ? a.film[size_t(b) * a.film_stride + C + ch] : 0.0f;
             const float gam = a.gamma[p][ch], bet = a.beta[p][ch];
-            float* o = sC + size_t(ch) * 8;
+            float* o = a.coef + (size_t(bp) * C + ch) * 8;
             o[0] = rstd; o[1] = -mean * rstd; o[2] = gam * sc; o[3] = bet * sc + sh;
             o[4] = rstd * gam * sc; o[5] = rstd * k1; o[6] = rstd * k2; o[7] = 0.f;
         }
     }
-    __syncthreads();
-    const float4* ct = reinterpret_cast<const float4*>(sC + size_t(4 * q) * 8);
+}
+// extra block (plane p, sample b) of the apply launch: dgamma / dbeta of plane p (sum over the batch; b == 0 only) and the FiLM
+// gradients of sample b (sum over the planes, which share emb_out; p == 0 only)
+__device__ __forceinline__ void gn_bwd_param_grads(const GnBwdArgs& a, int p, int b) {
+    const int C = a.C;
+    if (b == 0)
+        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+            double dg = 0, db = 0;
+            for (int bb = 0; bb < a.B; ++bb) {
+                const double sc = a.film ? 1.0 + a.film[size_t(bb) * a.film_stride + ch] : 1.0;
+                const float* A = a.A + ((size_t(bb) * 3 + p) * C + ch) * 2;
+                db += sc * A[0]; dg += sc * A[1];
+            }
+            a.dgamma[p][ch] = float(dg); a.dbeta[p][ch] = float(db);
+        }
+    if (p == 0 && a.dfilm)
+        for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+            double ds = 0, dh = 0;
+            for (int pp = 0; pp < 3; ++pp) {
+                const float* A = a.A + ((size_t(b) * 3 + pp) * C + ch) * 2;
+                ds += double(a.gamma[pp][ch]) * A[1] + double(a.beta[pp][ch]) * A[0];
+                dh += A[0];
+            }
+            a.dfilm[size_t(b) * a.film_stride + ch] = float(ds);
+            a.dfilm[size_t(b) * a.film_stride + C + ch] = float(dh);
+        }
+}
+// block = (plane, sample, chunk of the plane's pixels); thread = (pixel lane, channel quad): the quad's constants sit in
+// registers and four pixels are in flight per trip
+__global__ __launch_bounds__(256) void k_gn_bwd_apply(GnBwdArgs a, int nchunk) {
+    const int chunk = blockIdx.x, p = blockIdx.y, b = blockIdx.z;
+    if (chunk == nchunk) { gn_bwd_param_grads(a, p, b); return; }
+    const int w = a.w[p], h = a.h[p];
+    const int npix = h * w;
+    const int p0 = int((long long)npix * chunk / nchunk), p1 = int((long long)npix * (chunk + 1) / nchunk);
+    const int q = threadIdx.x % a.cq, l = threadIdx.x / a.cq;
+    const float4* ct = reinterpret_cast<const float4*>(a.coef + ((size_t(b) * 3 + p) * a.C + 4 * q) * 8);
     float4 c0[4], c1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { c0[k] = ct[2 * k]; c1[k] = ct[2 * k + 1]; }
+    const float4* xs = reinterpret_cast<const float4*>(a.x[p]);
+    const float4* as = reinterpret_cast<const float4*>(a.add[p]);
+    float4* dxs = reinterpret_cast<float4*>(a.dx[p]);
     constexpr int U = 4;
     for (int i0 = p0 + l; i0 < p1; i0 += U * a.pl) {
         float4 x[U], dy[U], ad[U];
@@ -977,14 +984,21 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     if (!s.B || !begin[3]) return 0;
     hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(a.cq * a.pl), size_t(a.pl) * x.C * 2 * sizeof(float), st, a);
     S3D_HIP(hipGetLastError());
-    GnBwdFin f;
-    for (int p = 0; p < 3; ++p) f.count[p] = double(x.C / s.ngroups) * x.g.h[p] * x.g.w[p];
+    GnBwdFinArgs f;
+    f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride; f.mr = s.stats.mr;
+    for (int p = 0; p < 3; ++p) {
+        f.gamma[p] = s.gamma[p]; f.beta[p] = s.beta[p]; f.dgamma[p] = s.dgamma[p]; f.dbeta[p] = s.dbeta[p];
+        f.count[p] = double(x.C / s.ngroups) * x.g.h[p] * x.g.w[p];
+    }
+    f.C = x.C; f.B = s.B; f.nchunk = kGnBwdChunks; f.ngroups = s.ngroups;
+    hipLaunchKernelGGL(k_gn_bwd_fin, dim3(s.B * 3), dim3(256), size_t(x.C) * 2 * sizeof(float), st, f);
+    S3D_HIP(hipGetLastError());
     a.A = A; a.dfilm = s.dfilm;
     for (int p = 0; p < 3; ++p) { a.dgamma[p] = s.dgamma[p]; a.dbeta[p] = s.dbeta[p]; }
     long long maxpix = 0;
     for (int p = 0; p < 3; ++p) maxpix = std::max(maxpix, (long long)x.g.h[p] * x.g.w[p]);
     const int nchunk = int(std::max(1LL, (maxpix + a.pl * 8 - 1) / (a.pl * 8)));          // two trips of four pixels per thread
-    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(nchunk + 1, 3, s.B), dim3(a.cq * a.pl), size_t(x.C) * 10 * sizeof(float), st, a, nchunk, f);   // (+1: the parameter-gradient blocks)
+    hipLaunchKernelGGL(k_gn_bwd_apply, dim3(nchunk + 1, 3, s.B), dim3(a.cq * a.pl), 0, st, a, nchunk);   // (+1: the parameter-gradient blocks)
     S3D_HIP(hipGetLastError());
     return 0;
 }

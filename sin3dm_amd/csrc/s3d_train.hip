@@ -220,14 +220,6 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         if (!m->bwd_side) {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            // (experiment) S3D_BWD_SIDE_MASK=<hex word>: the side stream on the CUs whose bit is set in the word, repeated over the part
-            const char* mk = getenv("S3D_BWD_SIDE_MASK");
-            if (mk && *mk) {
-                const uint32_t word = uint32_t(strtoul(mk, nullptr, 16));
-                uint32_t mask[8];
-                for (int k = 0; k < 8; ++k) mask[k] = word;
-                S3D_HIP(hipExtStreamCreateWithCUMask(&m->bwd_side, 8, mask));
-            } else
             S3D_HIP(hipStreamCreateWithPriority(&m->bwd_side, hipStreamNonBlocking, least));
         }
         b.sw = m->bwd_side;

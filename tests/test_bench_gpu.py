@@ -35,3 +35,18 @@ def test_bench_line_contract_and_live_roofline(config, launches_per_step, kernel
     assert r["launches_timed"] == 4 * launches_per_step and kernel in r["kernel"]
     assert r["conv3x3_ms_per_step"] <= d["ms_per_step"] * 1.05          # (events on every step cost a little)
     assert "cpu_baseline" not in d
+    if config == "c2":
+        # the same workload as two independent chains, measured in the same run and reported BESIDE the headline
+        c = d["chains2"]
+        assert c["chains"] == 2 and c["unit"] == "samples/s" and c["value"] > 0 and c["per_chain_latency_ms"] > d["ms_per_step"] * 0.9
+        assert abs(c["ms_per_step_per_sample"] * 2 - c["per_chain_latency_ms"]) < 1e-6 * c["per_chain_latency_ms"]
+        assert "16 step(s)" in d["data"]
+    else:
+        assert d["chains2"] is None
+        w = r["wgrad3x3"]                                               # the 3x3 weight-gradient launches: eight per training step
+        assert w["launches_timed"] == 4 * 8 and "k_wgrad_wino" in w["kernel"] and 0.02 < w["frac"] < 1.0
+
+
+def test_bench_chains_can_be_switched_off():
+    d = _line("--config", "c2", "--chains", "0")
+    assert d["chains2"] is None
