@@ -41,7 +41,7 @@ int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, 
                     float* colsum, hipStream_t st);
 int launch_add_slice(const float* a, const float* b, int bstride, int coff, float* out, long long rows, int C, hipStream_t st);
 size_t colsum_ws_floats(int C);
-int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st);
+int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st, float* out2 = nullptr);   // out2: a second parameter with the same gradient
 int launch_last_fwd(const float* h, const float* W, const float* b, int I, int O, int sigm, float* pred, int pstride, int ooff,
                     long long N, hipStream_t st);
 size_t last_bwd_ws_floats(int I, int O);

@@ -318,6 +318,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // ---- MLPs
     float* dX0[2];
     float* cws = ar.alloc<float>(colsum_ws_floats(std::max(hid, up)));
+    float* cws2 = ar.alloc<float>(colsum_ws_floats(up));           // the plane blocks' bias sums (side stream) have a workspace of their own
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
         float* dH = ar.alloc<float>(size_t(Np) * hid);            // gradient of a hidden activation (reused)
@@ -374,11 +375,13 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             dw_out[p] = R.G(N_.f_out_w + size_t(p) * up * up * 25); dw_sc[p] = R.G(N_.f_sc_w + size_t(p) * up * N_.cin);
             dw_in[p] = R.G(N_.f_in_w + size_t(p) * up * N_.cin * 25);
         }
-        if (!meas)
-            for (int p = 0; p < 3; ++p) {              // out conv and shortcut share dy: identical bias gradients
-                S3D_TRY(launch_colsum(dF[n][p], (long long)hw[p], up, cws, R.G(N_.f_out_b + size_t(p) * up), st));
-                S3D_TRY(launch_colsum(dF[n][p], (long long)hw[p], up, cws, R.G(N_.f_sc_b + size_t(p) * up), st));
-            }
+        // bias gradients are column sums nobody inside the pass reads: side stream (the workspace `cws2` belongs to it in this phase)
+        hipStream_t sb = R.side ? R.sw : st;
+        if (!meas) {
+            S3D_TRY(R.edge(st, sb));
+            for (int p = 0; p < 3; ++p)                // out conv and shortcut share dy: identical bias gradients, one pass, two outputs
+                S3D_TRY(launch_colsum(dF[n][p], (long long)hw[p], up, cws2, R.G(N_.f_out_b + size_t(p) * up), sb, R.G(N_.f_sc_b + size_t(p) * up)));
+        }
         S3D_TRY(R.conv(CONV_5x5, up, up, g, dF[n], w_outT, nullptr, nullptr, d_y));
         S3D_TRY(R.wgrad(25, up, up, up, g, dF[n], up, T.y, dw_out));
         S3D_TRY(R.conv(CONV_1x1, up, 32, g, dF[n], w_scT, nullptr, nullptr, d_xs));
@@ -395,8 +398,10 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             s.ws = ar.alloc<float>(gn_bwd_ws_floats(1, up));
             if (!meas) S3D_TRY(launch_gn_act_bwd(s, st));
         }
-        if (!meas)
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_colsum(d_a1[p], (long long)hw[p], up, cws, R.G(N_.f_in_b + size_t(p) * up), st));
+        if (!meas) {
+            S3D_TRY(R.edge(st, sb));                    // d_a1 is final
+            for (int p = 0; p < 3; ++p) S3D_TRY(launch_colsum(d_a1[p], (long long)hw[p], up, cws2, R.G(N_.f_in_b + size_t(p) * up), sb));
+        }
         S3D_TRY(R.wgrad(25, 32, N_.cin, up, g, d_a1, 32, T.x, dw_in));
         S3D_TRY(R.conv(CONV_5x5, up, 32, g, d_a1, w_inT, nullptr, d_xs, d_x));
         if (!meas)

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dact
         part[size_t(blockIdx.x) * C + c] = t;
     }
 }
-__global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, float* __restrict__ out, int C) {
+__global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ part, float* __restrict__ out, int C, float* __restrict__ out2 = nullptr) {
     // block = 64 columns x 4 chunk lanes (lane j adds chunks j, j+4, ... in double; the four sums meet through LDS in lane
     // order): one thread per column walked 256 dependent loads in four blocks, 11 us, 28 times per iteration
     __shared__ double red[4][64];
@@ -511,7 +511,11 @@ __global__ __launch_bounds__(256) void k_colsum_fin(const float* __restrict__ pa
         for (int k = kl; k < kColChunks; k += 4) s += part[size_t(k) * C + c];
     red[kl][l] = s;
     __syncthreads();
-    if (kl == 0 && c < C) out[c] = float(((red[0][l] + red[1][l]) + red[2][l]) + red[3][l]);
+    if (kl == 0 && c < C) {
+        const float v = float(((red[0][l] + red[1][l]) + red[2][l]) + red[3][l]);
+        out[c] = v;
+        if (out2) out2[c] = v;                            // (two parameters with the same gradient: the out convolution's and the shortcut's bias)
+    }
 }
 int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,
                     float* colsum, hipStream_t st) {
@@ -520,7 +524,7 @@ int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, 
     const int cq = C / 4, pl = std::max(1, 256 / cq);
     hipLaunchKernelGGL(k_relu_bwd, dim3(kColChunks), dim3(cq * pl), size_t(pl) * C * sizeof(float), st, dact, dstride, coff, act, dpre, rows, C, ws);
     S3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, colsum, C);
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, colsum, C, (float*)nullptr);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -547,10 +551,10 @@ __global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x
     }
 }
 size_t colsum_ws_floats(int C) { return size_t(kColChunks) * C; }
-int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st) {
+int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, hipStream_t st, float* out2) {
     hipLaunchKernelGGL(k_colsum_part, dim3(kColChunks), dim3(256), 0, st, x, ws, rows, C);
     S3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, out, C);
+    hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, out, C, out2);
     S3D_HIP(hipGetLastError());
     return 0;
 }
