@@ -153,7 +153,8 @@ class _TriplaneUNetBase(nn.Module):
     def _select_lane(self, k):
         if not 0 <= k < _lib.MAX_LANES:
             raise AssertionError(f"lane must be in [0, {_lib.MAX_LANES})")
-        lib = self._ensure_handle()
+        # (entered and left around every step of a chain: the parameter sync of _ensure_handle is the callee's job, not this switch's)
+        lib = _lib.load() if self._handle is not None else self._ensure_handle()
         _lib.check(lib.s3d_unet_select_lane(self._handle, k))
         self._lane = k
 
