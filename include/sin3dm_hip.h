@@ -54,7 +54,8 @@ S3D_API int s3d_abi_version(void);
  *   CONV_IMPL     "naive": one-thread-per-output reference kernels (tests)                                   (rounding differs)
  *   CONV1X1_T     unset: by launch size | 0 never | 1 always the transposed-accumulator 1x1 epilogue         (bit-identical)
  *   GN_FUSED      unset: by launch size | 0: GroupNorm partials added ahead of the consumer | 1: inside it   (bit-identical)
- *   BWD_SIDE      0: the backward pass's weight-gradient launches stay on the caller's stream (default: a side stream) (bit-identical)
+ *   BWD_SIDE      0: every launch of a training step stays on the caller's stream (default: weight gradients on a side stream, the
+ *                 auto-encoder's two nets as two chains)                                                     (bit-identical)
  * s3d_get_option: the current value, -1 when unset. */
 S3D_API int s3d_set_option(const char* name, const char* value);
 S3D_API int s3d_get_option(const char* name, int* value);

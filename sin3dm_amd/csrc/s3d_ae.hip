@@ -64,10 +64,12 @@ struct s3d_ae {
     // backward pass: weight-gradient launches (no consumer before the optimizer) on a handle-owned low-priority side stream, beside
     // the chain of input gradients — as in the denoiser's backward pass (s3d_train.hip: Bwd::edge / join)
     hipStream_t side = nullptr;
+    hipStream_t chain2 = nullptr;       // the texture MLP's backward chain beside the geometry MLP's (the two nets only meet at the scatter)
     std::vector<hipEvent_t> events;
     ~s3d_ae() {
         for (auto e : events) (void)hipEventDestroy(e);
         if (side) (void)hipStreamDestroy(side);
+        if (chain2) (void)hipStreamDestroy(chain2);
     }
     const float* P(size_t off) const { return static_cast<const float*>(pbuf.p) + off; }
     size_t off_of(const std::string& n) const {
@@ -171,7 +173,7 @@ struct AeRun {
     float* G(size_t off) const { return grads ? grads + off : reinterpret_cast<float*>(uintptr_t(256)); }
 
     int conv(ConvKind kind, int cin, int cout, const Geo& g, float* const in[3], const float* const wgt[3], const float* const bias[3],
-             float* const res[3], float* const out[3], int njobs = 3, bool relu = false) {
+             float* const res[3], float* const out[3], int njobs = 3, bool relu = false, hipStream_t on = nullptr, bool use_on = false) {
         if (meas()) return 0;
         ConvArgs ca; memset(&ca, 0, sizeof ca);
         ca.B = 1; ca.cin = cin; ca.cout = cout; ca.njobs = njobs; ca.relu = relu ? 1 : 0;
@@ -180,10 +182,11 @@ struct AeRun {
             J.in = in[p]; J.wgt = wgt[p]; J.bias = bias ? bias[p] : nullptr; J.res = res ? res[p] : nullptr; J.out = out[p];
             J.h = g.h[p]; J.w = g.w[p];
         }
-        return launch_conv(kind, ca, st);
+        return launch_conv(kind, ca, use_on ? on : st);
     }
+    // from / use_from: the stream dy was produced on when it is not the caller's (the second MLP chain)
     int wgrad(int taps, int cin, int cin_store, int cout, const Geo& g, float* const dy[3], int a_cstride, float* const act[3],
-              float* const dW[3], int nplanes = 3) {
+              float* const dW[3], int nplanes = 3, hipStream_t from = nullptr, bool use_from = false) {
         WgradArgs w;
         w.dy.C = cout; w.a.C = a_cstride; w.dy.g = w.a.g = g;
         for (int p = 0; p < 3; ++p) { w.dy.p[p] = p < nplanes ? dy[p] : nullptr; w.a.p[p] = p < nplanes ? act[p] : nullptr; }
@@ -191,8 +194,9 @@ struct AeRun {
         w.ksplit = wgrad_ksplit(g, 1, cin, cout, taps);
         for (int p = 0; p < nplanes; ++p) { w.part[p] = ar().alloc<float>(wgrad_part_floats(w.ksplit, cin, cout, taps)); w.dW[p] = dW[p]; }
         if (meas()) return 0;
-        hipStream_t on = side ? sw : st;
-        S3D_TRY(edge(st, on));                             // dy and the activation are final in the order of the caller's stream
+        hipStream_t src = use_from ? from : st;
+        hipStream_t on = side ? sw : src;
+        S3D_TRY(edge(src, on));                            // dy and the activation are final in the order of the stream that produced them
         return launch_wgrad(w, on);
     }
 };
@@ -219,6 +223,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             S3D_HIP(hipStreamCreateWithPriority(&a->side, hipStreamNonBlocking, least));
         }
+        if (!a->chain2) S3D_HIP(hipStreamCreateWithFlags(&a->chain2, hipStreamNonBlocking));
         R.sw = a->side;
         R.side = true;
     }
@@ -237,9 +242,14 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
 
     // ---- plane blocks
     struct NetAct { float *x[3], *a1[3], *y[3], *s[3], *f[3], *mr; double* part[3]; } A[2];
+    // (training with the side streams on: the texture net's plane blocks run as a second chain beside the geometry net's — they
+    // share nothing but the encoder's feature planes — here, and again in the backward pass)
+    if (!meas && R.side) S3D_TRY(R.edge(st, a->chain2));
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
         NetAct& T = A[n];
+        const bool second = n == 1 && R.side && !meas;
+        hipStream_t cs = second ? a->chain2 : st;
         for (int p = 0; p < 3; ++p) {
             T.x[p] = ar.alloc<float>(hw[p] * 32); T.a1[p] = ar.alloc<float>(hw[p] * up); T.y[p] = ar.alloc<float>(hw[p] * up);
             T.s[p] = ar.alloc<float>(hw[p] * up); T.f[p] = ar.alloc<float>(hw[p] * up);
@@ -253,16 +263,17 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             w_sc[p] = a->P(N_.sc_dense[p]); b_sc[p] = R.F(N_.f_sc_b + size_t(p) * up);
         }
         if (!meas)
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_slice_pad_nhwc(feat[p], T.x[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, st));
-        S3D_TRY(R.conv(CONV_5x5, 32, up, g, T.x, w_in, b_in, nullptr, T.a1));
+            for (int p = 0; p < 3; ++p) S3D_TRY(launch_slice_pad_nhwc(feat[p], T.x[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, cs));
+        S3D_TRY(R.conv(CONV_5x5, 32, up, g, T.x, w_in, b_in, nullptr, T.a1, 3, false, cs, true));
         if (!meas)
             for (int p = 0; p < 3; ++p) {
-                S3D_TRY(launch_inorm_silu(T.a1[p], T.part[p], R.F(N_.f_gamma[p]), R.F(N_.f_beta[p]), T.y[p], int(hw[p]), up, 1e-6f, st));
-                S3D_TRY(launch_mr_from_partials(T.part[p], kInNormChunks, up, double(hw[p]), 1e-6f, T.mr + size_t(p) * up * 2, st));
+                S3D_TRY(launch_inorm_silu(T.a1[p], T.part[p], R.F(N_.f_gamma[p]), R.F(N_.f_beta[p]), T.y[p], int(hw[p]), up, 1e-6f, cs));
+                S3D_TRY(launch_mr_from_partials(T.part[p], kInNormChunks, up, double(hw[p]), 1e-6f, T.mr + size_t(p) * up * 2, cs));
             }
-        S3D_TRY(R.conv(CONV_1x1, 32, up, g, T.x, w_sc, b_sc, nullptr, T.s));
-        S3D_TRY(R.conv(CONV_5x5, up, up, g, T.y, w_out, b_out, T.s, T.f));
+        S3D_TRY(R.conv(CONV_1x1, 32, up, g, T.x, w_sc, b_sc, nullptr, T.s, 3, false, cs, true));
+        S3D_TRY(R.conv(CONV_5x5, up, up, g, T.y, w_out, b_out, T.s, T.f, 3, false, cs, true));
     }
+    if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the gather reads both nets' planes
 
     // ---- points: gather, MLPs
     PointSet ps; ps.pts = pts; ps.N = N; ps.Np = Np;
@@ -319,14 +330,22 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     float* dX0[2];
     float* cws = ar.alloc<float>(colsum_ws_floats(std::max(hid, up)));
     float* cws2 = ar.alloc<float>(colsum_ws_floats(up));           // the plane blocks' bias sums (side stream) have a workspace of their own
+    // The two MLPs' backward chains are independent until the scatter: the texture net's runs on a second stream beside the
+    // geometry net's (side-stream builds only) — each alternates a bandwidth-bound ReLU backward with an MFMA-bound 1x1 dgrad, so
+    // the two chains want different things at most times.  Same kernels on the same operands: same bits.
+    float* cws_n[2] = {cws, ar.alloc<float>(colsum_ws_floats(std::max(hid, up)))};
+    if (!meas && R.side) S3D_TRY(R.edge(st, a->chain2));
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
+        const bool second = n == 1 && R.side && !meas;
+        hipStream_t cs = second ? a->chain2 : st;                  // this net's chain
+        float* cws = cws_n[n];
         float* dH = ar.alloc<float>(size_t(Np) * hid);            // gradient of a hidden activation (reused)
         float* dCAT = ar.alloc<float>(size_t(Np) * (up + hid));
         float* dXa = ar.alloc<float>(size_t(Np) * up);
         dX0[n] = ar.alloc<float>(size_t(Np) * up);
         float* lws = ar.alloc<float>(last_bwd_ws_floats(hid, N_.nout));
-        if (!meas) S3D_TRY(launch_last_bwd(dout, S, n == 0 ? 0 : 1, R.F(N_.f_mw[5]), H[n][4], hid, N_.nout, Np, dH, lws, R.G(N_.f_mw[5]), R.G(N_.f_mb[5]), st));
+        if (!meas) S3D_TRY(launch_last_bwd(dout, S, n == 0 ? 0 : 1, R.F(N_.f_mw[5]), H[n][4], hid, N_.nout, Np, dH, lws, R.G(N_.f_mw[5]), R.G(N_.f_mb[5]), cs));
         // hidden layers 4..0: dP = dH * relu'(H_l) ; db_l = colsum(dP) ; dW_l = dP^T in_l ; d in_l = dP W_l
         struct Step { int l; float* act; float* in; int in_stride; float* din; const float* dact; int dstride, coff; };
         const Step steps[5] = {{4, H[n][4], H[n][3], hid, dH, dH, hid, 0},
@@ -339,16 +358,17 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             // gradient of the layer's pre-activation: one buffer per layer — the weight gradient that reads it runs on the side
             // stream while this chain has moved on
             float* dP = ar.alloc<float>(size_t(Np) * hid);
-            if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws, R.G(N_.f_mb[s.l]), st));
+            if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws, R.G(N_.f_mb[s.l]), cs));
             Geo g1; for (int p = 0; p < 3; ++p) { g1.h[p] = p == 0 ? int(Np / 64) : 0; g1.w[p] = p == 0 ? 64 : 0; }
             float* dy3[3] = {dP, nullptr, nullptr}; float* a3[3] = {s.in, nullptr, nullptr}; float* dw3[3] = {R.G(N_.f_mw[s.l]), nullptr, nullptr};
-            S3D_TRY(R.wgrad(1, I, I, O, g1, dy3, s.in_stride, a3, dw3, 1));
+            S3D_TRY(R.wgrad(1, I, I, O, g1, dy3, s.in_stride, a3, dw3, 1, cs, true));
             const float* wT[3] = {a->P(N_.mT[s.l]), nullptr, nullptr};
             float* o3[3] = {s.din, nullptr, nullptr};
-            S3D_TRY(R.conv(CONV_1x1, O, I, g1, dy3, wT, nullptr, nullptr, o3, 1));
+            S3D_TRY(R.conv(CONV_1x1, O, I, g1, dy3, wT, nullptr, nullptr, o3, 1, false, cs, true));
         }
-        if (!meas) S3D_TRY(launch_add_slice(dXa, dCAT, up + hid, 0, dX0[n], Np, up, st));
+        if (!meas) S3D_TRY(launch_add_slice(dXa, dCAT, up + hid, 0, dX0[n], Np, up, cs));
     }
+    if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the scatter reads both nets' point gradients
     // ---- scatter the point gradients onto the planes
     float* dF[2][3];
     for (int n = 0; n < 2; ++n) for (int p = 0; p < 3; ++p) dF[n][p] = ar.alloc<float>(hw[p] * up);
@@ -360,9 +380,12 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // ---- plane blocks
     float* dfeat[3];
     for (int p = 0; p < 3; ++p) dfeat[p] = ar.alloc<float>(hw[p] * CO);
+    if (!meas && R.side) S3D_TRY(R.edge(st, a->chain2));          // (the scatter's plane gradients are final)
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
         NetAct& T = A[n];
+        const bool second = n == 1 && R.side && !meas;
+        hipStream_t cs = second ? a->chain2 : st;                  // this net's chain (see the forward pass)
         float *d_y[3], *d_xs[3], *d_a1[3], *d_x[3];
         for (int p = 0; p < 3; ++p) {
             d_y[p] = ar.alloc<float>(hw[p] * up); d_xs[p] = ar.alloc<float>(hw[p] * 32);
@@ -378,14 +401,14 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         // bias gradients are column sums nobody inside the pass reads: side stream (the workspace `cws2` belongs to it in this phase)
         hipStream_t sb = R.side ? R.sw : st;
         if (!meas) {
-            S3D_TRY(R.edge(st, sb));
+            S3D_TRY(R.edge(cs, sb));
             for (int p = 0; p < 3; ++p)                // out conv and shortcut share dy: identical bias gradients, one pass, two outputs
                 S3D_TRY(launch_colsum(dF[n][p], (long long)hw[p], up, cws2, R.G(N_.f_out_b + size_t(p) * up), sb, R.G(N_.f_sc_b + size_t(p) * up)));
         }
-        S3D_TRY(R.conv(CONV_5x5, up, up, g, dF[n], w_outT, nullptr, nullptr, d_y));
-        S3D_TRY(R.wgrad(25, up, up, up, g, dF[n], up, T.y, dw_out));
-        S3D_TRY(R.conv(CONV_1x1, up, 32, g, dF[n], w_scT, nullptr, nullptr, d_xs));
-        S3D_TRY(R.wgrad(1, 32, N_.cin, up, g, dF[n], 32, T.x, dw_sc));
+        S3D_TRY(R.conv(CONV_5x5, up, up, g, dF[n], w_outT, nullptr, nullptr, d_y, 3, false, cs, true));
+        S3D_TRY(R.wgrad(25, up, up, up, g, dF[n], up, T.y, dw_out, 3, cs, true));
+        S3D_TRY(R.conv(CONV_1x1, up, 32, g, dF[n], w_scT, nullptr, nullptr, d_xs, 3, false, cs, true));
+        S3D_TRY(R.wgrad(1, 32, N_.cin, up, g, dF[n], 32, T.x, dw_sc, 3, cs, true));
         {   // InstanceNorm(affine) + SiLU backward = GroupNorm backward with one channel per group
             GnActBwd s;
             s.x.C = s.dy.C = s.dx.C = up; s.x.g = s.dy.g = s.dx.g = g;
@@ -396,17 +419,18 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             s.rowadd = nullptr; s.coladd = nullptr; s.add = nullptr; s.stats.mr = T.mr; s.film = nullptr; s.dfilm = nullptr; s.film_stride = 0;
             s.B = 1; s.ngroups = up;
             s.ws = ar.alloc<float>(gn_bwd_ws_floats(1, up));
-            if (!meas) S3D_TRY(launch_gn_act_bwd(s, st));
+            if (!meas) S3D_TRY(launch_gn_act_bwd(s, cs));
         }
         if (!meas) {
-            S3D_TRY(R.edge(st, sb));                    // d_a1 is final
+            S3D_TRY(R.edge(cs, sb));                    // d_a1 is final
             for (int p = 0; p < 3; ++p) S3D_TRY(launch_colsum(d_a1[p], (long long)hw[p], up, cws2, R.G(N_.f_in_b + size_t(p) * up), sb));
         }
-        S3D_TRY(R.wgrad(25, 32, N_.cin, up, g, d_a1, 32, T.x, dw_in));
-        S3D_TRY(R.conv(CONV_5x5, up, 32, g, d_a1, w_inT, nullptr, d_xs, d_x));
+        S3D_TRY(R.wgrad(25, 32, N_.cin, up, g, d_a1, 32, T.x, dw_in, 3, cs, true));
+        S3D_TRY(R.conv(CONV_5x5, up, 32, g, d_a1, w_inT, nullptr, d_xs, d_x, 3, false, cs, true));
         if (!meas)
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_unslice_nhwc(d_x[p], dfeat[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, st));
+            for (int p = 0; p < 3; ++p) S3D_TRY(launch_unslice_nhwc(d_x[p], dfeat[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, cs));
     }
+    if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the encoder's backward reads both nets' slices of dfeat
     // ---- encoder
     float* dpre[3];
     for (int p = 0; p < 3; ++p) dpre[p] = ar.alloc<float>(hw[p] * CO);
