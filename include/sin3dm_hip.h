@@ -56,6 +56,8 @@ S3D_API int s3d_abi_version(void);
  *   GN_FUSED      unset: by launch size | 0: GroupNorm partials added ahead of the consumer | 1: inside it   (bit-identical)
  *   BWD_SIDE      0: every launch of a training step stays on the caller's stream (default: weight gradients on a side stream, the
  *                 auto-encoder's two nets as two chains)                                                     (bit-identical)
+ *   GNB_FUSED     0: the GroupNorm backward's two per-channel sums always from its own read pass (default: from the epilogue of
+ *                 the input-gradient convolution in front of it where that is the mixed Winograd kernel)     (rounding differs)
  * s3d_get_option: the current value, -1 when unset. */
 S3D_API int s3d_set_option(const char* name, const char* value);
 S3D_API int s3d_get_option(const char* name, int* value);

@@ -58,6 +58,9 @@ struct GnActBwd {
     float* ws;                                                // gn_bwd_ws_floats(B, C)
     int B;
     int ngroups = 32;                                         // GroupNorm32; C for an InstanceNorm
+    // the two per-channel sums were left by the input-gradient convolution that produced dy (k_conv_wino24s_gnb): per-tile records in
+    // the GroupNorm-partial layout with one subgroup per channel — no read pass over (x, dy) then
+    const GnPartials* conv_part = nullptr;
 };
 size_t gn_bwd_ws_floats(int B, int C);
 int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st);
@@ -77,6 +80,9 @@ int launch_small_outer(const SmallOuter& s, hipStream_t st);
 int launch_pool_bwd_add(const Tri* dpool, const Tri* dskip, int skip_coff, int B, Tri& out, hipStream_t st);
 int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out_cstride, int out_coff, float* din, int hi,
                         int wi, hipStream_t st);
+// the three planes of a triplane in one launch (same per-element arithmetic)
+int launch_bilinear_bwd3(const float* const dout[3], int B, int C, const int ho[3], const int wo[3], int out_cstride, int out_coff,
+                         float* const din[3], const int hi[3], const int wi[3], hipStream_t st);
 // y = L(f(in)): dW/db (when dW != null) and dx = (dy W) * f'(in) (when dx != null); dy rows are dy_stride apart
 int launch_linear_bwd(const float* dy, int dy_stride, const float* in, int B, int I, const float* W, int O, int in_mode, float* dW,
                       float* db, float* dx, hipStream_t st);

@@ -835,6 +835,7 @@ __global__ __launch_bounds__(256) void k_gn_bwd_partials(GnBwdArgs a) {
 }
 // A[b][p][c][2] = sum over chunks (double) ; then group coefficients and the parameter / FiLM gradients
 struct GnBwdFinArgs {
+    const double* dpart; int dmaxparts; int dnparts[3];   // != null: the sums come from the dgrad convolution's epilogue, [b][plane][channel][tile][2] doubles
     const float* part; float* A; float* coef;
     const float* gamma[3]; const float* beta[3];
     float* dgamma[3]; float* dbeta[3];
@@ -853,10 +854,17 @@ __global__ __launch_bounds__(256) void k_gn_bwd_fin(GnBwdFinArgs a) {
     const int bp = blockIdx.x, b = bp / 3, p = bp % 3;
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
         double s1 = 0, s2 = 0;
+        if (a.dpart) {                                    // tile records of k_conv_wino24s_gnb, added in tile order
+            const double* q = a.dpart + (size_t(bp) * C + ch) * a.dmaxparts * 2;
+            const int n = a.dnparts[p];
+#pragma unroll 4
+            for (int k = 0; k < n; ++k) { s1 += q[2 * k]; s2 += q[2 * k + 1]; }
+        } else {
 #pragma unroll 8
-        for (int k = 0; k < a.nchunk; ++k) {
-            const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * C + ch) * 2);
-            s1 += q.x; s2 += q.y;
+            for (int k = 0; k < a.nchunk; ++k) {
+                const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * C + ch) * 2);
+                s1 += q.x; s2 += q.y;
+            }
         }
         const float f1 = float(s1), f2 = float(s2);
         a.A[(size_t(bp) * C + ch) * 2] = f1; a.A[(size_t(bp) * C + ch) * 2 + 1] = f2;
@@ -982,9 +990,14 @@ int launch_gn_act_bwd(const GnActBwd& s, hipStream_t st) {
     float* coef = A + size_t(s.B) * 3 * x.C * 2;
     a.part = part; a.coef = coef;
     if (!s.B || !begin[3]) return 0;
-    hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(a.cq * a.pl), size_t(a.pl) * x.C * 2 * sizeof(float), st, a);
-    S3D_HIP(hipGetLastError());
+    if (!s.conv_part) {
+        hipLaunchKernelGGL(k_gn_bwd_partials, dim3(kGnBwdChunks, 3, s.B), dim3(a.cq * a.pl), size_t(a.pl) * x.C * 2 * sizeof(float), st, a);
+        S3D_HIP(hipGetLastError());
+    } else S3D_CHECK(s.conv_part->nsub == x.C && s.conv_part->p, S3D_ERR_INVALID, "gn_act_bwd: the convolution's partial records must be per channel");
     GnBwdFinArgs f;
+    f.dpart = s.conv_part ? s.conv_part->p : nullptr;
+    f.dmaxparts = s.conv_part ? s.conv_part->maxparts : 0;
+    for (int p = 0; p < 3; ++p) f.dnparts[p] = s.conv_part ? s.conv_part->nparts[p] : 0;
     f.part = part; f.A = A; f.coef = coef; f.film = s.film; f.dfilm = s.dfilm; f.film_stride = s.film_stride; f.mr = s.stats.mr;
     for (int p = 0; p < 3; ++p) {
         f.gamma[p] = s.gamma[p]; f.beta[p] = s.beta[p]; f.dgamma[p] = s.dgamma[p]; f.dbeta[p] = s.dbeta[p];
@@ -1221,8 +1234,14 @@ __device__ __forceinline__ void bl_src(int o, int in, float scale, int& i0, int&
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
     l1 = f - float(i0); l0 = 1.f - l1;
 }
-__global__ void k_bilinear_bwd(const float* __restrict__ dout, float* __restrict__ din, int B, int cq, int hi, int wi,
-                               int ho, int wo, int out_cq, int out_q0) {
+// (blockIdx.y = plane: the three planes of a triplane in ONE launch — they were three dependent 16-us launches on the backward
+// pass's main chain)
+struct BlBwdArgs { const float* dout[3]; float* din[3]; int hi[3], wi[3], ho[3], wo[3]; int B, cq, out_cq, out_q0; };
+__global__ void k_bilinear_bwd(BlBwdArgs a) {
+    const int pl = blockIdx.y;
+    const float* __restrict__ dout = a.dout[pl];
+    float* __restrict__ din = a.din[pl];
+    const int B = a.B, cq = a.cq, hi = a.hi[pl], wi = a.wi[pl], ho = a.ho[pl], wo = a.wo[pl], out_cq = a.out_cq, out_q0 = a.out_q0;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long n = (long long)B * hi * wi * cq;
     if (i >= n) return;
@@ -1261,8 +1280,24 @@ int launch_bilinear_bwd(const float* dout, int B, int C, int ho, int wo, int out
                         int wi, hipStream_t st) {
     const long long n = (long long)B * hi * wi * (C / 4);
     if (!n) return 0;
-    hipLaunchKernelGGL(k_bilinear_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, din, B, C / 4, hi, wi, ho, wo,
-                       out_cstride / 4, out_coff / 4);
+    BlBwdArgs a{};
+    a.dout[0] = dout; a.din[0] = din; a.hi[0] = hi; a.wi[0] = wi; a.ho[0] = ho; a.wo[0] = wo;
+    a.B = B; a.cq = C / 4; a.out_cq = out_cstride / 4; a.out_q0 = out_coff / 4;
+    hipLaunchKernelGGL(k_bilinear_bwd, dim3((unsigned)((n + 255) / 256), 1), dim3(256), 0, st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+int launch_bilinear_bwd3(const float* const dout[3], int B, int C, const int ho[3], const int wo[3], int out_cstride, int out_coff,
+                         float* const din[3], const int hi[3], const int wi[3], hipStream_t st) {
+    BlBwdArgs a{};
+    long long nmax = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.dout[p] = dout[p]; a.din[p] = din[p]; a.hi[p] = hi[p]; a.wi[p] = wi[p]; a.ho[p] = ho[p]; a.wo[p] = wo[p];
+        nmax = std::max(nmax, (long long)B * hi[p] * wi[p] * (C / 4));
+    }
+    if (!nmax) return 0;
+    a.B = B; a.cq = C / 4; a.out_cq = out_cstride / 4; a.out_q0 = out_coff / 4;
+    hipLaunchKernelGGL(k_bilinear_bwd, dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }

@@ -90,7 +90,7 @@ int upload(DevBuf& dst, const void* host, size_t bytes);
 // S3D_<NAME> (read once, at the first query of that option); before that the default (kOptUnset for the choices the library
 // makes by launch size).  Queries are a table read: cheap enough for every launch.
 enum Opt { OPT_WINO = 0, OPT_WINO24W, OPT_VCAT, OPT_WGRAD_WINO, OPT_RANK1_SLICES, OPT_RANK1_BATCH, OPT_CONV_IMPL, OPT_CONV1X1_T,
-           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_COUNT };
+           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_GNB_FUSED, OPT_COUNT };
 constexpr int kOptUnset = -1;
 int opt(Opt o);                       // kOptUnset when neither set nor in the environment
 inline bool opt_on(Opt o) { return opt(o) != 0; }      // switches that default to on: anything but an explicit 0
@@ -144,6 +144,17 @@ struct ConvJob {
     int block_begin;                          // first block id of this job
 };
 constexpr int kMaxConvJobs = 8;
+// Training: what the input-gradient convolution in front of a GroupNorm(+FiLM)+SiLU backward needs to form that backward's two
+// per-channel sums (sum dz, sum dz * xh) in its epilogue (k_conv_wino24s_gnb).  Index = plane = job of the launch.
+struct GnbArgs {
+    const float* x[3];                       // the norm's input [B][h][w][C]
+    const float* rowadd[3]; const float* coladd[3];   // broadcast gradients of the rollout means, [B][h][C] / [B][w][C], or null
+    float rowscale[3], colscale[3];
+    const float* gamma[3]; const float* beta[3];
+    const float* mr;                         // {mean, rstd} [B][3][groups]
+    const float* film; int film_stride;      // FiLM row(s): scale at [0, C), shift at [C, 2C); or null
+    int groups;
+};
 struct ConvArgs {
     ConvJob job[kMaxConvJobs];
     int njobs;
@@ -155,6 +166,7 @@ struct ConvArgs {
     // 128-channel chunks and writes slice s at out + s * B * L * 4 * cout.  k_conv_wino24s: rrow / rcol are read as the sum of the
     // two tables (slice stride B * h * 4 * cout / B * w * 4 * cout floats)
     int r1_slices;
+    const GnbArgs* gnb;                       // HOST pointer, 3x3 mixed-Winograd launches only: see GnbArgs (null: plain convolution)
 };
 // CONV_1x3_ROLL: the forward rollout tables — args.cout = the convolution's cout, out [B][pos][4 variants][cout] (k_rank1<true>)
 enum ConvKind { CONV_3x3 = 0, CONV_1x1 = 1, CONV_1x3_VEC = 2, CONV_5x5 = 3, CONV_1x3_ROLL = 4 };

@@ -62,29 +62,57 @@ struct Bwd {
     //  d_a      (optional) dense input gradient of the own channels (+ res), via the forward conv kernels
     //  rowadd / coladd (rollout) the gradients of the six mean vectors, routed to the plane they were taken from
     //           and divided by the averaged length: to be broadcast-added to that plane's d_a by the caller
+    // gnf (optional): the GroupNorm(+FiLM)+SiLU whose backward follows this convolution's: when the dgrad launch is the mixed
+    // Winograd kernel its epilogue leaves that backward's two per-channel sums in *gnf_part (k_conv_wino24s_gnb; option GNB_FUSED) —
+    // the mean-vector gradients are then built BEFORE the dgrad launch (its epilogue adds their broadcast to dy, as gn_bwd does)
+    struct GnFuse { const Tri* x; const GnStats* stats; const NormW* nw; const float* film; };
     int conv_bwd(const ConvW& cw, const ConvWT& wt, const std::string& prefix, const Tri& dy, const Tri& a, const NormTape* nt,
-                 Tri* d_a, const Tri* res, float* rowadd[3], float* coladd[3], float* per_sample_bias) {
+                 Tri* d_a, const Tri* res, float* rowadd[3], float* coladd[3], float* per_sample_bias,
+                 const GnFuse* gnf = nullptr, GnPartials* gnf_part = nullptr) {
         const Geo& g = dy.g;
         const int cin = cw.cin, cout = cw.cout, taps = cw.k * cw.k;
         const bool roll = cw.rollout && nt && nt->roll;
-        // (1) dgrad of the own channels
-        if (d_a) {
+        if (gnf_part) gnf_part->p = nullptr;
+        const bool fuse = gnf && gnf_part && d_a && cw.k == 3 && wt.has_wino24s_T && conv_use_wino24() && !conv_use_naive() &&
+                          cin % 32 == 0 && opt_on(OPT_GNB_FUSED) && gnf->x->C == cin;
+        // (1) dgrad of the own channels — enqueued after (2) when its epilogue needs the mean-vector gradients
+        auto dgrad = [&]() -> int {
+            if (!d_a) return 0;
             *d_a = alloc_tri(cin, g);
             S3D_CHECK(!(wt.only24_current && (!conv_use_wino24() || conv_use_naive())), S3D_ERR_INVALID,
                       "backward of conv %d->%d: the kernel form selected now reads a transposed weight image the repack plan does not "
                       "keep current (options changed after s3d_unet_train_attach): attach again", cin, cout);
-            if (!meas()) {
-                ConvArgs ca; memset(&ca, 0, sizeof ca);
-                ca.B = B; ca.cin = cout; ca.cout = cin; ca.njobs = 3;
-                for (int p = 0; p < 3; ++p) {
-                    ConvJob& J = ca.job[p];
-                    J.in = dy.p[p]; J.wgt = m->tdev(wt.dense_T[p]); J.wgt_wino = cw.k == 3 && wt.has_wino_T ? m->tdev(wt.wino_T[p]) : nullptr;
-                    J.wgt_wino24s = cw.k == 3 && wt.has_wino24s_T ? m->tdev(wt.wino24s_T[p]) : nullptr;
-                    J.res = res ? res->p[p] : nullptr; J.out = d_a->p[p]; J.h = g.h[p]; J.w = g.w[p];
-                }
-                S3D_TRY(m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st));      // (events only inside a profiled step)
+            GnPartials part{nullptr, 0, {0, 0, 0}, 0};
+            if (fuse) {
+                conv_gn_parts(CONV_3x3, g, part.nparts, true);
+                part.maxparts = std::max(part.nparts[0], std::max(part.nparts[1], part.nparts[2]));
+                part.nsub = cin;                                   // one record per channel and tile
+                part.p = ar().alloc<double>(size_t(B) * 3 * part.maxparts * part.nsub * 2);
+                *gnf_part = part;
             }
-        }
+            if (meas()) return 0;
+            ConvArgs ca; memset(&ca, 0, sizeof ca);
+            ca.B = B; ca.cin = cout; ca.cout = cin; ca.njobs = 3;
+            GnbArgs gb; memset(&gb, 0, sizeof gb);
+            if (fuse) {
+                ca.gn_sg = 1; ca.gn_nsub = part.nsub; ca.gn_maxparts = part.maxparts; ca.gnb = &gb;
+                gb.mr = gnf->stats->mr; gb.film = gnf->film; gb.film_stride = m->film_total; gb.groups = 32;
+            }
+            for (int p = 0; p < 3; ++p) {
+                ConvJob& J = ca.job[p];
+                J.in = dy.p[p]; J.wgt = m->tdev(wt.dense_T[p]); J.wgt_wino = cw.k == 3 && wt.has_wino_T ? m->tdev(wt.wino_T[p]) : nullptr;
+                J.wgt_wino24s = cw.k == 3 && wt.has_wino24s_T ? m->tdev(wt.wino24s_T[p]) : nullptr;
+                J.res = res ? res->p[p] : nullptr; J.out = d_a->p[p]; J.h = g.h[p]; J.w = g.w[p];
+                if (fuse) {
+                    J.gn_part = part.p + size_t(p) * part.maxparts * part.nsub * 2;
+                    gb.x[p] = gnf->x->p[p]; gb.gamma[p] = m->dev(gnf->nw->gamma[p]); gb.beta[p] = m->dev(gnf->nw->beta[p]);
+                    gb.rowadd[p] = rowadd ? rowadd[p] : nullptr; gb.coladd[p] = coladd ? coladd[p] : nullptr;
+                    gb.rowscale[p] = 1.0f / float(g.w[p]); gb.colscale[p] = 1.0f / float(g.h[p]);      // (as launch_gn_act_bwd)
+                }
+            }
+            return m->timed_conv(cw.k == 3 ? 0 : 1, cw.k == 3 ? CONV_3x3 : CONV_1x1, ca, st);      // (events only inside a profiled step)
+        };
+        if (!fuse) S3D_TRY(dgrad());
         // (2) row / column sums of dy -> bias gradient, mean-slot gradients
         float* R[3]; float* Cs[3];
         for (int p = 0; p < 3; ++p) {
@@ -136,6 +164,7 @@ struct Bwd {
         } else if (rowadd) {
             for (int p = 0; p < 3; ++p) rowadd[p] = coladd[p] = nullptr;
         }
+        if (fuse) S3D_TRY(dgrad());
         // (3) dense weight gradient of the own channels
         WgradArgs w;
         w.dy = dy; w.a = a; w.B = B; w.cin = cin; w.cout = cout; w.ctot = cw.rollout ? 3 * cin : cin; w.taps = taps;
@@ -163,9 +192,11 @@ struct Bwd {
     }
 
     int gn_bwd(const Tri& x, const GnStats& stats, const NormW& nw, const std::string& prefix, const float* film_ptr,
-               float* dfilm_ptr, const Tri& dy, float* const rowadd[3], float* const coladd[3], const Tri* add, Tri& dx) {
+               float* dfilm_ptr, const Tri& dy, float* const rowadd[3], float* const coladd[3], const Tri* add, Tri& dx,
+               const GnPartials* conv_part = nullptr) {
         dx = alloc_tri(x.C, x.g);
         GnActBwd s;
+        s.conv_part = conv_part && conv_part->p ? conv_part : nullptr;
         s.x = x; s.dy = dy; s.dx = dx; s.add = add; s.stats = stats; s.B = B;
         const float* ra[3]; const float* ca[3];
         for (int p = 0; p < 3; ++p) { ra[p] = rowadd ? rowadd[p] : nullptr; ca[p] = coladd ? coladd[p] : nullptr; }
@@ -194,11 +225,13 @@ struct Bwd {
         }
         float *ra[3], *ca[3];
         Tri d_y2, d_h1, d_y1;
-        S3D_TRY(conv_bwd(rb.c2, wt.c2, rb.prefix + ".out_layers.2", d_out, T.y2, &T.n2, &d_y2, nullptr, ra, ca, nullptr));
+        GnPartials gp2, gp1;
+        const GnFuse f2{&T.h1, &T.n2.stats, &rb.n2, ssn ? film_ptr : nullptr}, f1{&T.x, &T.n1.stats, &rb.n1, nullptr};
+        S3D_TRY(conv_bwd(rb.c2, wt.c2, rb.prefix + ".out_layers.2", d_out, T.y2, &T.n2, &d_y2, nullptr, ra, ca, nullptr, &f2, &gp2));
         S3D_TRY(gn_bwd(T.h1, T.n2.stats, rb.n2, rb.prefix + ".out_layers.0", ssn ? film_ptr : nullptr, ssn ? dfilm_ptr : nullptr,
-                       d_y2, ra, ca, nullptr, d_h1));
-        S3D_TRY(conv_bwd(rb.c1, wt.c1, rb.prefix + ".in_layers.2", d_h1, T.y1, &T.n1, &d_y1, nullptr, ra, ca, ssn ? nullptr : dfilm_ptr));
-        S3D_TRY(gn_bwd(T.x, T.n1.stats, rb.n1, rb.prefix + ".in_layers.0", nullptr, nullptr, d_y1, ra, ca, add, d_x));
+                       d_y2, ra, ca, nullptr, d_h1, &gp2));
+        S3D_TRY(conv_bwd(rb.c1, wt.c1, rb.prefix + ".in_layers.2", d_h1, T.y1, &T.n1, &d_y1, nullptr, ra, ca, ssn ? nullptr : dfilm_ptr, &f1, &gp1));
+        S3D_TRY(gn_bwd(T.x, T.n1.stats, rb.n1, rb.prefix + ".in_layers.0", nullptr, nullptr, d_y1, ra, ca, add, d_x, &gp1));
         return 0;
     }
 };
@@ -260,6 +293,12 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
         const Tri& u = T.up_src[oi];
         const Geo up = u.g.twice();
         Tri d_prev = b.alloc_tri(u.C, u.g);
+        if (up == d_in.g) {                                  // the common case: one launch for the three planes
+            if (!meas) {
+                const float* dsrc[3] = {d_in.p[0], d_in.p[1], d_in.p[2]};
+                S3D_TRY(launch_bilinear_bwd3(dsrc, B, u.C, up.h, up.w, d_in.C, 0, d_prev.p, u.g.h, u.g.w, st));
+            }
+        } else
         for (int p = 0; p < 3; ++p) {
             const bool same = up.h[p] == d_in.g.h[p] && up.w[p] == d_in.g.w[p];
             if (same) {

@@ -497,3 +497,44 @@ def test_a_form_change_after_attach_fails_instead_of_using_stale_weights():
         _lib.set_option("WINO", None)
     _, g1 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
     assert torch.equal(g0, g1)
+
+
+def test_groupnorm_backward_sums_from_the_dgrad_epilogue_agree_with_the_read_pass():
+    """GroupNorm(+FiLM)+SiLU backward (forward: src/diffusion/unet_triplane.py:63-95, 269-311) needs sum(dz) and sum(dz * xh) per
+    channel before it can form dx.  By default the input-gradient convolution in front of it (k_conv_wino24s_gnb) leaves them as
+    per-tile records from its epilogue, where dy already sits in registers; GNB_FUSED = 0 takes them from the read pass over (x, dy)
+    (k_gn_bwd_partials).  Same mathematics, another summation order: every parameter gradient agrees to round-off, both forms are
+    repeatable, the fused form is what the default step runs (the library names the kernel), and the losses are the same bits
+    (the forward is untouched)."""
+    import torch
+    from sin3dm_amd import _lib
+    diffusion = _diffusion()
+    dev = torch.device("cuda:0")
+    for mc, (H, W, D), B, ssn in ((64, (48, 64, 40), 3, True), (32, (9, 13, 7), 2, True), (32, (12, 16, 10), 2, False)):
+        x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 420)).clamp(-1, 1).to(dev)
+        noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 421)).to(dev)
+        t = torch.tensor([700, 3, 250][:B], device=dev)
+        w = torch.tensor([1.0, 0.5, 2.0][:B], device=dev)
+        kw = dict(H=H, W=W, D=D)
+        out = {}
+        try:
+            for mode in (None, 0):
+                _lib.set_option("GNB_FUSED", mode)
+                m = _model(mc, ssn=ssn)
+                m.profile(1, classes=1)
+                terms, g = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                g = g.clone()
+                _, g2 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                assert torch.equal(g, g2), mode
+                m.profile_read()
+                out[mode] = (terms["loss"].clone(), g, m.profile_kernel(0), m.split_flat(g))
+        finally:
+            _lib.set_option("GNB_FUSED", None)
+        assert "k_conv_wino24s_gnb" in out[None][2] and "gnb" not in out[0][2], (out[None][2], out[0][2])
+        assert torch.equal(out[None][0], out[0][0])
+        for name, a in out[None][3].items():
+            b = out[0][3][name]
+            scale = max(float(b.norm()), 1e-3 * float(out[0][1].norm()))      # (floor: a conv bias in front of a GroupNorm has a zero gradient, round-off noise in both forms)
+            # (the gate of the golden-gradient tests; the FiLM / affine gradients ARE these sums, each a cancelling sum of thousands of terms)
+            assert float((a - b).norm()) <= 2e-4 * scale, (mc, name, float((a - b).norm()), scale)
+        assert not torch.equal(out[None][1], out[0][1]) or mc == 0          # (another summation order: not the same bits)
