@@ -852,14 +852,28 @@ __global__ __launch_bounds__(256) void k_gn_bwd_fin(GnBwdFinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sA[];          // [C][2]
     const int C = a.C, G = a.ngroups, cg = C / G;
     const int bp = blockIdx.x, b = bp / 3, p = bp % 3;
+    if (a.dpart) {
+        // tile records of k_conv_wino24s_gnb: [channel][tile][2] doubles, a channel's records contiguous.  Eight lanes per channel —
+        // lane l adds tiles l, l + 8, ... (its 16-byte records and its neighbours' form 128-byte runs), the eight sums meet in a fixed
+        // xor tree: a wave reads whole lines instead of 64 scattered ones, and the order never depends on anything but the tile count
+        const int l = threadIdx.x & 7, n = a.dnparts[p];
+        for (int ch = threadIdx.x >> 3; ch < C; ch += blockDim.x >> 3) {
+            const double2* q = reinterpret_cast<const double2*>(a.dpart + (size_t(bp) * C + ch) * a.dmaxparts * 2);
+            double s1 = 0, s2 = 0;
+#pragma unroll 4
+            for (int k = l; k < n; k += 8) { const double2 v = q[k]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 8); s2 += __shfl_xor(s2, o, 8); }
+            if (l == 0) {
+                const float f1 = float(s1), f2 = float(s2);
+                a.A[(size_t(bp) * C + ch) * 2] = f1; a.A[(size_t(bp) * C + ch) * 2 + 1] = f2;
+                sA[2 * ch] = f1; sA[2 * ch + 1] = f2;
+            }
+        }
+    } else
     for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
         double s1 = 0, s2 = 0;
-        if (a.dpart) {                                    // tile records of k_conv_wino24s_gnb, added in tile order
-            const double* q = a.dpart + (size_t(bp) * C + ch) * a.dmaxparts * 2;
-            const int n = a.dnparts[p];
-#pragma unroll 4
-            for (int k = 0; k < n; ++k) { s1 += q[2 * k]; s2 += q[2 * k + 1]; }
-        } else {
+        {
 #pragma unroll 8
             for (int k = 0; k < a.nchunk; ++k) {
                 const float2 q = *reinterpret_cast<const float2*>(a.part + ((size_t(bp) * a.nchunk + k) * C + ch) * 2);
