@@ -153,3 +153,22 @@ def test_sample_cli_chains_write_the_same_files(tmp_path):
             assert sorted(a) == sorted(b)
             for k in a:
                 assert np.array_equal(a[k], b[k]), (name, k)
+
+
+def test_chains_at_the_scored_size_are_bit_identical():
+    """BASELINE configs[1]'s model and planes (128-ch, 128^3; respaced to 100 ancestral steps to keep the test short): three samples
+    as three chains, as two chains and alone — the same bits; and the whole run's state stays finite with an exactly zero corner."""
+    H = W = D = 128
+    kw = dict(H=H, W=W, D=D)
+    model = make_model(128)
+    diff = make_diffusion("100")
+    shape = (1, 12, H + D, W + D)
+    seeds = [[1000], [1001], [1002]]
+    alone = [diff.p_sample_loop(model, shape, model_kwargs=kw, generator=gens(s)) for s in seeds]
+    for chains in (3, 2):
+        got = diff.sample_loop_chains(model, shape, 3, chains=chains, generators=[gens(s) for s in seeds], model_kwargs=kw)
+        torch.cuda.synchronize()
+        for r in range(3):
+            assert torch.equal(got[r], alone[r]), (chains, r)
+    assert all(torch.isfinite(a).all() and float(a[..., H:, W:].abs().max()) == 0.0 for a in alone)
+    assert not torch.equal(alone[0], alone[1])
