@@ -31,10 +31,27 @@ int launch_inorm_silu(const float* x, double* part, const float* gamma, const fl
 struct PointSet { const float* pts; long long N, Np; float aabb[6]; };   // Np = N rounded up to the GEMM row tile
 int launch_gather(const PointSet& ps, const float* const feat[2][3], const int ph[3], const int pw[3], int C, int nnets,
                   float* const X[2], hipStream_t st);
+struct GatherArgs {
+    const float* pts; long long N, Np;
+    float amin[3], ainv[3];                     // x_n = 2 (x - amin) * ainv - 1
+    const float* feat[2][3]; float* dfeat[2][3];
+    int ph[3], pw[3];
+    float* X[2]; const float* dX[2];            // [Np][C]
+    int C, nnets;
+};
+struct ScatterSortedArgs {
+    GatherArgs g;
+    const unsigned* order[3]; const unsigned* start[3];            // sorted point ids / first position of every cell
+    long long begin[4];
+};
+struct ScatterPlan { ScatterSortedArgs args; bool ready = false; };     // the point order of one batch (launch_scatter_prepare)
 // backward of launch_gather: dfeat (every element written) from dX; ws: scatter_ws_bytes(...) bytes.  No float atomics.
 size_t scatter_ws_bytes(long long Np, const int ph[3], const int pw[3]);
 int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
                    const float* const dX[2], void* ws, hipStream_t st);
+// the same in two halves: the point order depends on the points alone (21 small dependent launches) and may be enqueued early
+int launch_scatter_prepare(const PointSet& ps, const int ph[3], const int pw[3], int C, int nnets, void* ws, ScatterPlan& plan, hipStream_t st);
+int launch_scatter_apply(ScatterPlan& plan, float* const dfeat[2][3], const float* const dX[2], hipStream_t st);
 
 // dpre = dact[:, coff:coff+C] * (act > 0) and colsum[C] = its column sums (ws: colsum_ws_floats(C))
 int launch_relu_bwd(const float* dact, int dstride, int coff, const float* act, float* dpre, long long rows, int C, float* ws,

@@ -274,10 +274,13 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         S3D_TRY(R.conv(CONV_5x5, up, up, g, T.y, w_out, b_out, T.s, T.f, 3, false, cs, true));
     }
     if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the gather reads both nets' planes
-
-    // ---- points: gather, MLPs
+    // (measured and not kept: the backward scatter's point sort — 21 small dependent launches that depend on the points alone —
+    // enqueued here on the second chain's stream, beside the MLPs' forward pass: every one of them waits for a slot behind the
+    // 8192-block launches of that pass, the chain arrives late at its backward half, 5.00 -> 5.30 ms/iteration)
     PointSet ps; ps.pts = pts; ps.N = N; ps.Np = Np;
     for (int k = 0; k < 6; ++k) ps.aabb[k] = aabb[k];
+
+    // ---- points: gather, MLPs
     float *X0[2], *H[2][5], *CAT[2];
     for (int n = 0; n < 2; ++n) {
         X0[n] = ar.alloc<float>(size_t(Np) * up);
@@ -335,30 +338,39 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // the two chains want different things at most times.  Same kernels on the same operands: same bits.
     float* cws_n[2] = {cws, ar.alloc<float>(colsum_ws_floats(std::max(hid, up)))};
     if (!meas && R.side) S3D_TRY(R.edge(st, a->chain2));
+    // (issued layer by layer for BOTH nets, not net after net: the two chains then advance together however far the host is ahead)
+    struct Step { int l; float* act; float* in; int in_stride; float* din; const float* dact; int dstride, coff; };
+    Step steps[2][5];
+    float *dXa_n[2], *dCAT_n[2];
+    hipStream_t cs_n[2];
     for (int n = 0; n < 2; ++n) {
         const AeNet& N_ = a->net[n];
-        const bool second = n == 1 && R.side && !meas;
-        hipStream_t cs = second ? a->chain2 : st;                  // this net's chain
-        float* cws = cws_n[n];
+        cs_n[n] = n == 1 && R.side && !meas ? a->chain2 : st;      // this net's chain
         float* dH = ar.alloc<float>(size_t(Np) * hid);            // gradient of a hidden activation (reused)
         float* dCAT = ar.alloc<float>(size_t(Np) * (up + hid));
         float* dXa = ar.alloc<float>(size_t(Np) * up);
         dX0[n] = ar.alloc<float>(size_t(Np) * up);
+        dXa_n[n] = dXa; dCAT_n[n] = dCAT;
         float* lws = ar.alloc<float>(last_bwd_ws_floats(hid, N_.nout));
-        if (!meas) S3D_TRY(launch_last_bwd(dout, S, n == 0 ? 0 : 1, R.F(N_.f_mw[5]), H[n][4], hid, N_.nout, Np, dH, lws, R.G(N_.f_mw[5]), R.G(N_.f_mb[5]), cs));
+        if (!meas) S3D_TRY(launch_last_bwd(dout, S, n == 0 ? 0 : 1, R.F(N_.f_mw[5]), H[n][4], hid, N_.nout, Np, dH, lws, R.G(N_.f_mw[5]), R.G(N_.f_mb[5]), cs_n[n]));
         // hidden layers 4..0: dP = dH * relu'(H_l) ; db_l = colsum(dP) ; dW_l = dP^T in_l ; d in_l = dP W_l
-        struct Step { int l; float* act; float* in; int in_stride; float* din; const float* dact; int dstride, coff; };
-        const Step steps[5] = {{4, H[n][4], H[n][3], hid, dH, dH, hid, 0},
-                               {3, H[n][3], CAT[n], up + hid, dCAT, dH, hid, 0},
-                               {2, H[n][2], H[n][1], hid, dH, dCAT, up + hid, up},
-                               {1, H[n][1], H[n][0], hid, dH, dH, hid, 0},
-                               {0, H[n][0], X0[n], up, dXa, dH, hid, 0}};
-        for (const Step& s : steps) {
+        const Step st5[5] = {{4, H[n][4], H[n][3], hid, dH, dH, hid, 0},
+                             {3, H[n][3], CAT[n], up + hid, dCAT, dH, hid, 0},
+                             {2, H[n][2], H[n][1], hid, dH, dCAT, up + hid, up},
+                             {1, H[n][1], H[n][0], hid, dH, dH, hid, 0},
+                             {0, H[n][0], X0[n], up, dXa, dH, hid, 0}};
+        for (int k = 0; k < 5; ++k) steps[n][k] = st5[k];
+    }
+    for (int kk = 0; kk < 10; ++kk) {
+            const int k = kk / 2, n = kk % 2;
+            const AeNet& N_ = a->net[n];
+            const Step& s = steps[n][k];
+            hipStream_t cs = cs_n[n];
             const int I = N_.I[s.l], O = N_.O[s.l];
             // gradient of the layer's pre-activation: one buffer per layer — the weight gradient that reads it runs on the side
             // stream while this chain has moved on
             float* dP = ar.alloc<float>(size_t(Np) * hid);
-            if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws, R.G(N_.f_mb[s.l]), cs));
+            if (!meas) S3D_TRY(launch_relu_bwd(s.dact, s.dstride, s.coff, s.act, dP, Np, O, cws_n[n], R.G(N_.f_mb[s.l]), cs));
             Geo g1; for (int p = 0; p < 3; ++p) { g1.h[p] = p == 0 ? int(Np / 64) : 0; g1.w[p] = p == 0 ? 64 : 0; }
             float* dy3[3] = {dP, nullptr, nullptr}; float* a3[3] = {s.in, nullptr, nullptr}; float* dw3[3] = {R.G(N_.f_mw[s.l]), nullptr, nullptr};
             S3D_TRY(R.wgrad(1, I, I, O, g1, dy3, s.in_stride, a3, dw3, 1, cs, true));
@@ -366,8 +378,8 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             float* o3[3] = {s.din, nullptr, nullptr};
             S3D_TRY(R.conv(CONV_1x1, O, I, g1, dy3, wT, nullptr, nullptr, o3, 1, false, cs, true));
         }
-        if (!meas) S3D_TRY(launch_add_slice(dXa, dCAT, up + hid, 0, dX0[n], Np, up, cs));
-    }
+    for (int n = 0; n < 2; ++n)
+        if (!meas) S3D_TRY(launch_add_slice(dXa_n[n], dCAT_n[n], up + hid, 0, dX0[n], Np, up, cs_n[n]));
     if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the scatter reads both nets' point gradients
     // ---- scatter the point gradients onto the planes
     float* dF[2][3];

@@ -297,14 +297,6 @@ int launch_mr_from_partials(const double* part, int nchunks, int C, double count
 // ------------------------------------------------------------------ point gather and its backward (F.grid_sample, bilinear, border, align_corners=False)
 // sample_feature_plane2D (networks.py:182-190): plane [h][w][C] indexed by (u -> rows, v -> columns) of the
 // aabb-normalised point; h_net = sum over the three planes.
-struct GatherArgs {
-    const float* pts; long long N, Np;
-    float amin[3], ainv[3];                     // x_n = 2 (x - amin) * ainv - 1
-    const float* feat[2][3]; float* dfeat[2][3];
-    int ph[3], pw[3];
-    float* X[2]; const float* dX[2];            // [Np][C]
-    int C, nnets;
-};
 __device__ __forceinline__ void gs_coord(float xn, int size, int& i0, int& i1, float& w0, float& w1) {
     float f = ((xn + 1.f) * float(size) - 1.f) * 0.5f;         // unnormalize, align_corners=False
     f = fminf(fmaxf(f, 0.f), float(size - 1));                 // border padding: clip the coordinate
@@ -383,11 +375,6 @@ __global__ void k_bin_starts(const unsigned* __restrict__ keys_sorted, long long
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys_sorted[mid] < unsigned(cell)) lo = mid + 1; else hi = mid; }
     start[cell] = unsigned(lo);
 }
-struct ScatterSortedArgs {
-    GatherArgs g;
-    const unsigned* order[3]; const unsigned* start[3];            // sorted point ids / first position of every cell
-    long long begin[4];
-};
 __global__ void k_scatter_sorted(ScatterSortedArgs s) {
     const GatherArgs& a = s.g;
     const int cq = a.C / 4;
@@ -437,14 +424,16 @@ size_t scatter_ws_bytes(long long Np, const int ph[3], const int pw[3]) {
     for (int p = 0; p < 3; ++p) cells += size_t(ph[p]) * pw[p] + 2;
     return ((cub + 255) & ~size_t(255)) + (size_t(12) * Np + cells) * sizeof(unsigned) + 1024;
 }
-int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
-                   const float* const dX[2], void* ws, hipStream_t st) {
-    ScatterSortedArgs s; memset(&s, 0, sizeof s);
+// Two halves: the point ORDER (cell keys, three radix sorts, bin starts — 21 small dependent launches) depends on the points
+// alone, so a trainer can enqueue it long before the gradients exist (s3d_ae.hip does, on the second chain's stream beside the
+// forward pass); the scatter proper follows when dX is final.
+int launch_scatter_prepare(const PointSet& ps, const int ph[3], const int pw[3], int C, int nnets, void* ws, ScatterPlan& plan, hipStream_t st) {
+    ScatterSortedArgs& s = plan.args; memset(&s, 0, sizeof s);
     GatherArgs& a = s.g;
     a.pts = ps.pts; a.N = ps.N; a.Np = ps.Np; a.C = C; a.nnets = nnets;
     for (int k = 0; k < 3; ++k) { a.amin[k] = ps.aabb[k]; a.ainv[k] = 1.f / (ps.aabb[3 + k] - ps.aabb[k]); a.ph[k] = ph[k]; a.pw[k] = pw[k]; }
-    for (int n = 0; n < nnets; ++n) { a.dX[n] = dX[n]; for (int p = 0; p < 3; ++p) a.dfeat[n][p] = dfeat[n][p]; }
     const long long Np = ps.Np;
+    plan.ready = false;
     if (!Np) return 0;
     size_t cub = 0;
     unsigned* d0 = nullptr;
@@ -468,9 +457,22 @@ int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3]
         start += ncell + 2;
         s.begin[p + 1] = s.begin[p] + (long long)ncell * (C / 4);
     }
-    hipLaunchKernelGGL(k_scatter_sorted, dim3(cdivll(s.begin[3] * nnets, 256)), dim3(256), 0, st, s);
+    plan.ready = true;
+    return 0;
+}
+int launch_scatter_apply(ScatterPlan& plan, float* const dfeat[2][3], const float* const dX[2], hipStream_t st) {
+    if (!plan.ready) return 0;
+    ScatterSortedArgs& s = plan.args;
+    for (int n = 0; n < s.g.nnets; ++n) { s.g.dX[n] = dX[n]; for (int p = 0; p < 3; ++p) s.g.dfeat[n][p] = dfeat[n][p]; }
+    hipLaunchKernelGGL(k_scatter_sorted, dim3(cdivll(s.begin[3] * s.g.nnets, 256)), dim3(256), 0, st, s);
     S3D_HIP(hipGetLastError());
     return 0;
+}
+int launch_scatter(const PointSet& ps, float* const dfeat[2][3], const int ph[3], const int pw[3], int C, int nnets,
+                   const float* const dX[2], void* ws, hipStream_t st) {
+    ScatterPlan plan;
+    S3D_TRY(launch_scatter_prepare(ps, ph, pw, C, nnets, ws, plan, st));
+    return launch_scatter_apply(plan, dfeat, dX, st);
 }
 
 // ------------------------------------------------------------------ small element-wise pieces of the MLP
@@ -595,7 +597,8 @@ __global__ __launch_bounds__(256) void k_last_bwd(const float* __restrict__ dout
     for (int i = threadIdx.x; i < I; i += 256) {
         float w[3] = {0, 0, 0}, acc[3] = {0, 0, 0};
         for (int o = 0; o < O; ++o) w[o] = W[size_t(o) * I + i];
-        for (long long n = r0; n < r1; ++n) {
+#pragma unroll 8
+        for (long long n = r0; n < r1; ++n) {                // (unrolled: eight rows of loads in flight per thread)
             const float hv = h[n * I + i];
             float d = 0.f;
             for (int o = 0; o < O; ++o) { const float g = dout[n * dstride + ooff + o]; d = fmaf(g, w[o], d); acc[o] = fmaf(g, hv, acc[o]); }
@@ -609,13 +612,20 @@ __global__ __launch_bounds__(256) void k_last_bwd(const float* __restrict__ dout
         part[(size_t(blockIdx.x) * O + threadIdx.x) * (I + 1) + I] = s;
     }
 }
-__global__ void k_last_bwd_fin(const float* __restrict__ part, int I, int O, float* __restrict__ dW, float* __restrict__ db) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= O * (I + 1)) return;
-    const int i = idx % (I + 1), o = idx / (I + 1);
+// 32 lanes per output: lane l adds chunks l, l + 32, ... (double), the 32 sums meet in a fixed xor tree.  (One thread per output
+// walked 512 dependent loads: 38 us for the geometry net's 257 outputs — one block and one wave of it — at the head of each net's
+// backward chain.)
+__global__ __launch_bounds__(256) void k_last_bwd_fin(const float* __restrict__ part, int I, int O, float* __restrict__ dW, float* __restrict__ db) {
+    const int idx = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    const bool ok = idx < O * (I + 1);
+    const int i = ok ? idx % (I + 1) : 0, o = ok ? idx / (I + 1) : 0;
     double s = 0;
-    for (int k = 0; k < kLastChunks; ++k) s += part[(size_t(k) * O + o) * (I + 1) + i];
-    if (i < I) dW[size_t(o) * I + i] = float(s); else db[o] = float(s);
+    if (ok)
+#pragma unroll 4
+        for (int k = l; k < kLastChunks; k += 32) s += part[(size_t(k) * O + o) * (I + 1) + i];
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) s += __shfl_xor(s, d, 32);
+    if (ok && l == 0) { if (i < I) dW[size_t(o) * I + i] = float(s); else db[o] = float(s); }
 }
 size_t last_bwd_ws_floats(int I, int O) { return size_t(kLastChunks) * O * (I + 1); }
 int launch_last_bwd(const float* dout, int dstride, int ooff, const float* W, const float* h, int I, int O, long long Np, float* dh,
@@ -623,7 +633,7 @@ int launch_last_bwd(const float* dout, int dstride, int ooff, const float* W, co
     S3D_CHECK(O >= 1 && O <= 3, S3D_ERR_UNSUPPORTED, "last layer: %d outputs", O);
     hipLaunchKernelGGL(k_last_bwd, dim3(kLastChunks), dim3(256), 0, st, dout, dstride, ooff, W, h, I, O, Np, dh, ws);
     S3D_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_last_bwd_fin, dim3(cdiv(O * (I + 1), 256)), dim3(256), 0, st, ws, I, O, dW, db);
+    hipLaunchKernelGGL(k_last_bwd_fin, dim3(cdiv(O * (I + 1), 8)), dim3(256), 0, st, ws, I, O, dW, db);
     S3D_HIP(hipGetLastError());
     return 0;
 }
