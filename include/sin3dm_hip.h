@@ -278,9 +278,10 @@ S3D_API int s3d_unet_forward_train(s3d_unet* m, const float* x, const float* t, 
 S3D_API int s3d_unet_backward(s3d_unet* m, const float* d_out, float* grads, void* stream);
 /* The same with progress marks for a data-parallel trainer that overlaps the gradient all-reduce with the backward pass
  * (the reference's DDP is commented out, src/diffusion/train_util.py:8-9, 98-99): events[k] (HIP events
- * owned by the caller, n_events <= 2) are recorded on `stream` when a group of gradients is final — [0] out.* and
- * output_blocks.* except their emb_layers, [1] input_blocks.* except their emb_layers and in_conv.*; time_embed.* and all
- * emb_layers.* are final when the call's work is. */
+ * owned by the caller, n_events <= 2) are recorded when a group of gradients is final — [0] out.* and output_blocks.* except
+ * their emb_layers, [1] input_blocks.* except their emb_layers and in_conv.*; time_embed.* and all emb_layers.* are final when
+ * the call's work on `stream` is.  (Recorded on `stream`, or — option BWD_SIDE on, the default — on the handle's side stream, which
+ * finishes a group last and has been ordered behind `stream`'s progress: wait for the EVENT, as a communication stream does.) */
 S3D_API int s3d_unet_backward_marked(s3d_unet* m, const float* d_out, float* grads, void* stream, void** events, int n_events);
 
 /* q_sample (:189-207): x_t = sqrt_ac[t] * x0 + sqrt_1mac[t] * noise; tables fp32 [T] on the device, t int64 [B].

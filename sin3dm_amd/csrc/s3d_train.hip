@@ -315,7 +315,9 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
     }
 
     if (!meas) { S3D_TRY(b.edge(st, b.sw)); S3D_TRY(b.tail.flush(b.sw)); }      // (the output blocks' weight / bias gradients are final at mark 0; the bias sums read the main chain's edge sums)
-    if (!meas && n_marks > 0 && marks[0]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[0], st)); }
+    // (the mark is recorded on the stream that finishes the group LAST — the side stream, which has just been made to wait for the
+    // caller's stream: the caller's chain is not stalled for the side stream's backlog of weight gradients)
+    if (!meas && n_marks > 0 && marks[0]) S3D_HIP(hipEventRecord(marks[0], b.sw));
 
     // ---- input blocks, deepest to first
     Tri d_x;                                        // gradient of the current level's resblock input
@@ -355,7 +357,7 @@ static int run_backward(s3d_unet* m, const float* d_out, float* grads, hipStream
 
     if (!meas) { S3D_TRY(b.edge(st, b.sw)); S3D_TRY(b.tail.flush(b.sw)); }      // (... the input blocks' at mark 1)
     if (!meas && c.use_scale_shift_norm == 0) S3D_TRY(b.join());      // h + emb_out: the per-sample bias sums (side stream) are the FiLM gradient the timestep MLP below reads
-    if (!meas && n_marks > 1 && marks[1]) { S3D_TRY(b.join()); S3D_HIP(hipEventRecord(marks[1], st)); }
+    if (!meas && n_marks > 1 && marks[1]) S3D_HIP(hipEventRecord(marks[1], b.sw));
 
     // ---- timestep MLP: film = Lf(silu(emb)), emb = L2(silu(pre1)), pre1 = L0(temb(t))
     {

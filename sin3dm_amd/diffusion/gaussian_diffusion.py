@@ -398,7 +398,7 @@ class GaussianDiffusion:
                 if prep is not None:
                     prep(model, shape[0], device)             # host-side schedule caches are built once, ahead of every chain
                 main = th.cuda.current_stream(device)
-                own = [th.cuda.Stream(device=device) for _ in range(nch)]
+                own = chain_streams(device, nch)
                 for s in own:
                     s.wait_stream(main)                       # whatever produced the inputs (noises, weights) comes first
                 streams = [th.cuda.stream(s) for s in own]
@@ -515,6 +515,53 @@ class GaussianDiffusion:
         g = model.backward_flat(_mse_grad(out, target, wgt, H, W, D, divisor=float(out.shape[0])), out=grad_out,
                                 **({"marks": grad_marks} if grad_marks else {}))
         return {"mse_xy": mse[:, 0], "mse_xz": mse[:, 1], "mse_yz": mse[:, 2], "loss": mse[:, 3]}, g
+
+
+_CHAIN_STREAMS = {}
+
+
+def chain_streams(device, n, probe=True):
+    """`n` torch streams for independent chains on `device`, the same ones for every call of this process.  HIP maps streams onto
+    a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams on one queue run one after the other however
+    independent their work is — a process that has created many streams gets such pairs.  With `probe` every stream handed out
+    has been seen to run BESIDE the current stream and beside the chain streams chosen before it (a ~1-ms spin on those, a tiny
+    kernel on the candidate, once per process and stream); when no candidate passes, the remaining ones are taken as they come —
+    chains then still compute the same bits, only with less overlap."""
+    dev = th.device(device)
+    dev = th.device("cuda", th.cuda.current_device()) if dev.type == "cuda" and dev.index is None else dev
+    have = _CHAIN_STREAMS.setdefault(str(dev), [])
+    main = th.cuda.current_stream(dev)
+    spare = []
+    while len(have) < n:
+        chosen = None
+        for _ in range(8 if probe else 1):
+            cand = th.cuda.Stream(device=dev)
+            spare.append(cand)                                # (held while probing: the next candidate is another pool stream)
+            if not probe or _runs_beside(cand, [main] + have, dev):
+                chosen = cand
+                break
+        have.append(chosen if chosen is not None else spare[len(have) % len(spare)])
+    return have[:n]
+
+
+def _runs_beside(cand, busy, dev):
+    if any(cand.cuda_stream == b.cuda_stream for b in busy):
+        return False
+    e0, e_c = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    ends = [th.cuda.Event(enable_timing=True) for _ in busy]
+    x = th.zeros(256, device=dev)
+    th.cuda.synchronize(dev)
+    e0.record(busy[0])
+    for b, e in zip(busy, ends):
+        with th.cuda.stream(b):
+            th.cuda._sleep(2_000_000)                         # ~1 ms of spinning
+            e.record(b)
+    with th.cuda.stream(cand):
+        cand.wait_event(e0)
+        x.add_(1)
+        e_c.record(cand)
+    th.cuda.synchronize(dev)
+    return e0.elapsed_time(e_c) < 0.5 * min(e0.elapsed_time(e) for e in ends)
 
 
 def _batch_rows(x):
