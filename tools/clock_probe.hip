@@ -8,6 +8,7 @@
 //     MFMAs per second / 32 is the matrix pipe's clock whatever the counters mean.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DW24_TIMING tools/clock_probe.hip -o tools/ub_clock -L/opt/rocm/lib -lrocm_smi64 -lpthread
 #include "../sin3dm_amd/csrc/s3d_common.h"
+#include "ub_stubs.h"
 namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; }
   bool conv_use_wino24() { return true; }
   size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }

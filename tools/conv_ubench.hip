@@ -1,6 +1,7 @@
 // Stand-alone timing harness for the MFMA convolution (tuning only; not part of the library).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DS3D_ABLATE=k] tools/conv_ubench.hip -o /tmp/ub && /tmp/ub
 #include "../sin3dm_amd/csrc/s3d_common.h"
+#include "ub_stubs.h"
 namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } }
 #include "../sin3dm_amd/csrc/s3d_conv.hip"
 #include <vector>

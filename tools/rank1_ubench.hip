@@ -1,5 +1,6 @@
 // Stand-alone timing of the rank-1 table kernel (tuning only): hot (back-to-back) and cold (caches swept between launches).
 #include "../sin3dm_amd/csrc/s3d_common.h"
+#include "ub_stubs.h"
 namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_wino() { return false; } void wino_gn_parts(const Geo&, int*) {}
   int launch_conv_wino(ConvArgs&, hipStream_t) { return 0; } }
 #include "../sin3dm_amd/csrc/s3d_conv.hip"

@@ -3,6 +3,7 @@
 //   -DW24_TIMING: per-block phase stamps; -DW24W_RING=N: weight-fragment ring depth of the wide kernel
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino24_ubench.hip -o tools/ub_wino24
 #include "../sin3dm_amd/csrc/s3d_common.h"
+#include "ub_stubs.h"
 namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } bool conv_use_naive() { return false; } void conv_note_kernel(const char*) {} const char* conv_last_kernel() { return ""; }
   size_t push(std::vector<float>& st, const float* src, size_t n) { size_t off = (st.size() + 63) & ~size_t(63); st.resize(off + n); if (src) memcpy(st.data() + off, src, n * 4); return off; } }
 #include "../sin3dm_amd/csrc/s3d_wino.hip"
