@@ -15,7 +15,8 @@ int launch_project(const float* vol, int C, int X2, int Y2, int Z2, float* const
 int launch_enc_pack(const float* wgeo, const float* wtex, int geo, int tex, int C, float* Wp, hipStream_t st);
 int launch_enc_fwd(const EncDesc& e, const float* Wp, const float* bias, float* const pre[3], hipStream_t st);
 int launch_enc_norm(bool backward, float* const x[3], float* const y[3], float* mr, float* const dy[3], float* const dx[3],
-                    const Geo& g, int CO, hipStream_t st);
+                    const Geo& g, int CO, void* ws, hipStream_t st);       // ws (backward only): enc_norm_bwd_ws_bytes(CO)
+size_t enc_norm_bwd_ws_bytes(int CO);
 size_t enc_wgrad_ws_floats(int C, int CO);
 int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, float* ws, float* dwgeo, float* dbgeo, float* dwtex,
                      float* dbtex, hipStream_t st);

@@ -207,7 +207,7 @@ static int ae_encode(AeRun& R, float* pre[3], float* feat[3], float* mr) {
     if (R.meas()) return 0;
     S3D_TRY(launch_enc_pack(R.F(a->f_enc_w[0]), R.F(a->f_enc_w[1]), a->geo, a->tex, a->C, static_cast<float*>(a->pbuf.p) + a->wp_off, R.st));
     S3D_TRY(launch_enc_fwd(a->enc, a->P(a->wp_off), a->P(a->encb_off), pre, R.st));
-    return launch_enc_norm(false, pre, feat, mr, nullptr, nullptr, a->enc.g, a->enc.CO, R.st);
+    return launch_enc_norm(false, pre, feat, mr, nullptr, nullptr, a->enc.g, a->enc.CO, nullptr, R.st);
 }
 
 // Forward + (when grads != null) backward of one batch of points.  pred: [N][1+TC] output.
@@ -446,9 +446,9 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // ---- encoder
     float* dpre[3];
     for (int p = 0; p < 3; ++p) dpre[p] = ar.alloc<float>(hw[p] * CO);
-    float* ews = ar.alloc<float>(enc_wgrad_ws_floats(a->C, CO));
+    float* ews = ar.alloc<float>(std::max(enc_wgrad_ws_floats(a->C, CO), enc_norm_bwd_ws_bytes(CO) / sizeof(float)));
     if (!meas) {
-        S3D_TRY(launch_enc_norm(true, pre, feat, enc_mr, dfeat, dpre, g, CO, st));
+        S3D_TRY(launch_enc_norm(true, pre, feat, enc_mr, dfeat, dpre, g, CO, ews, st));        // (its chunk sums are consumed before the weight gradient reuses ews)
         S3D_TRY(launch_enc_wgrad(a->enc, dpre, a->geo, a->tex, ews, R.G(a->f_enc_w[0]), R.G(a->f_enc_b[0]), R.G(a->f_enc_w[1]),
                                  R.G(a->f_enc_b[1]), st));
         S3D_TRY(R.edge(R.sw, st));                        // every gradient of the pass is final in the order of the caller's stream (no-op in line)

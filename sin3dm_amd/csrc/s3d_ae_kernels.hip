@@ -65,28 +65,63 @@ struct EncArgs {
     int C, CO;
     long long begin[4];
 };
-__global__ void k_enc_fwd(EncArgs a) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.begin[3]) return;
-    const int p = idx >= a.begin[2] ? 2 : (idx >= a.begin[1] ? 1 : 0);
-    const long long r = idx - a.begin[p];
-    const int co = int(r % a.CO);
-    const int y = int((r / a.CO) % a.w[p]), x = int(r / ((long long)a.CO * a.w[p]));
-    const int K = 4 * a.C, h2 = 2 * a.h[p], w2 = 2 * a.w[p];
-    const float* W = a.Wp + (size_t(p) * a.CO + co) * 16 * K;
-    float s = 0.f;
-    for (int ka = 0; ka < 4; ++ka) {
-        const int X = 2 * x + ka - 1;
-        if (X < 0 || X >= h2) continue;
-        for (int kb = 0; kb < 4; ++kb) {
-            const int Y = 2 * y + kb - 1;
-            if (Y < 0 || Y >= w2) continue;
-            const float* pr = a.P[p] + (size_t(X) * w2 + Y) * K;
-            const float* wr = W + (ka * 4 + kb) * K;
-            for (int k = 0; k < K; ++k) s = fmaf(wr[k], pr[k], s);
+// One thread per output PIXEL, one wave per block (round 5; it was one thread per (pixel, output channel): 256 scalar
+// multiply-adds on 512 scalar loads each, 300 us for 0.3 GFLOP): the wave first copies its plane's weights into LDS as
+// [tap][k/4][co][4] (12 KB for CO = 12, C = 4), then every pixel's 4x4 taps x 4C projection values are read once as float4 and
+// feed all CO accumulators from broadcast LDS reads.  Same order of the multiply-adds as before.
+constexpr int kEncFwdMaxCO = 12, kEncFwdMaxK4 = 4;
+__global__ __launch_bounds__(64) void k_enc_fwd(EncArgs a) {
+    __shared__ float4 sw[16 * kEncFwdMaxK4 * kEncFwdMaxCO];
+    const int p = blockIdx.y;
+    const int h = a.h[p], w = a.w[p];
+    const int K = 4 * a.C, h2 = 2 * h, w2 = 2 * w, CO = a.CO, K4 = K / 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.Wp + size_t(p) * CO * 16 * K);      // [co][tap][k4]
+        if (CO < kEncFwdMaxCO || K4 < kEncFwdMaxK4) {                                                 // [tap][k4][co], zero past K4 / CO
+            for (int e = threadIdx.x; e < 16 * kEncFwdMaxK4 * kEncFwdMaxCO; e += 64) sw[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < CO * 16 * K4; e += 64) {                                      // consecutive lanes read consecutive float4
+            const int k4 = e % K4, tap = (e / K4) % 16, co = e / (16 * K4);
+            sw[(tap * kEncFwdMaxK4 + k4) * kEncFwdMaxCO + co] = src[e];
         }
     }
-    a.pre[p][r] = a.bias[co] + a.inv_len[p] * s;
+    __syncthreads();
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= h * w) return;
+    const int x = idx / w, y = idx - x * w;
+    float acc[kEncFwdMaxCO];
+#pragma unroll
+    for (int c = 0; c < kEncFwdMaxCO; ++c) acc[c] = 0.f;
+    for (int ka = 0; ka < 4; ++ka) {
+        const int X = 2 * x + ka - 1;
+        float4 v[4][kEncFwdMaxK4];                           // the row's 4 taps x K values, every load issued before the first use
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int Y = 2 * y + kb - 1;
+            const bool in = X >= 0 && X < h2 && Y >= 0 && Y < w2;
+            const float4* pr = reinterpret_cast<const float4*>(a.P[p] + (size_t(in ? X : 0) * w2 + (in ? Y : 0)) * K);
+#pragma unroll
+            for (int k4 = 0; k4 < kEncFwdMaxK4; ++k4) {
+                const float4 ld = pr[min(k4, K4 - 1)];       // (weights past K4 are zero)
+                v[kb][k4] = in ? ld : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int k4 = 0; k4 < kEncFwdMaxK4; ++k4) {
+                const float4* wt = sw + ((ka * 4 + kb) * kEncFwdMaxK4 + k4) * kEncFwdMaxCO;
+#pragma unroll
+                for (int c = 0; c < kEncFwdMaxCO; ++c) {
+                    const float4 wc = wt[c], u = v[kb][k4];
+                    acc[c] = fmaf(wc.w, u.w, fmaf(wc.z, u.z, fmaf(wc.y, u.y, fmaf(wc.x, u.x, acc[c]))));
+                }
+            }
+    }
+    float* o = a.pre[p] + size_t(idx) * CO;
+#pragma unroll
+    for (int c = 0; c < kEncFwdMaxCO; ++c) if (c < CO) o[c] = a.bias[c] + a.inv_len[p] * acc[c];
 }
 // Conv3d weights [CO][C][4][4][4] (geo rows use input channel 0 only) -> Wp[p][co][(ka*4+kb)*4*C + ks*C + ci]
 __global__ void k_enc_pack(const float* __restrict__ wgeo, const float* __restrict__ wtex, int geo, int tex, int C, float* __restrict__ Wp) {
@@ -115,7 +150,11 @@ int launch_enc_fwd(const EncDesc& e, const float* Wp, const float* bias, float* 
         a.P[p] = e.P[p]; a.pre[p] = pre[p]; a.h[p] = e.g.h[p]; a.w[p] = e.g.w[p]; a.inv_len[p] = e.inv_len[p];
         a.begin[p + 1] = a.begin[p] + (long long)e.g.h[p] * e.g.w[p] * e.CO;
     }
-    hipLaunchKernelGGL(k_enc_fwd, dim3(cdivll(a.begin[3], 256)), dim3(256), 0, st, a);
+    S3D_CHECK(e.CO <= kEncFwdMaxCO && e.C <= kEncFwdMaxK4, S3D_ERR_UNSUPPORTED, "encoder: %d feature channels (max %d), %d input channels (max %d)",
+              e.CO, kEncFwdMaxCO, e.C, kEncFwdMaxK4);
+    int maxpix = 0;
+    for (int p = 0; p < 3; ++p) maxpix = std::max(maxpix, e.g.h[p] * e.g.w[p]);
+    hipLaunchKernelGGL(k_enc_fwd, dim3(cdiv(maxpix, 64), 3), dim3(64), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -123,14 +162,16 @@ int launch_enc_fwd(const EncDesc& e, const float* Wp, const float* bias, float* 
 // ------------------------------------------------------------------ InstanceNorm2d (no affine, eps 1e-5) + tanh(0.5 x)
 // forward: y = tanh(0.5 * (x - mean_c) * rstd_c) per (plane, channel) over the plane's pixels; one block per (plane, channel)
 struct EncNormArgs { const float* x[3]; float* y[3]; float* mr; const float* dy[3]; float* dx[3]; int hw[3]; int CO; };
-__global__ __launch_bounds__(256) void k_enc_norm_fwd(EncNormArgs a) {
-    __shared__ double red[2][256];
+// (1024 threads per (plane, channel): the 36 blocks walk their 16 384 pixels in 16 trips instead of 64)
+constexpr int kEncNormThreads = 1024;
+__global__ __launch_bounds__(kEncNormThreads) void k_enc_norm_fwd(EncNormArgs a) {
+    __shared__ double red[2][kEncNormThreads];
     const int c = blockIdx.x, p = blockIdx.y, n = a.hw[p], CO = a.CO;
     double s = 0, ss = 0;
-    for (int i = threadIdx.x; i < n; i += 256) { const double v = a.x[p][size_t(i) * CO + c]; s += v; ss += v * v; }
+    for (int i = threadIdx.x; i < n; i += kEncNormThreads) { const double v = a.x[p][size_t(i) * CO + c]; s += v; ss += v * v; }
     red[0][threadIdx.x] = s; red[1][threadIdx.x] = ss;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = kEncNormThreads / 2; o > 0; o >>= 1) {
         if (int(threadIdx.x) < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
         __syncthreads();
     }
@@ -138,41 +179,74 @@ __global__ __launch_bounds__(256) void k_enc_norm_fwd(EncNormArgs a) {
     double var = red[1][0] / n - mean * mean; if (var < 0) var = 0;
     const float m = float(mean), rstd = float(1.0 / sqrt(var + 1e-5));
     if (threadIdx.x == 0) { a.mr[(p * CO + c) * 2] = m; a.mr[(p * CO + c) * 2 + 1] = rstd; }
-    for (int i = threadIdx.x; i < n; i += 256) a.y[p][size_t(i) * CO + c] = tanhf(0.5f * (a.x[p][size_t(i) * CO + c] - m) * rstd);
+    for (int i = threadIdx.x; i < n; i += kEncNormThreads) a.y[p][size_t(i) * CO + c] = tanhf(0.5f * (a.x[p][size_t(i) * CO + c] - m) * rstd);
 }
 // backward: dn = dy * 0.5 * (1 - y^2) ; dx = rstd * (dn - mean(dn) - n_hat * mean(dn * n_hat))
-__global__ __launch_bounds__(256) void k_enc_norm_bwd(EncNormArgs a) {
-    __shared__ double red[2][256];
-    const int c = blockIdx.x, p = blockIdx.y, n = a.hw[p], CO = a.CO;
+// Two launches over (pixel chunk, plane) blocks of 16 pixels x CO channels (round 5; it was one block per (plane, channel)
+// reading every twelfth float, 71 us): a thread keeps its channel, consecutive threads read consecutive floats; the chunk sums
+// go out as doubles and every block of the second launch adds the chunks of its plane in the same order.
+constexpr int kEncNormChunks = 64, kEncNormLanes = 16;
+struct EncNormBwdArgs { EncNormArgs n; double* part; };          // part [3][kEncNormChunks][CO][2]
+__device__ __forceinline__ float enc_norm_dn(const EncNormArgs& a, int p, size_t e, float m, float rstd, float& nh) {
+    const float y = a.y[p][e];
+    nh = (a.x[p][e] - m) * rstd;
+    return a.dy[p][e] * 0.5f * (1.f - y * y);
+}
+__global__ __launch_bounds__(kEncNormLanes * 12) void k_enc_norm_bwd_part(EncNormBwdArgs b) {
+    __shared__ double red[2][kEncNormLanes * 12];
+    const EncNormArgs& a = b.n;
+    const int chunk = blockIdx.x, p = blockIdx.y, n = a.hw[p], CO = a.CO;
+    const int c = threadIdx.x % CO, lane = threadIdx.x / CO;
+    const int p0 = int((long long)n * chunk / kEncNormChunks), p1 = int((long long)n * (chunk + 1) / kEncNormChunks);
     const float m = a.mr[(p * CO + c) * 2], rstd = a.mr[(p * CO + c) * 2 + 1];
     double s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float nh = (a.x[p][size_t(i) * CO + c] - m) * rstd, y = a.y[p][size_t(i) * CO + c];
-        const float dn = a.dy[p][size_t(i) * CO + c] * 0.5f * (1.f - y * y);
+    for (int i = p0 + lane; i < p1; i += kEncNormLanes) {
+        float nh;
+        const float dn = enc_norm_dn(a, p, size_t(i) * CO + c, m, rstd, nh);
         s1 += dn; s2 += double(dn) * nh;
     }
     red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (int(threadIdx.x) < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-        __syncthreads();
+    if (lane == 0) {
+        for (int l = 1; l < kEncNormLanes; ++l) { s1 += red[0][l * CO + c]; s2 += red[1][l * CO + c]; }
+        double* o = b.part + ((size_t(p) * kEncNormChunks + chunk) * CO + c) * 2;
+        o[0] = s1; o[1] = s2;
     }
-    const float k1 = float(red[0][0] / n), k2 = float(red[1][0] / n);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float nh = (a.x[p][size_t(i) * CO + c] - m) * rstd, y = a.y[p][size_t(i) * CO + c];
-        const float dn = a.dy[p][size_t(i) * CO + c] * 0.5f * (1.f - y * y);
+}
+__global__ __launch_bounds__(kEncNormLanes * 12) void k_enc_norm_bwd_apply(EncNormBwdArgs b) {
+    __shared__ float kk[2][12];
+    const EncNormArgs& a = b.n;
+    const int chunk = blockIdx.x, p = blockIdx.y, n = a.hw[p], CO = a.CO;
+    const int c = threadIdx.x % CO, lane = threadIdx.x / CO;
+    if (int(threadIdx.x) < 2 * CO) {
+        const int cc = threadIdx.x >> 1, which = threadIdx.x & 1;
+        double s = 0;
+        for (int k = 0; k < kEncNormChunks; ++k) s += b.part[((size_t(p) * kEncNormChunks + k) * CO + cc) * 2 + which];
+        kk[which][cc] = float(s / n);
+    }
+    __syncthreads();
+    const int p0 = int((long long)n * chunk / kEncNormChunks), p1 = int((long long)n * (chunk + 1) / kEncNormChunks);
+    const float m = a.mr[(p * CO + c) * 2], rstd = a.mr[(p * CO + c) * 2 + 1], k1 = kk[0][c], k2 = kk[1][c];
+    for (int i = p0 + lane; i < p1; i += kEncNormLanes) {
+        float nh;
+        const float dn = enc_norm_dn(a, p, size_t(i) * CO + c, m, rstd, nh);
         a.dx[p][size_t(i) * CO + c] = rstd * (dn - k1 - nh * k2);
     }
 }
+size_t enc_norm_bwd_ws_bytes(int CO) { return size_t(3) * kEncNormChunks * CO * 2 * sizeof(double); }
 int launch_enc_norm(bool backward, float* const x[3], float* const y[3], float* mr, float* const dy[3], float* const dx[3],
-                    const Geo& g, int CO, hipStream_t st) {
+                    const Geo& g, int CO, void* ws, hipStream_t st) {
     EncNormArgs a;
     for (int p = 0; p < 3; ++p) {
         a.x[p] = x[p]; a.y[p] = y[p]; a.dy[p] = dy ? dy[p] : nullptr; a.dx[p] = dx ? dx[p] : nullptr; a.hw[p] = g.h[p] * g.w[p];
     }
     a.mr = mr; a.CO = CO;
-    if (backward) hipLaunchKernelGGL(k_enc_norm_bwd, dim3(CO, 3), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_enc_norm_fwd, dim3(CO, 3), dim3(256), 0, st, a);
+    if (backward) {
+        S3D_CHECK(CO <= 12 && ws, S3D_ERR_UNSUPPORTED, "encoder norm backward: %d channels (max 12) / no workspace", CO);
+        EncNormBwdArgs b{a, static_cast<double*>(ws)};
+        hipLaunchKernelGGL(k_enc_norm_bwd_part, dim3(kEncNormChunks, 3), dim3(kEncNormLanes * CO), 0, st, b);
+        hipLaunchKernelGGL(k_enc_norm_bwd_apply, dim3(kEncNormChunks, 3), dim3(kEncNormLanes * CO), 0, st, b);
+    } else hipLaunchKernelGGL(k_enc_norm_fwd, dim3(CO, 3), dim3(kEncNormThreads), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -181,10 +255,14 @@ int launch_enc_norm(bool backward, float* const x[3], float* const y[3], float* 
 // dWp[p][co][j] = inv_len[p] * sum_{a,b} dpre[p][a][b][co] * P[p][2a+ka-1][2b+kb-1][ks][ci],  j = (ka*4+kb)*4C + ks*C + ci
 // Stage 1: block = (pixel chunk, plane), thread = j (16*4*C = 256 for C = 4), CO accumulators per thread.
 // Stage 2 (k_enc_wgrad_reduce): add chunks in order, un-permute the taps, add the three planes, write Conv3d layouts.
-constexpr int kEncChunks = 64, kEncMaxCO = 12;
+constexpr int kEncChunks = 256, kEncMaxCO = 12;
 struct EncWgArgs { const float* P[3]; const float* dpre[3]; float* part; float* bpart; int h[3], w[3]; int C, CO, J; };
+// (round 5: 256 chunks instead of 64 — three blocks per CU instead of 0.75 — and 64 pixels of dpre per barrier pair with 32
+// projection loads issued before their first use; the launch was a chain of 256 x {barrier, 12 floats into LDS, barrier, one
+// load, 12 multiply-adds} per block, 190-250 us.  The sums are formed in the same order as before within a chunk.)
+constexpr int kEncStage = 64, kEncHalf = 32;
 __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
-    __shared__ float sd[kEncMaxCO];
+    __shared__ float sd[kEncStage][kEncMaxCO];
     const int chunk = blockIdx.x, p = blockIdx.y;
     const int h = a.h[p], w = a.w[p], K = 4 * a.C, CO = a.CO;
     const int npix = h * w, p0 = int((long long)npix * chunk / kEncChunks), p1 = int((long long)npix * (chunk + 1) / kEncChunks);
@@ -194,16 +272,37 @@ __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
     float acc[kEncMaxCO];
 #pragma unroll
     for (int c = 0; c < kEncMaxCO; ++c) acc[c] = 0.f;
-    float bsum = 0.f;                                        // threads < CO: sum of dpre over the chunk (bias gradient)
-    for (int i = p0; i < p1; ++i) {
+    float bsum = 0.f;                                        // threads < CO: sum of dpre over the chunk (bias gradient), in pixel order
+    for (int i0 = p0; i0 < p1; i0 += kEncStage) {
+        const int ns = min(kEncStage, p1 - i0);
         __syncthreads();
-        if (int(threadIdx.x) < CO) { sd[threadIdx.x] = a.dpre[p][size_t(i) * CO + threadIdx.x]; bsum += sd[threadIdx.x]; }
+        for (int e = threadIdx.x; e < kEncStage * kEncMaxCO; e += 256) {      // rows past ns and columns past CO are zero
+            const int t = e / kEncMaxCO, c = e - t * kEncMaxCO;
+            sd[t][c] = t < ns && c < CO ? a.dpre[p][size_t(i0 + t) * CO + c] : 0.f;
+        }
         __syncthreads();
-        const int x = i / w, y = i % w, X = 2 * x + ka - 1, Y = 2 * y + kb - 1;
-        if (!active || X < 0 || X >= 2 * h || Y < 0 || Y >= 2 * w) continue;
-        const float v = a.P[p][(size_t(X) * 2 * w + Y) * K + k];
+        if (int(threadIdx.x) < CO) {
 #pragma unroll
-        for (int c = 0; c < kEncMaxCO; ++c) if (c < CO) acc[c] = fmaf(sd[c], v, acc[c]);
+            for (int t = 0; t < kEncStage; ++t) bsum += sd[t][threadIdx.x];
+        }
+        if (!active) continue;
+        int x = i0 / w, y = i0 - x * w;
+        for (int t0 = 0; t0 < ns; t0 += kEncHalf) {
+            float v[kEncHalf];
+#pragma unroll
+            for (int t = 0; t < kEncHalf; ++t) {
+                const int X = 2 * x + ka - 1, Y = 2 * y + kb - 1;
+                const bool in = t0 + t < ns && X >= 0 && X < 2 * h && Y >= 0 && Y < 2 * w;
+                const float ld = a.P[p][(size_t(min(max(X, 0), 2 * h - 1)) * 2 * w + min(max(Y, 0), 2 * w - 1)) * K + k];
+                v[t] = in ? ld : 0.f;
+                if (++y == w) { y = 0; ++x; }
+            }
+#pragma unroll
+            for (int t = 0; t < kEncHalf; ++t) {
+#pragma unroll
+                for (int c = 0; c < kEncMaxCO; ++c) acc[c] = fmaf(sd[t0 + t][c], v[t], acc[c]);
+            }
+        }
     }
     if (blockIdx.z == 0 && int(threadIdx.x) < CO) a.bpart[(size_t(p) * kEncChunks + chunk) * CO + threadIdx.x] = bsum;
     if (!active) return;
@@ -211,7 +310,27 @@ __global__ __launch_bounds__(256) void k_enc_wgrad(EncWgArgs a) {
 #pragma unroll
     for (int c = 0; c < kEncMaxCO; ++c) if (c < CO) o[size_t(c) * a.J] = acc[c];
 }
-struct EncWgRedArgs { const float* part; const float* bpart; float* dwgeo; float* dwtex; float* dbgeo; float* dbtex; float inv_len[3]; int hw[3]; int geo, tex, C, J; };
+struct EncWgRedArgs { const double* psum; float* dwgeo; float* dwtex; float* dbgeo; float* dbtex; float inv_len[3]; int hw[3]; int geo, tex, C, J; };
+// Stage 2a: psum[p][co][j] = sum over the chunks, eight lanes per element (32 chunks each, in order; the eight sums in lane order);
+// consecutive elements are consecutive in memory.  The biases ride along as j == J.
+constexpr int kEncRedLanes = 8;
+struct EncWgSumArgs { const float* part; const float* bpart; double* psum; int CO, J; };
+__global__ __launch_bounds__(256) void k_enc_wgrad_sum(EncWgSumArgs a) {
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x, lane = gt & (kEncRedLanes - 1);
+    const int e = gt / kEncRedLanes, n = 3 * a.CO * (a.J + 1);
+    double s = 0;
+    if (e < n) {
+        const int j = e % (a.J + 1), co = (e / (a.J + 1)) % a.CO, p = e / ((a.J + 1) * a.CO);
+        const int k0 = lane * (kEncChunks / kEncRedLanes);
+        if (j < a.J) for (int k = k0; k < k0 + kEncChunks / kEncRedLanes; ++k) s += a.part[((size_t(p) * kEncChunks + k) * a.CO + co) * a.J + j];
+        else for (int k = k0; k < k0 + kEncChunks / kEncRedLanes; ++k) s += a.bpart[(size_t(p) * kEncChunks + k) * a.CO + co];
+    }
+    const int base = threadIdx.x & 63 & ~(kEncRedLanes - 1);
+    double sum = __shfl(s, base);
+    for (int l = 1; l < kEncRedLanes; ++l) sum += __shfl(s, base + l);
+    if (lane == 0 && e < n) a.psum[e] = sum;
+}
+// Stage 2b: un-permute the taps, add the three planes, write the Conv3d layouts
 __global__ void k_enc_wgrad_reduce(EncWgRedArgs a) {
     const int CO = a.geo + a.tex, C = a.C;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;       // over CO * C * 64 Conv3d weight elements, then CO biases
@@ -221,20 +340,19 @@ __global__ void k_enc_wgrad_reduce(EncWgRedArgs a) {
         for (int p = 0; p < 3; ++p) {
             const int ka = p == 2 ? ky : kx, kb = p == 0 ? ky : kz, ks = p == 0 ? kz : (p == 1 ? ky : kx);
             const int j = (ka * 4 + kb) * 4 * C + ks * C + ci;
-            double s = 0;
-            for (int k = 0; k < kEncChunks; ++k) s += a.part[((size_t(p) * kEncChunks + k) * CO + co) * a.J + j];
-            tot += s * a.inv_len[p];
+            tot += a.psum[(size_t(p) * CO + co) * (a.J + 1) + j] * a.inv_len[p];
         }
         if (co < a.geo) { if (ci == 0) a.dwgeo[size_t(co) * 64 + (kx * 4 + ky) * 4 + kz] = float(tot); }
         else a.dwtex[(size_t(co - a.geo) * C + ci) * 64 + (kx * 4 + ky) * 4 + kz] = float(tot);
     } else if (idx < CO * C * 64 + CO) {
         const int co = idx - CO * C * 64;
         double tot = 0;
-        for (int p = 0; p < 3; ++p) for (int k = 0; k < kEncChunks; ++k) tot += a.bpart[(size_t(p) * kEncChunks + k) * CO + co];
+        for (int p = 0; p < 3; ++p) tot += a.psum[(size_t(p) * CO + co) * (a.J + 1) + a.J];
         if (co < a.geo) a.dbgeo[co] = float(tot); else a.dbtex[co - a.geo] = float(tot);
     }
 }
-size_t enc_wgrad_ws_floats(int C, int CO) { return size_t(3) * kEncChunks * CO * (16 * 4 * C + 1); }
+// partial sums [3][chunks][CO][J], bias partials [3][chunks][CO], then (8-byte aligned) the chunk totals [3][CO][J + 1] as doubles
+size_t enc_wgrad_ws_floats(int C, int CO) { return size_t(3) * kEncChunks * CO * (16 * 4 * C + 1) + 2 + size_t(2) * 3 * CO * (16 * 4 * C + 1); }
 int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, float* ws, float* dwgeo, float* dbgeo, float* dwtex,
                      float* dbtex, hipStream_t st) {
     S3D_CHECK(e.CO <= kEncMaxCO, S3D_ERR_UNSUPPORTED, "encoder: %d feature channels (max %d)", e.CO, kEncMaxCO);
@@ -244,8 +362,14 @@ int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, f
     for (int p = 0; p < 3; ++p) { a.P[p] = e.P[p]; a.dpre[p] = dpre[p]; a.h[p] = e.g.h[p]; a.w[p] = e.g.w[p]; }
     hipLaunchKernelGGL(k_enc_wgrad, dim3(kEncChunks, 3, cdiv(a.J, 256)), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
+    EncWgSumArgs q;
+    q.part = ws; q.bpart = a.bpart; q.CO = e.CO; q.J = a.J;
+    const size_t pfl = size_t(3) * kEncChunks * e.CO * (a.J + 1);
+    q.psum = reinterpret_cast<double*>(ws + pfl + (pfl & 1));
+    hipLaunchKernelGGL(k_enc_wgrad_sum, dim3(cdiv(3 * e.CO * (a.J + 1) * kEncRedLanes, 256)), dim3(256), 0, st, q);
+    S3D_HIP(hipGetLastError());
     EncWgRedArgs r;
-    r.part = ws; r.bpart = a.bpart; r.dwgeo = dwgeo; r.dwtex = dwtex; r.dbgeo = dbgeo; r.dbtex = dbtex; r.geo = geo; r.tex = tex; r.C = e.C; r.J = a.J;
+    r.psum = q.psum; r.dwgeo = dwgeo; r.dwtex = dwtex; r.dbgeo = dbgeo; r.dbtex = dbtex; r.geo = geo; r.tex = tex; r.C = e.C; r.J = a.J;
     for (int p = 0; p < 3; ++p) { r.inv_len[p] = e.inv_len[p]; r.hw[p] = e.g.h[p] * e.g.w[p]; }
     hipLaunchKernelGGL(k_enc_wgrad_reduce, dim3(cdiv(e.CO * e.C * 64 + e.CO, 256)), dim3(256), 0, st, r);
     S3D_HIP(hipGetLastError());
