@@ -424,8 +424,8 @@ struct Fwd {
         const float* film_ptr = film ? film + rb.film_off : nullptr;
         Tri y1, h1, y2;
         const float *rr[3], *rc[3];
-        // skip_connection(x) only depends on x (a second stream for it was measured in rounds 1 and 2: the event edges cost
-        // more than the overlap returns, DESIGN.md §5 — the switch is gone)
+        // skip_connection(x) only depends on x (a second stream for it was measured in rounds 1, 2 and — on a low-priority hardware
+        // queue of its own — 5: the event edges cost more than the overlap returns, profiles/r05_fwd_side.txt — the switch is gone)
         Tri skip;
         const Tri* res = &x;
         if (rb.has_skip) {
