@@ -480,7 +480,7 @@ __global__ void k_cell_keys(GatherArgs a, unsigned* __restrict__ keys, unsigned*
     if (idx >= 3 * a.Np) return;
     const int p = int(idx / a.Np);
     const long long n = idx % a.Np;
-    unsigned key = unsigned(a.ph[p]) * unsigned(a.pw[p]);          // padding rows sort behind every real cell
+    unsigned key = unsigned(a.ph[p]) * unsigned(a.pw[p]);          // padding rows sort behind every real cell of their plane
     if (n < a.N) {
         const int ku = p == 2 ? 1 : 0, kv = p == 0 ? 1 : 2;
         const float xu = 2.f * (a.pts[n * 3 + ku] - a.amin[ku]) * a.ainv[ku] - 1.f;
@@ -490,7 +490,11 @@ __global__ void k_cell_keys(GatherArgs a, unsigned* __restrict__ keys, unsigned*
         gs_coord(xv, a.pw[p], c0, c1, v0, v1);
         key = unsigned(r0) * unsigned(a.pw[p]) + unsigned(c0);
     }
-    keys[idx] = key; vals[idx] = unsigned(n);
+    // one key space for the three planes (round 5: ONE stable radix sort instead of three — 21 small dependent launches were 0.33 ms
+    // between the MLPs' backward and the plane blocks'): plane p's cells and its padding key follow plane p-1's
+    unsigned base = 0;
+    for (int k = 0; k < p; ++k) base += unsigned(a.ph[k]) * unsigned(a.pw[k]) + 1u;
+    keys[idx] = base + key; vals[idx] = unsigned(n);
 }
 __global__ void k_bin_starts(const unsigned* __restrict__ keys_sorted, long long Np, int ncell, unsigned* __restrict__ start) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;          // start[cell] = first sorted position with key >= cell
@@ -543,14 +547,14 @@ __global__ void k_scatter_sorted(ScatterSortedArgs s) {
 size_t scatter_ws_bytes(long long Np, const int ph[3], const int pw[3]) {
     size_t cub = 0;
     unsigned* d = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub, d, d, d, d, int(Np), 0, 32, nullptr);
-    size_t cells = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, cub, d, d, d, d, int(3 * Np), 0, 32, nullptr);
+    size_t cells = 8;
     for (int p = 0; p < 3; ++p) cells += size_t(ph[p]) * pw[p] + 2;
     return ((cub + 255) & ~size_t(255)) + (size_t(12) * Np + cells) * sizeof(unsigned) + 1024;
 }
-// Two halves: the point ORDER (cell keys, three radix sorts, bin starts — 21 small dependent launches) depends on the points
-// alone, so a trainer can enqueue it long before the gradients exist (s3d_ae.hip does, on the second chain's stream beside the
-// forward pass); the scatter proper follows when dX is final.
+// Two halves: the point ORDER (cell keys, one radix sort over the three planes' keys, bin starts) depends on the points alone;
+// the scatter proper follows when dX is final.  (Enqueued early — on the second chain's stream beside the MLPs' forward pass, or
+// on the idle weight-gradient stream from the first moment of the iteration — the order costs more than it returns: DESIGN.md §9.)
 int launch_scatter_prepare(const PointSet& ps, const int ph[3], const int pw[3], int C, int nnets, void* ws, ScatterPlan& plan, hipStream_t st) {
     ScatterSortedArgs& s = plan.args; memset(&s, 0, sizeof s);
     GatherArgs& a = s.g;
@@ -561,7 +565,7 @@ int launch_scatter_prepare(const PointSet& ps, const int ph[3], const int pw[3],
     if (!Np) return 0;
     size_t cub = 0;
     unsigned* d0 = nullptr;
-    S3D_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, cub, d0, d0, d0, d0, int(Np), 0, 32, st));
+    S3D_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, cub, d0, d0, d0, d0, int(3 * Np), 0, 32, st));
     char* base = static_cast<char*>(ws);
     void* cub_tmp = base; base += (cub + 255) & ~size_t(255);
     unsigned* keys = reinterpret_cast<unsigned*>(base); unsigned* vals = keys + 3 * Np;
@@ -569,16 +573,20 @@ int launch_scatter_prepare(const PointSet& ps, const int ph[3], const int pw[3],
     unsigned* start = vals_s + 3 * Np;
     hipLaunchKernelGGL(k_cell_keys, dim3(cdivll(3 * Np, 256)), dim3(256), 0, st, a, keys, vals);
     S3D_HIP(hipGetLastError());
+    long long nbins = 0;
+    for (int p = 0; p < 3; ++p) nbins += (long long)ph[p] * pw[p] + 1;      // every plane's cells + its padding key
+    S3D_CHECK(nbins < (1ll << 31) && 3 * Np < (1ll << 31), S3D_ERR_UNSUPPORTED, "scatter: %lld cells / %lld points", nbins, Np);
+    int bits = 1; while ((1ll << bits) < nbins) ++bits;
+    size_t tb = cub;
+    S3D_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, keys, keys_s, vals, vals_s, int(3 * Np), 0, bits, st));
+    hipLaunchKernelGGL(k_bin_starts, dim3(cdivll(nbins + 1, 256)), dim3(256), 0, st, keys_s, 3 * Np, int(nbins), start);
+    S3D_HIP(hipGetLastError());
     s.begin[0] = 0;
+    long long b0 = 0;
     for (int p = 0; p < 3; ++p) {
         const int ncell = ph[p] * pw[p];
-        int bits = 1; while ((1u << bits) <= unsigned(ncell)) ++bits;       // keys are in [0, ncell]
-        size_t tb = cub;
-        S3D_HIP(hipcub::DeviceRadixSort::SortPairs(cub_tmp, tb, keys + p * Np, keys_s + p * Np, vals + p * Np, vals_s + p * Np, int(Np), 0, bits, st));
-        hipLaunchKernelGGL(k_bin_starts, dim3(cdiv(ncell + 1, 256)), dim3(256), 0, st, keys_s + p * Np, Np, ncell, start);
-        S3D_HIP(hipGetLastError());
-        s.order[p] = vals_s + p * Np; s.start[p] = start;
-        start += ncell + 2;
+        s.order[p] = vals_s; s.start[p] = start + b0;          // (positions in the one sorted array)
+        b0 += ncell + 1;
         s.begin[p + 1] = s.begin[p] + (long long)ncell * (C / 4);
     }
     plan.ready = true;
