@@ -131,6 +131,49 @@ def cpu_baseline(steps_budget_s=20.0):
                       f"{cores} threads), {s_per_step * 1e3:.0f} ms/step, extrapolated to 1000 steps"}
 
 
+def eager_gpu_baseline(budget_s=10.0):
+    """The same port as cpu_baseline — the reference's arithmetic as the ATen ops the reference itself calls (F.conv2d on the
+    dense rollout concat, F.group_norm, F.interpolate, torch.cat ...) — with its tensors on cuda:0: what a PyTorch-ROCm install
+    makes of the reference's forward on this very GPU (MIOpen / rocBLAS kernels, fp32, TF32 off, eager mode, one launch per op).
+    A reported baseline like the CPU legs: run after the timed region, bounded, never the thing measured or shipped."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import torch_port as tp
+    from sin3dm_amd import testing as T
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    dev = torch.device("cuda:0")
+    H, W, D = HWD
+    sd = {k: v.to(dev) for k, v in T.synthetic_state_dict(T.unet_param_shapes(model_channels=MC), 0).items()}
+    x = torch.from_numpy(T.synthetic_noise((1, 12, H + D, W + D), 1)).to(dev)
+    t = torch.tensor([500.0], device=dev)
+    out = {}
+    with torch.no_grad():
+        for mode in ("default", "benchmark"):                         # benchmark = MIOpen's find over its solvers for every shape
+            torch.backends.cudnn.benchmark = mode == "benchmark"
+            t_w = time.perf_counter()
+            for _ in range(3):
+                tp.unet_forward(sd, x, t, H, W, D, MC)
+            torch.cuda.synchronize()
+            warm_s = time.perf_counter() - t_w
+            n, t0 = 0, time.perf_counter()
+            while True:
+                y = tp.unet_forward(sd, x, t, H, W, D, MC)
+                x = 0.5 * y.clamp(-1, 1) + 0.5 * x
+                n += 1
+                if n % 5 == 0:
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - t0 > budget_s / 2 or n >= 100:
+                        break
+            torch.cuda.synchronize()
+            out[mode] = {"ms_per_step": round((time.perf_counter() - t0) / n * 1e3, 3), "steps": n, "warmup_s": round(warm_s, 1)}
+    torch.backends.cudnn.benchmark = False
+    best = min(v["ms_per_step"] for v in out.values())
+    return {"value": round(1.0 / (T_STEPS * best * 1e-3), 4), "unit": "samples/s", "kind": "port", "ms_per_step": best, "modes": out,
+            "sample": "full-size UNet steps (128-ch, 128^3, B=1) of oracle/torch_port.py with its tensors on cuda:0 (PyTorch-ROCm eager: "
+                      "MIOpen / rocBLAS, fp32), the better of MIOpen's default and find modes, extrapolated to 1000 steps"}
+
+
 def cpu_baseline_c_oracle(budget_s=25.0):
     """BASELINE.md §3 path (i): the plain-C/OpenMP restatement (oracle/sin3dm_oracle.c, literal dense rollout concat,
     no vendor library) on the same host cores.  One 128-ch step at (64,64,64) — a quarter of the full-size pixels — is
@@ -579,6 +622,12 @@ def worker(args):
             line["cpu_baseline_c_openmp"] = cpu_baseline_c_oracle()
         except Exception as e:                                         # the C oracle is a checker; never fail the line for it
             line["cpu_baseline_c_openmp"] = {"error": repr(e)}
+        if not args.no_eager_baseline:
+            try:
+                line["eager_gpu_baseline"] = eager_gpu_baseline()
+                line["over_eager_gpu"] = round(value / line["eager_gpu_baseline"]["value"], 2)
+            except Exception as e:
+                line["eager_gpu_baseline"] = {"error": repr(e)}
     print(json.dumps(line), flush=True)
     return 0
 
@@ -589,6 +638,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the PyTorch-ROCm eager leg of the baselines (the same port on cuda:0)")
     ap.add_argument("--profile-every", type=int, default=8, help="instrument every n-th step with HIP events (0=off)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE.json workload (default: configs[1], the scored one)")
     ap.add_argument("--prewarm", type=int, default=PREWARM, help="untimed steps before --warmup (a fresh box needs them to reach steady clocks)")

@@ -20,7 +20,7 @@ PLANES = ("xy", "xz", "yz")
 def timestep_embedding(t, dim):
     """src/diffusion/nn.py:103-121"""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:

@@ -50,3 +50,15 @@ def test_bench_line_contract_and_live_roofline(config, launches_per_step, kernel
 def test_bench_chains_can_be_switched_off():
     d = _line("--config", "c2", "--chains", "0")
     assert d["chains2"] is None
+
+
+def test_eager_gpu_baseline_leg():
+    """The PyTorch-ROCm eager leg of the baselines: the CPU port's ATen ops with their tensors on cuda:0 (bounded, a reported figure)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b = bench.eager_gpu_baseline(budget_s=1.0)
+    assert b["unit"] == "samples/s" and b["kind"] == "port" and b["value"] > 0
+    assert set(b["modes"]) == {"default", "benchmark"} and all(m["steps"] >= 5 and m["ms_per_step"] > 0 for m in b["modes"].values())
+    assert abs(b["value"] - 1.0 / (1000 * b["ms_per_step"] * 1e-3)) < 1e-3 * b["value"]
