@@ -109,8 +109,8 @@ def p_sample_update(model_out, x, eps, tab, t):
 # ---------------------------------------------------------------------------------------------- training tier
 def q_sample(x0, noise, sqrt_ac, sqrt_1mac, t):
     """src/diffusion/gaussian_diffusion.py:189-207; sqrt_ac / sqrt_1mac: float64 numpy tables, t: int64 [B]."""
-    a = torch.from_numpy(sqrt_ac)[t].float()[:, None, None, None]
-    b = torch.from_numpy(sqrt_1mac)[t].float()[:, None, None, None]
+    a = torch.from_numpy(sqrt_ac).to(x0.device)[t].float()[:, None, None, None]
+    b = torch.from_numpy(sqrt_1mac).to(x0.device)[t].float()[:, None, None, None]
     return a * x0 + b * noise
 
 

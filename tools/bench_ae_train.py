@@ -18,6 +18,7 @@ ap.add_argument("--points", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--cpu-baseline", action="store_true")
+ap.add_argument("--eager-gpu-baseline", action="store_true")
 args = ap.parse_args()
 H, W, D = args.fm
 N = args.points
@@ -77,4 +78,32 @@ if args.cpu_baseline:
     line["cpu_baseline"] = {"ms_per_step": round(cdt * 1e3, 1), "cores": usable_cores(), "kind": "port",
                             "sample": f"{n} forward+backward iterations of oracle/torch_port.py (PyTorch-CPU autograd, incl. the Conv3d encoder)"}
     line["gpu_over_cpu"] = round(cdt / dt, 1)
+if args.eager_gpu_baseline:
+    # the same port under PyTorch-ROCm autograd with its tensors on this GPU (Conv3d encoder, 5x5 convolutions, grid_sample, MLPs
+    # through MIOpen / rocBLAS, fp32, eager) + torch.optim.AdamW: the reference's iteration (src/encoding/model.py) on this box
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import torch_port as tp
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.benchmark = True
+    p = {k: v.clone().to(dev).requires_grad_(True) for k, v in sd.items()}
+    opt_t = torch.optim.AdamW(list(p.values()), lr=5e-3, weight_decay=0.2)
+    aabb = torch.tensor([-1., -1, -1, 1, 1, 1], device=dev)
+    n, c0 = 0, None
+    while True:
+        ls = tp.ae_losses(tp.ae_decode(p, pts, tp.ae_encode(p, vol), aabb), sdf, tex, 0.05)
+        opt_t.zero_grad(set_to_none=True)
+        sum(ls.values()).backward()
+        opt_t.step()
+        n += 1
+        if n == 3:
+            torch.cuda.synchronize(); c0 = time.perf_counter()
+        if n > 3 and n % 5 == 3:
+            torch.cuda.synchronize()
+            if time.perf_counter() - c0 > 10 or n >= 43:
+                break
+    edt = (time.perf_counter() - c0) / (n - 3)
+    line["eager_gpu_baseline"] = {"ms_per_step": round(edt * 1e3, 2), "kind": "port",
+                                  "sample": f"{n - 3} forward+backward+AdamW iterations of oracle/torch_port.py under PyTorch-ROCm autograd on cuda:0 (MIOpen find mode, fp32, incl. the per-step Conv3d encoder)"}
+    line["over_eager_gpu"] = round(edt / dt, 2)
 print(json.dumps(line), flush=True)

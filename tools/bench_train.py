@@ -42,6 +42,7 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--cpu-baseline", action="store_true")
+ap.add_argument("--eager-gpu-baseline", action="store_true")
 ap.add_argument("--gpus", type=int, default=None, help="ranks (default: WORLD_SIZE under torchrun, else 1)")
 ap.add_argument("--overlap", type=int, default=-1, choices=(-1, 0, 1),
                 help="1 / 0: gradient all-reduce cut into groups overlapped with the backward pass / one all-reduce after it "
@@ -117,6 +118,41 @@ if rank == 0:
         line["cpu_baseline"] = {"ms_per_step": round(cdt * 1e3, 1), "cores": usable_cores(), "kind": "port",
                                 "sample": f"{n} forward+backward steps of oracle/torch_port.py (PyTorch-CPU autograd)"}
         line["gpu_over_cpu"] = round(cdt / dt, 1)
+    if args.eager_gpu_baseline and world == 1:
+        # the same port under PyTorch-ROCm autograd with its tensors on this GPU (MIOpen / rocBLAS, fp32, eager) + torch.optim.AdamW
+        # + the EMA update: what the reference's run_step (train_util.py:163-247) costs on this box without this library
+        sys.path.insert(0, os.path.join(REPO, "oracle"))
+        import oracle as orc
+        import torch_port as tp
+        torch.backends.cudnn.allow_tf32 = False
+        torch.backends.cuda.matmul.allow_tf32 = False
+        torch.backends.cudnn.benchmark = True
+        p = {k: v.clone().to(dev).requires_grad_(True) for k, v in sd.items()}
+        ema = [v.detach().clone() for v in p.values()]
+        opt_t = torch.optim.AdamW(list(p.values()), lr=5e-4, weight_decay=0.0)
+        tabs = orc.schedule_tables_named(1000)
+        xb = x0.to(dev).unsqueeze(0).expand(args.batch, -1, -1, -1).contiguous()
+        n, c0 = 0, None
+        while True:
+            t = torch.randint(0, 1000, (args.batch,), device=dev)
+            terms, _ = tp.training_losses(p, xb, t, torch.randn_like(xb), tabs, H, W, D, model_channels=args.mc)
+            opt_t.zero_grad(set_to_none=True)
+            terms["loss"].mean().backward()
+            opt_t.step()
+            with torch.no_grad():
+                torch._foreach_mul_(ema, 0.9999)
+                torch._foreach_add_(ema, [v.detach() for v in p.values()], alpha=1 - 0.9999)
+            n += 1
+            if n == 3:
+                torch.cuda.synchronize(); c0 = time.perf_counter()    # three warm-up steps (MIOpen's find)
+            if n > 3 and n % 5 == 3:
+                torch.cuda.synchronize()
+                if time.perf_counter() - c0 > 10 or n >= 43:
+                    break
+        edt = (time.perf_counter() - c0) / (n - 3)
+        line["eager_gpu_baseline"] = {"ms_per_step": round(edt * 1e3, 2), "kind": "port",
+                                      "sample": f"{n - 3} forward+backward+AdamW+EMA steps of oracle/torch_port.py under PyTorch-ROCm autograd on cuda:0 (MIOpen find mode, fp32)"}
+        line["over_eager_gpu"] = round(edt / dt, 2)
     print(json.dumps(line), flush=True)
 if world > 1:
     dist.destroy_process_group()
