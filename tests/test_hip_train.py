@@ -236,7 +236,8 @@ def test_grads_vs_oracle_wider(oracle, mc, hwd, B):
     CPU oracle's autograd (oracle/torch_port.py, itself pinned to the reference's gradients).  The towerruins-size case runs at
     batch 1 — BASELINE config 4's per-GPU batch is 4 — because the CPU oracle's autograd at that size costs ~20 s per sample;
     every kernel of the step is batch-parallel over independent samples (GroupNorm statistics and rollout means are per sample),
-    tools/bench_train.py times the real batch of 4, and test_full_size_directional_derivative runs batch 2."""
+    tools/bench_train.py times the real batch of 4, test_full_size_directional_derivative runs batch 2 and
+    test_full_size_batch_of_four_is_the_mean_of_its_samples ties the batch-4 step to its four batch-1 steps."""
     import torch
     import torch_port as tp
     H, W, D = hwd
@@ -298,6 +299,34 @@ def test_full_size_directional_derivative():
     flat.copy_(base); m.mark_parameters_changed()
     fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - gv) < 2e-2 * abs(gv), (fd, gv, L0, eps)
+
+
+def test_full_size_batch_of_four_is_the_mean_of_its_samples():
+    """BASELINE config 4 per GPU at its own batch: 64-ch UNet, towerruins (92,128,92), batch 4.  The step's loss terms are per
+    sample and its gradient is the mean over the batch, so the batch-4 gradient must equal the mean of the four batch-1 gradients
+    (same x0, noise, t per sample) up to the order of fp32 sums — a size-independent check of the batched launches (batch offsets
+    of every kernel, per-sample GroupNorm statistics and rollout means, split-K weight-gradient sums over B x tiles)."""
+    import torch
+    mc, (H, W, D), B = 64, (92, 128, 92), 4
+    m = _model(mc)
+    diffusion = _diffusion()
+    g = torch.Generator(device="cuda").manual_seed(23)
+    x0 = torch.rand((B, 12, H + D, W + D), device="cuda", generator=g) * 2 - 1
+    noise = torch.randn((B, 12, H + D, W + D), device="cuda", generator=g)
+    t = torch.tensor([650, 40, 999, 0], device="cuda")
+    kw = dict(H=H, W=W, D=D)
+    terms4, g4 = diffusion.training_losses_and_grads(m, x0, t, torch.ones(B, device="cuda"), kw, noise=noise)
+    g4, loss4 = g4.clone(), terms4["loss"].clone()
+    acc = torch.zeros_like(g4, dtype=torch.float64)
+    for b in range(B):
+        terms1, g1 = diffusion.training_losses_and_grads(m, x0[b:b + 1], t[b:b + 1], torch.ones(1, device="cuda"), kw, noise=noise[b:b + 1])
+        assert abs(float(terms1["loss"][0]) - float(loss4[b])) <= 2e-6 * abs(float(loss4[b])), b
+        acc += g1.double()
+    mean = (acc / B).float()
+    named4, named1 = m.split_flat(g4), m.split_flat(mean)
+    gmax = max(float(v.norm()) for v in named1.values())
+    worst = sorted(((float((named4[k] - named1[k]).norm()) / max(float(named1[k].norm()), 1e-2 * gmax), k) for k in named1), reverse=True)
+    assert worst[0][0] < 2e-5, worst[:5]
 
 
 @pytest.mark.parametrize("dtag", ["r50_rescale", "s200_rescale", "r50"])
