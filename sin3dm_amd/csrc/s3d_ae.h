@@ -21,9 +21,14 @@ size_t enc_wgrad_ws_floats(int C, int CO);
 int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, float* ws, float* dwgeo, float* dbgeo, float* dwtex,
                      float* dbtex, hipStream_t st);
 
-int launch_slice_pad_nhwc(const float* in, float* out, long long hw, int CT, int c0, int cin, hipStream_t st);
-int launch_unslice_nhwc(const float* dx, float* dfeat, long long hw, int CT, int c0, int cin, hipStream_t st);
-int launch_mr_from_partials(const double* part, int nchunks, int C, double count, float eps, float* mr, hipStream_t st);
+// the three planes of a net in one launch each
+int launch_slice_pad_nhwc3(const float* const in[3], float* const out[3], const size_t hw[3], int CT, int c0, int cin, hipStream_t st);
+int launch_unslice_nhwc3(const float* const dx[3], float* const dfeat[3], const size_t hw[3], int CT, int c0, int cin, hipStream_t st);
+int launch_mr_from_partials3(double* const part[3], int nchunks, int C, const size_t hw[3], float eps, float* mr, hipStream_t st);   // mr [3][C][2]
+// InstanceNorm2d(affine) + SiLU of a net's three planes + their {mean, rstd} (mr [3][C][2]): partials, statistics, apply — three launches
+int launch_inorm_silu3(float* const x[3], double* const part[3], const float* const gamma[3], const float* const beta[3], float* const y[3],
+                       const size_t hw[3], int C, float eps, float* mr, hipStream_t st);
+int launch_colsum3(const float* const x[3], const size_t rows[3], int C, float* ws, float* const out[3], float* const out2[3], hipStream_t st);   // ws: 3 * colsum_ws_floats(C)
 // InstanceNorm2d(affine, eps) + SiLU of one NHWC plane (s3d_decoder.hip); part: kInNormChunks*C*2 doubles
 constexpr int kInNormChunks = 64;
 int launch_inorm_silu(const float* x, double* part, const float* gamma, const float* beta, float* y, int hw, int C, float eps,

@@ -197,8 +197,9 @@ struct AeRun {
         hipStream_t src = use_from ? from : st;
         hipStream_t on = side ? sw : src;
         S3D_TRY(edge(src, on));                            // dy and the activation are final in the order of the stream that produced them
-        return launch_wgrad(w, on);
+        return launch_wgrad(w, on, &tail);                 // (the split-K partials stay in the arena; every reduction of the pass in ONE launch at its end)
     }
+    DeferredTail tail;
 };
 
 // encode: projections -> pre-activation planes -> InstanceNorm + tanh.  pre/feat: NHWC [hw][CO] per plane
@@ -262,14 +263,13 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
             w_out[p] = a->P(N_.out_dense[p]); b_out[p] = R.F(N_.f_out_b + size_t(p) * up);
             w_sc[p] = a->P(N_.sc_dense[p]); b_sc[p] = R.F(N_.f_sc_b + size_t(p) * up);
         }
-        if (!meas)
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_slice_pad_nhwc(feat[p], T.x[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, cs));
+        if (!meas) S3D_TRY(launch_slice_pad_nhwc3(feat, T.x, hw, CO, n == 0 ? 0 : a->geo, N_.cin, cs));
         S3D_TRY(R.conv(CONV_5x5, 32, up, g, T.x, w_in, b_in, nullptr, T.a1, 3, false, cs, true));
-        if (!meas)
-            for (int p = 0; p < 3; ++p) {
-                S3D_TRY(launch_inorm_silu(T.a1[p], T.part[p], R.F(N_.f_gamma[p]), R.F(N_.f_beta[p]), T.y[p], int(hw[p]), up, 1e-6f, cs));
-                S3D_TRY(launch_mr_from_partials(T.part[p], kInNormChunks, up, double(hw[p]), 1e-6f, T.mr + size_t(p) * up * 2, cs));
-            }
+        if (!meas) {
+            const float *gam[3], *bet[3];
+            for (int p = 0; p < 3; ++p) { gam[p] = R.F(N_.f_gamma[p]); bet[p] = R.F(N_.f_beta[p]); }
+            S3D_TRY(launch_inorm_silu3(T.a1, T.part, gam, bet, T.y, hw, up, 1e-6f, T.mr, cs));
+        }
         S3D_TRY(R.conv(CONV_1x1, 32, up, g, T.x, w_sc, b_sc, nullptr, T.s, 3, false, cs, true));
         S3D_TRY(R.conv(CONV_5x5, up, up, g, T.y, w_out, b_out, T.s, T.f, 3, false, cs, true));
     }
@@ -332,7 +332,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
     // ---- MLPs
     float* dX0[2];
     float* cws = ar.alloc<float>(colsum_ws_floats(std::max(hid, up)));
-    float* cws2 = ar.alloc<float>(colsum_ws_floats(up));           // the plane blocks' bias sums (side stream) have a workspace of their own
+    float* cws2 = ar.alloc<float>(3 * colsum_ws_floats(up));       // the plane blocks' bias sums (side stream, three planes per launch) have a workspace of their own
     // The two MLPs' backward chains are independent until the scatter: the texture net's runs on a second stream beside the
     // geometry net's (side-stream builds only) — each alternates a bandwidth-bound ReLU backward with an MFMA-bound 1x1 dgrad, so
     // the two chains want different things at most times.  Same kernels on the same operands: same bits.
@@ -414,8 +414,9 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         hipStream_t sb = R.side ? R.sw : st;
         if (!meas) {
             S3D_TRY(R.edge(cs, sb));
-            for (int p = 0; p < 3; ++p)                // out conv and shortcut share dy: identical bias gradients, one pass, two outputs
-                S3D_TRY(launch_colsum(dF[n][p], (long long)hw[p], up, cws2, R.G(N_.f_out_b + size_t(p) * up), sb, R.G(N_.f_sc_b + size_t(p) * up)));
+            float *ob[3], *sb2[3];                     // out conv and shortcut share dy: identical bias gradients, one pass, two outputs
+            for (int p = 0; p < 3; ++p) { ob[p] = R.G(N_.f_out_b + size_t(p) * up); sb2[p] = R.G(N_.f_sc_b + size_t(p) * up); }
+            S3D_TRY(launch_colsum3(dF[n], hw, up, cws2, ob, sb2, sb));
         }
         S3D_TRY(R.conv(CONV_5x5, up, up, g, dF[n], w_outT, nullptr, nullptr, d_y, 3, false, cs, true));
         S3D_TRY(R.wgrad(25, up, up, up, g, dF[n], up, T.y, dw_out, 3, cs, true));
@@ -435,12 +436,14 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         }
         if (!meas) {
             S3D_TRY(R.edge(cs, sb));                    // d_a1 is final
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_colsum(d_a1[p], (long long)hw[p], up, cws2, R.G(N_.f_in_b + size_t(p) * up), sb));
+            float* ib[3];
+            for (int p = 0; p < 3; ++p) ib[p] = R.G(N_.f_in_b + size_t(p) * up);
+            S3D_TRY(launch_colsum3(d_a1, hw, up, cws2, ib, nullptr, sb));
         }
         S3D_TRY(R.wgrad(25, 32, N_.cin, up, g, d_a1, 32, T.x, dw_in, 3, cs, true));
         S3D_TRY(R.conv(CONV_5x5, up, 32, g, d_a1, w_inT, nullptr, d_xs, d_x, 3, false, cs, true));
         if (!meas)
-            for (int p = 0; p < 3; ++p) S3D_TRY(launch_unslice_nhwc(d_x[p], dfeat[p], (long long)hw[p], CO, n == 0 ? 0 : a->geo, N_.cin, cs));
+            S3D_TRY(launch_unslice_nhwc3(d_x, dfeat, hw, CO, n == 0 ? 0 : a->geo, N_.cin, cs));
     }
     if (!meas && R.side) S3D_TRY(R.edge(a->chain2, st));          // the encoder's backward reads both nets' slices of dfeat
     // ---- encoder
@@ -451,6 +454,7 @@ static int ae_step(s3d_ae* a, const float* pts, const float* sdf, const float* t
         S3D_TRY(launch_enc_norm(true, pre, feat, enc_mr, dfeat, dpre, g, CO, ews, st));        // (its chunk sums are consumed before the weight gradient reuses ews)
         S3D_TRY(launch_enc_wgrad(a->enc, dpre, a->geo, a->tex, ews, R.G(a->f_enc_w[0]), R.G(a->f_enc_b[0]), R.G(a->f_enc_w[1]),
                                  R.G(a->f_enc_b[1]), st));
+        S3D_TRY(R.tail.flush(R.side ? R.sw : st));        // the 16 weight-gradient reductions (they were 16 launches on the stream the iteration waits for)
         S3D_TRY(R.edge(R.sw, st));                        // every gradient of the pass is final in the order of the caller's stream (no-op in line)
     }
     return 0;

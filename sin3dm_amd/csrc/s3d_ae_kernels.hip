@@ -378,42 +378,64 @@ int launch_enc_wgrad(const EncDesc& e, float* const dpre[3], int geo, int tex, f
 
 // ------------------------------------------------------------------ channel slices between the 12-channel latent and the 32-padded conv input
 // feat NHWC [hw][CT] -> x [hw][32] = channels [c0, c0+cin) zero-padded (forward) ; and the reverse scatter (backward)
-__global__ void k_slice_pad_nhwc(const float* __restrict__ in, float* __restrict__ out, long long hw, int CT, int c0, int cin) {
+// (three planes per launch — blockIdx.y — since round 5: each of these was three 5-us launches on a plane-block chain)
+struct Slice3Args { const float* in[3]; float* out[3]; long long hw[3]; int CT, c0, cin; };
+__global__ void k_slice_pad_nhwc(Slice3Args a) {
+    const int p = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= hw * 32) return;
+    if (i >= a.hw[p] * 32) return;
     const int c = int(i & 31);
-    out[i] = c < cin ? in[(i >> 5) * CT + c0 + c] : 0.f;
+    a.out[p][i] = c < a.cin ? a.in[p][(i >> 5) * a.CT + a.c0 + c] : 0.f;
 }
-__global__ void k_unslice_nhwc(const float* __restrict__ dx, float* __restrict__ dfeat, long long hw, int CT, int c0, int cin) {
+__global__ void k_unslice_nhwc(Slice3Args a) {              // in: dx [hw][32], out: dfeat [hw][CT]
+    const int p = blockIdx.y;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= hw * cin) return;
-    const int c = int(i % cin);
-    const long long pix = i / cin;
-    dfeat[pix * CT + c0 + c] = dx[pix * 32 + c];
+    if (i >= a.hw[p] * a.cin) return;
+    const int c = int(i % a.cin);
+    const long long pix = i / a.cin;
+    a.out[p][pix * a.CT + a.c0 + c] = a.in[p][pix * 32 + c];
 }
-int launch_slice_pad_nhwc(const float* in, float* out, long long hw, int CT, int c0, int cin, hipStream_t st) {
-    hipLaunchKernelGGL(k_slice_pad_nhwc, dim3(cdivll(hw * 32, 256)), dim3(256), 0, st, in, out, hw, CT, c0, cin);
+int launch_slice_pad_nhwc3(const float* const in[3], float* const out[3], const size_t hw[3], int CT, int c0, int cin, hipStream_t st) {
+    Slice3Args a; a.CT = CT; a.c0 = c0; a.cin = cin;
+    long long mx = 0;
+    for (int p = 0; p < 3; ++p) { a.in[p] = in[p]; a.out[p] = out[p]; a.hw[p] = (long long)hw[p]; mx = std::max(mx, a.hw[p]); }
+    hipLaunchKernelGGL(k_slice_pad_nhwc, dim3(cdivll(mx * 32, 256), 3), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
-int launch_unslice_nhwc(const float* dx, float* dfeat, long long hw, int CT, int c0, int cin, hipStream_t st) {
-    hipLaunchKernelGGL(k_unslice_nhwc, dim3(cdivll(hw * cin, 256)), dim3(256), 0, st, dx, dfeat, hw, CT, c0, cin);
+int launch_unslice_nhwc3(const float* const dx[3], float* const dfeat[3], const size_t hw[3], int CT, int c0, int cin, hipStream_t st) {
+    Slice3Args a; a.CT = CT; a.c0 = c0; a.cin = cin;
+    long long mx = 0;
+    for (int p = 0; p < 3; ++p) { a.in[p] = dx[p]; a.out[p] = dfeat[p]; a.hw[p] = (long long)hw[p]; mx = std::max(mx, a.hw[p]); }
+    hipLaunchKernelGGL(k_unslice_nhwc, dim3(cdivll(mx * cin, 256), 3), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
 
 // InstanceNorm statistics {mean, rstd} per channel from the per-chunk double partials of k_chan_partials (s3d_decoder.hip)
-__global__ void k_mr_from_partials(const double* __restrict__ part, int nchunks, int C, double count, float eps, float* __restrict__ mr) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// eight lanes per channel: lane l adds chunks l, l + 8, ... in order, the eight sums meet in a fixed xor tree (one thread per channel
+// walked 64 dependent loads: 12 us, six times per iteration on the plane blocks' chains)
+struct Mr3Args { const double* part[3]; double count[3]; float* mr; int nchunks, C; float eps; };      // mr [3][C][2]
+__global__ __launch_bounds__(256) void k_mr_from_partials(Mr3Args a) {
+    const int p = blockIdx.y, C = a.C;
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x, c = gt >> 3, l = gt & 7;
+    const double* part = a.part[p];
     double S = 0, SS = 0;
-    for (int k = 0; k < nchunks; ++k) { S += part[(size_t(k) * C + c) * 2]; SS += part[(size_t(k) * C + c) * 2 + 1]; }
-    const double m = S / count;
-    double var = SS / count - m * m; if (var < 0) var = 0;
-    mr[c * 2] = float(m); mr[c * 2 + 1] = float(1.0 / sqrt(var + double(eps)));
+    if (c < C)
+#pragma unroll 4
+        for (int k = l; k < a.nchunks; k += 8) { S += part[(size_t(k) * C + c) * 2]; SS += part[(size_t(k) * C + c) * 2 + 1]; }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) { S += __shfl_xor(S, d, 8); SS += __shfl_xor(SS, d, 8); }
+    if (c >= C || l != 0) return;
+    const double m = S / a.count[p];
+    double var = SS / a.count[p] - m * m; if (var < 0) var = 0;
+    float* mr = a.mr + size_t(p) * C * 2;
+    mr[c * 2] = float(m); mr[c * 2 + 1] = float(1.0 / sqrt(var + double(a.eps)));
 }
-int launch_mr_from_partials(const double* part, int nchunks, int C, double count, float eps, float* mr, hipStream_t st) {
-    hipLaunchKernelGGL(k_mr_from_partials, dim3(cdiv(C, 64)), dim3(64), 0, st, part, nchunks, C, count, eps, mr);
+int launch_mr_from_partials3(double* const part[3], int nchunks, int C, const size_t hw[3], float eps, float* mr, hipStream_t st) {
+    Mr3Args a; a.mr = mr; a.nchunks = nchunks; a.C = C; a.eps = eps;
+    for (int p = 0; p < 3; ++p) { a.part[p] = part[p]; a.count[p] = double(hw[p]); }
+    hipLaunchKernelGGL(k_mr_from_partials, dim3(cdiv(C * 8, 256), 3), dim3(256), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
@@ -700,6 +722,67 @@ int launch_colsum(const float* x, long long rows, int C, float* ws, float* out, 
                        (float*)nullptr, rows, C, ws);
     S3D_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_colsum_fin, dim3(cdiv(C, 64)), dim3(1024), 0, st, ws, out, C, out2);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
+// the same for three planes in one launch pair (blockIdx.y; ws: 3 * colsum_ws_floats(C)) — the plane blocks' bias gradients were
+// twelve launch pairs per iteration on the weight-gradient stream, which is what the iteration waits for
+struct ColSum3Args { const float* x[3]; long long rows[3]; float* out[3]; float* out2[3]; float* part; int C; };
+__global__ __launch_bounds__(kColThreads) void k_colsum3_part(ColSum3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm_rb[];      // [pl][C]
+    const int p = blockIdx.y, C = a.C, cq = C / 4, pl = blockDim.x / cq;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const long long rows = a.rows[p], r0 = rows * blockIdx.x / kColChunks, r1 = rows * (blockIdx.x + 1) / kColChunks;
+    const float* x = a.x[p];
+    float4 s = make_float4(0, 0, 0, 0);
+    for (long long n0 = r0 + l; n0 < r1; n0 += 4 * pl) {
+        float4 d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) d[u] = *reinterpret_cast<const float4*>(x + min(n0 + (long long)u * pl, r1 - 1) * C + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (n0 + (long long)u * pl >= r1) break;
+            s.x += d[u].x; s.y += d[u].y; s.z += d[u].z; s.w += d[u].w;
+        }
+    }
+    reinterpret_cast<float4*>(sm_rb)[l * cq + q] = s;
+    __syncthreads();
+    float* part = a.part + size_t(p) * kColChunks * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int ll = 0; ll < pl; ++ll) t += sm_rb[ll * C + c];
+        part[size_t(blockIdx.x) * C + c] = t;
+    }
+}
+__global__ __launch_bounds__(1024) void k_colsum3_fin(ColSum3Args a) {
+    __shared__ double red[16][64];
+    const int p = blockIdx.y, C = a.C;
+    const int l = threadIdx.x & 63, kl = threadIdx.x >> 6, c = blockIdx.x * 64 + l;
+    const float* part = a.part + size_t(p) * kColChunks * C;
+    double s = 0;
+    if (c < C)
+#pragma unroll
+        for (int k = 0; k < kColChunks / 16; ++k) s += part[size_t(kl + 16 * k) * C + c];
+    red[kl][l] = s;
+    __syncthreads();
+    if (kl == 0 && c < C) {
+        double t = red[0][l];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][l];
+        const float v = float(t);
+        a.out[p][c] = v;
+        if (a.out2[p]) a.out2[p][c] = v;
+    }
+}
+int launch_colsum3(const float* const x[3], const size_t rows[3], int C, float* ws, float* const out[3], float* const out2[3], hipStream_t st) {
+    S3D_CHECK(C % 4 == 0 && C <= 1024, S3D_ERR_INVALID, "colsum: C=%d", C);
+    ColSum3Args a; a.part = ws; a.C = C;
+    for (int p = 0; p < 3; ++p) { a.x[p] = x[p]; a.rows[p] = (long long)rows[p]; a.out[p] = out[p]; a.out2[p] = out2 ? out2[p] : nullptr; }
+    const int cq = C / 4, pl = std::max(1, kColThreads / cq);
+    hipLaunchKernelGGL(k_colsum3_part, dim3(kColChunks, 3), dim3(cq * pl), size_t(pl) * C * sizeof(float), st, a);
+    S3D_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_colsum3_fin, dim3(cdiv(C, 64), 3), dim3(1024), 0, st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }

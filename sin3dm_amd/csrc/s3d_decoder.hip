@@ -102,6 +102,73 @@ int launch_inorm_silu(const float* x, double* part, const float* gamma, const fl
     return 0;
 }
 
+// The auto-encoder training tier's form (round 5): three planes per launch (blockIdx.y), the statistics finished by their own
+// small launch between the two (launch_mr_from_partials3, s3d_ae_kernels.hip — every block of the apply pass used to walk the 64
+// chunk records of its channels itself, 10 of its 18 us)
+struct InNorm3Args { const float* x[3]; float* y[3]; double* part[3]; const float* gamma[3]; const float* beta[3]; const float* mr; int hw[3]; int C; };
+__global__ void k_chan_partials3(InNorm3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* sm = reinterpret_cast<double*>(smem_raw);
+    const int p = blockIdx.y, C = a.C, hw = a.hw[p];
+    const float* x = a.x[p];
+    double* part = a.part[p];
+    const int cq = C / 4, pl = blockDim.x / cq;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const int per = (hw + kInChunks - 1) / kInChunks;
+    const int p0 = blockIdx.x * per, p1 = min(hw, p0 + per);
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int pix = p0 + l; pix < p1; pix += pl) {
+        const float4 v = reinterpret_cast<const float4*>(x)[size_t(pix) * cq + q];
+        s[0] += v.x; ss[0] += double(v.x) * v.x; s[1] += v.y; ss[1] += double(v.y) * v.y;
+        s[2] += v.z; ss[2] += double(v.z) * v.z; s[3] += v.w; ss[3] += double(v.w) * v.w;
+    }
+    for (int k = 0; k < 4; ++k) { sm[(size_t(l) * C + 4 * q + k) * 2] = s[k]; sm[(size_t(l) * C + 4 * q + k) * 2 + 1] = ss[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double S = 0, SS = 0;
+        for (int ll = 0; ll < pl; ++ll) { S += sm[(size_t(ll) * C + c) * 2]; SS += sm[(size_t(ll) * C + c) * 2 + 1]; }
+        part[(size_t(blockIdx.x) * C + c) * 2] = S; part[(size_t(blockIdx.x) * C + c) * 2 + 1] = SS;
+    }
+}
+__global__ void k_inorm_silu3(InNorm3Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int p = blockIdx.y, C = a.C, hw = a.hw[p];
+    float* A = reinterpret_cast<float*>(smem_raw); float* Bc = A + C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float m = a.mr[(size_t(p) * C + c) * 2], scale = a.mr[(size_t(p) * C + c) * 2 + 1] * a.gamma[p][c];
+        A[c] = scale; Bc[c] = a.beta[p][c] - scale * m;
+    }
+    __syncthreads();
+    const int cq = C / 4;
+    const float* x = a.x[p]; float* y = a.y[p];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)hw * cq; i += (long long)gridDim.x * blockDim.x) {
+        const int q = int(i % cq);
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 s = reinterpret_cast<const float4*>(A)[q], b = reinterpret_cast<const float4*>(Bc)[q];
+        float4 o;
+        o.x = fmaf(v.x, s.x, b.x); o.y = fmaf(v.y, s.y, b.y); o.z = fmaf(v.z, s.z, b.z); o.w = fmaf(v.w, s.w, b.w);
+        o.x = o.x / (1.f + expf(-o.x)); o.y = o.y / (1.f + expf(-o.y)); o.z = o.z / (1.f + expf(-o.z)); o.w = o.w / (1.f + expf(-o.w));
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+int launch_mr_from_partials3(double* const part[3], int nchunks, int C, const size_t hw[3], float eps, float* mr, hipStream_t st);
+int launch_inorm_silu3(float* const x[3], double* const part[3], const float* const gamma[3], const float* const beta[3], float* const y[3],
+                       const size_t hw[3], int C, float eps, float* mr, hipStream_t st) {
+    InNorm3Args a; a.C = C; a.mr = mr;
+    int mx = 0;
+    for (int p = 0; p < 3; ++p) {
+        a.x[p] = x[p]; a.y[p] = y[p]; a.part[p] = part[p]; a.gamma[p] = gamma[p]; a.beta[p] = beta[p]; a.hw[p] = int(hw[p]);
+        mx = std::max(mx, a.hw[p]);
+    }
+    const int cq = C / 4, pl = std::max(1, 256 / cq);
+    hipLaunchKernelGGL(k_chan_partials3, dim3(kInChunks, 3), dim3(cq * pl), size_t(pl) * C * 2 * sizeof(double), st, a);
+    S3D_HIP(hipGetLastError());
+    S3D_TRY(launch_mr_from_partials3(part, kInChunks, C, hw, eps, mr, st));
+    hipLaunchKernelGGL(k_inorm_silu3, dim3(std::min(1024, (mx * cq + 255) / 256), 3), dim3(256), size_t(2) * C * sizeof(float), st, a);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ fused gather + MLP
 struct MlpW {                 // device pointers of one DecoderMLPSkipConcat, padded to multiples of 32
     const float* w[6]; const float* b[6];
