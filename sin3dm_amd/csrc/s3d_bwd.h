@@ -6,7 +6,7 @@
 namespace s3d {
 
 // row / column sums of dy with the three edge variants: R[p] [B][h][3][C], Cs[p] [B][w][3][C]
-int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st);
+int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st, hipEvent_t stop = nullptr);   // stop: recorded with the launch's completion
 // dbias[p][C] from the row sums; per_sample [B][stride] (+= over planes) or null
 int launch_bias_grad(float* const R[3], const Geo& g, int C, int B, float* const dbias[3], float* per_sample,
                      int per_sample_stride, hipStream_t st);

@@ -8,6 +8,7 @@
 // and only the plane's own channels need the dense dgrad (the forward conv kernels with a transposed operator) and
 // the dense wgrad (k_wgrad_mfma).  All reductions are two-stage with a fixed order: bit-repeatable, no float atomics.
 #include "s3d_bwd.h"
+#include <hip/hip_ext.h>
 
 namespace s3d {
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_edge_sums(EdgeArgs a) {
         out[c] = s0; out[C + c] = s1; out[2 * C + c] = s2;
     }
 }
-int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st) {
+int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3], hipStream_t st, hipEvent_t stop) {
     EdgeArgs a;
     a.B = B; a.C = dy.C; a.begin[0] = 0;
     S3D_CHECK(dy.C % 4 == 0 && dy.C <= 1024, S3D_ERR_INVALID, "edge_sums: C=%d", dy.C);
@@ -70,7 +71,10 @@ int launch_edge_sums(const Tri& dy, int B, float* const R[3], float* const Cs[3]
     }
     if (!B || !a.begin[6]) return 0;
     const int cq = dy.C / 4, pl = std::max(1, 256 / cq);
-    hipLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(cq * pl), size_t(pl) * dy.C * sizeof(float), st, a);
+    // stop: an event tied to THIS launch's completion signal (hipExtLaunchKernelGGL) — a separate hipEventRecord behind the launch is
+    // a barrier packet of its own, which opens a 6-8-us gap in front of the stream's next kernel
+    if (stop) hipExtLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(cq * pl), size_t(pl) * dy.C * sizeof(float), st, nullptr, stop, 0, a);
+    else hipLaunchKernelGGL(k_edge_sums, dim3(a.begin[6] * B), dim3(cq * pl), size_t(pl) * dy.C * sizeof(float), st, a);
     S3D_HIP(hipGetLastError());
     return 0;
 }
