@@ -132,11 +132,20 @@ struct Bwd {
         if (!meas()) {
             // the side stream waits for the edge sums (and dy before them): the event rides on the launch's own completion signal
             // — a hipEventRecord behind it is a barrier packet of its own in front of the chain's next kernel (2.867 -> 2.850 ms/step)
+            // (under rocprofv3 an event on a dispatch's completion signal makes the waiting queue crawl — a traced step took 3.8 ms
+            // instead of 2.9 —: a plain record there, so that traces keep their shape)
+            static const bool traced = getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROFILER_LIBRARY_CTOR");
+            if (traced && st != sw) {
+                S3D_TRY(launch_edge_sums(dy, B, R, Cs, st));
+                S3D_TRY(edge(st, sw));
+                S3D_TRY(launch_bias_grad_deferred(R, g, cout, B, dbias, per_sample_bias, m->film_total, tail));
+            } else {
             hipEvent_t e = st != sw ? next_event() : nullptr;
             S3D_CHECK(st == sw || e, S3D_ERR_HIP, "backward: hipEventCreate failed");
             S3D_TRY(launch_edge_sums(dy, B, R, Cs, st, e));
             if (e) S3D_HIP(hipStreamWaitEvent(sw, e, 0));
             S3D_TRY(launch_bias_grad_deferred(R, g, cout, B, dbias, per_sample_bias, m->film_total, tail));
+            }
         }
         if (roll) {
             const MeanVecs& mv = nt->mv;
