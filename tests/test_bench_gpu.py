@@ -60,5 +60,5 @@ def test_eager_gpu_baseline_leg():
     spec.loader.exec_module(bench)
     b = bench.eager_gpu_baseline(budget_s=1.0)
     assert b["unit"] == "samples/s" and b["kind"] == "port" and b["value"] > 0
-    assert set(b["modes"]) == {"default", "benchmark"} and all(m["steps"] >= 5 and m["ms_per_step"] > 0 for m in b["modes"].values())
+    assert "default" in b["modes"] and set(b["modes"]) <= {"default", "benchmark"} and all(m["steps"] >= 5 and m["ms_per_step"] > 0 for m in b["modes"].values())
     assert abs(b["value"] - 1.0 / (1000 * b["ms_per_step"] * 1e-3)) < 1e-3 * b["value"]
