@@ -402,6 +402,9 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     (H, W, D), BATCH, sampler_kind, respacing, steps_per_sample, metric, workload = CONFIGS[args.config]
+    # --force-dist: the process group (RCCL) is created at N = 1 too, so every collective of the N > 1 path — barrier, MAX
+    # all-reduce, object gather, and in --config c4 the parameter broadcast + gradient all-reduce of TrainLoop — really executes
+    dist_on = world > 1 or (args.force_dist and not args.dry_run)
     clock = None
     chains2 = None
 
@@ -434,7 +437,11 @@ def worker(args):
         ident = device_identity(local)
         if rank == 0:
             clock = ClockSampler(ident.get("pci_bus_id"))            # (a child process; it is sampling by the time the model is built)
-        if world > 1:
+        if dist_on:
+            if world == 1:                                            # --force-dist: a local rendezvous of one
+                from sin3dm_amd.parallel import _free_port
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+                os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
             dist.init_process_group("nccl", device_id=dev)
         mc = MC_OF.get(args.config, MC)
         model = TriplaneUNetModelSmall(12, mc, 12, num_res_blocks=1, channel_mult=(1, 2), use_scale_shift_norm=True)
@@ -476,7 +483,7 @@ def worker(args):
         sync = torch.cuda.synchronize
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     with torch.no_grad():
@@ -520,7 +527,7 @@ def worker(args):
     # every rank reports who it was and what it measured: the line shows N distinct devices, not just a world size
     mine = dict(ident, rank=rank, ms_per_step=round(dt / args.steps * 1e3, 4))
     ranks, backend_world = [mine], 1
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -613,7 +620,7 @@ def worker(args):
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
             "roofline": roof, "chains2": chains2, "s3d_switches": switches,
             "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks], "devices_verified_distinct": bool(verifiable) if world > 1 else None,
-            "rccl_world_size": backend_world if world > 1 else None, "dist_backend": backend if world > 1 else None}
+            "rccl_world_size": backend_world if dist_on else None, "dist_backend": backend if dist_on else None}
     if args.dry_run:
         line["data"] = "DRY RUN (no GPU work: launcher / rendezvous plumbing check only)"
         line["value"] = 0.0
@@ -647,6 +654,8 @@ def main():
     ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
                     help="auto: measure roofline.traffic in this run with two rocprofv3 --pmc child passes (N = 1 only)")
     ap.add_argument("--chains", type=int, default=2, help="also report the c2 workload as this many independent chains in flight (field `chains2`; 0/1 = off)")
+    ap.add_argument("--force-dist", action="store_true", help="create the RCCL process group even at --gpus 1: barrier / all-reduce / gather "
+                    "(and --config c4's parameter broadcast + gradient all-reduce) execute at world size 1")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run-fail-early", action="store_true", help=argparse.SUPPRESS)

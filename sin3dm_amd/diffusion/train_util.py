@@ -99,8 +99,9 @@ class TrainLoop:
         self.log_dir = log_dir
         self.step = 0
         self.resume_step = 0
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.dist_on = parallel.active()             # a process group exists (any world size, a forced world-size-1 group included)
+        self.world = dist.get_world_size() if self.dist_on else 1
+        self.rank = dist.get_rank() if self.dist_on else 0
         self.global_batch = self.batch_size * self.world
         self._kvs = {}
         self._pending_losses = []
@@ -109,17 +110,18 @@ class TrainLoop:
         if resume_checkpoint:
             self.resume_step = parse_resume_step_from_filename(resume_checkpoint)
             self.model.load_state_dict(th.load(resume_checkpoint, map_location="cpu"))
-        if self.world > 1:                           # identical start on every rank (the role of sync_params)
+        if self.dist_on:                             # identical start on every rank (the role of sync_params)
             parallel.broadcast_flat_(self.model.flat_parameters, src=0)
             self.model.mark_parameters_changed()
         self.opt = optimizer if optimizer is not None else FlatAdamW(model, lr=self.lr, weight_decay=self.weight_decay, ema_rates=self.ema_rate)
         if self.resume_step:
             self._load_optimizer_and_ema()
         self._grad = th.empty_like(self.model.flat_parameters)
-        # Gradient exchange overlapped with the backward pass: OFF by default.  The communication-stream / event ordering has
-        # never run on more than one GPU (no multi-GPU node was available to this build), and from three ranks on the cut
-        # vector is reduced in a different order than the whole one (parallel.average_flat_groups_): S3D_OVERLAP_ALLREDUCE=1
-        # opts in until a multi-GPU RCCL run has compared both.
+        # Gradient exchange overlapped with the backward pass: OFF by default.  The communication-stream / event ordering runs
+        # on hardware at world size 1 (tests/test_rccl_world1.py: real RCCL calls behind the real backward marks) but has never
+        # run on more than one GPU (no multi-GPU node was available to this build), and from three ranks on the cut vector is
+        # reduced in a different order than the whole one (parallel.average_flat_groups_): S3D_OVERLAP_ALLREDUCE=1 opts in
+        # until a multi-GPU RCCL run has compared both.
         self.overlap_allreduce = os.environ.get("S3D_OVERLAP_ALLREDUCE", "0") == "1"
         self._marks = self._comm = self._groups = self._staging = None
 
@@ -161,11 +163,11 @@ class TrainLoop:
         dev = self.model.flat_parameters.device
         micro = batch.to(dev)
         t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
-        if self.world > 1 and self.overlap_allreduce:
+        if self.dist_on and self.overlap_allreduce:
             # loss = mean over the GLOBAL batch.  The backward pass fills the flat gradient from the output blocks towards
             # the input; the groups that are final early are all-reduced on a communication stream while the rest of it
             # runs (RCCL over xGMI on GPUs), joined before the optimizer step.  Bit-identical to the single all-reduce at
-            # world size 2 (tests/test_parallel.py); unmeasured on hardware until a multi-GPU node is available.
+            # world size 2 (tests/test_parallel.py); on hardware it has run at world size 1 only (tests/test_rccl_world1.py).
             if self._groups is None:
                 self._groups = self.model.grad_ready_groups()
                 self._staging = parallel.GroupStaging(self._grad, self._groups)       # allocated once, not per step

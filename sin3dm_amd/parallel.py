@@ -20,10 +20,20 @@ def env_rank_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None, device=None, timeout_s=None):
-    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+def init(backend=None, device=None, timeout_s=None, force=None):
+    """Initialise torch.distributed from the torchrun environment.  A single process stays without a process group unless
+    `force` (or S3D_FORCE_DIST=1): then the group is created at world size 1 as well and EVERY collective below really runs —
+    RCCL initialisation, the parameter broadcast, the AVG all-reduce and the communication-stream exchange execute on a one-GPU
+    box exactly as they do on eight (tests/test_rccl_world1.py; MASTER_ADDR / MASTER_PORT default to a local rendezvous)."""
     rank, local, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("S3D_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
         if timeout_s is not None:
@@ -31,6 +41,30 @@ def init(backend=None, device=None, timeout_s=None):
             kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
         dist.init_process_group(backend, **kw)
     return rank, local, world
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def active():
+    """True when a process group exists — at ANY world size: the collectives below run whenever it does (a forced world-size-1
+    group exercises the same RCCL calls as a multi-GPU launch), and are skipped only in a plain single process."""
+    return dist.is_available() and dist.is_initialized()
+
+
+def shutdown():
+    """Barrier, then destroy the process group (when there is one).  Every entry point that called init() ends with this:
+    a rank that exits with a live RCCL / gloo group can abort in the group's destructor ('terminate called without an active
+    exception', rc -6) after its work is done, and the launcher reports that finished run as failed."""
+    if active():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()
 
 
 def launch_token():
@@ -102,7 +136,7 @@ def gather_objects(obj):
 def broadcast_flat_(flat, src=0):
     """Identical start on every rank: overwrite `flat` with rank `src`'s copy (the role of the reference's dead
     sync_params, src/utils/dist_util.py:62-68)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         dist.broadcast(flat, src=src)
     return flat
 
@@ -110,7 +144,7 @@ def broadcast_flat_(flat, src=0):
 def average_flat_(flat):
     """Mean over ranks of a flat gradient vector, in place: ONE all-reduce per training step (RCCL over xGMI on GPUs:
     28 MB at 64 channels, 112 MB at 128).  loss = mean over the GLOBAL batch => average the per-rank gradients."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if active():
         if _has_avg():
             dist.all_reduce(flat, op=dist.ReduceOp.AVG)       # RCCL scales inside the collective: one pass over the vector, not two
         else:
@@ -120,9 +154,12 @@ def average_flat_(flat):
 
 
 def _has_avg():
-    """ReduceOp.AVG exists in RCCL (backend "nccl"), not in gloo.  RCCL's fp32 average scales every rank's operand by 1/world
-    before the sum; for a power-of-two world size that is exact, i.e. the same bits as sum-then-scale."""
-    return dist.get_backend() == "nccl"
+    """ReduceOp.AVG exists in RCCL (backend "nccl", also inside a composite backend string), not in gloo.  RCCL's fp32 average
+    scales every rank's operand by 1/world before the sum; for a power-of-two world size that is exact, i.e. the same bits as
+    sum-then-scale — for any other world size (DP 3 / 5 / 6 / 7) the two differ in the last bit, so those keep SUM + one scaling
+    pass: a run's arithmetic does not depend on which backend carried it."""
+    world = dist.get_world_size()
+    return "nccl" in str(dist.get_backend()) and (world & (world - 1)) == 0
 
 
 # ---- gradient exchange overlapped with the backward pass (SURVEY.md §5: "comm can simply overlap the tail of backward")
@@ -184,7 +221,7 @@ def average_flat_groups_(flat, groups, marks=None, comm_stream=None, staging=Non
     comm_stream behind its event, so they run while the main stream is still in the backward pass; the caller's stream waits for
     comm_stream at the end.  Without them (CPU / gloo): sequential.  staging: a GroupStaging kept by the caller across steps
     (None: buffers are allocated for this call)."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not active():
         return flat
     world = dist.get_world_size()
     on_gpu = flat.is_cuda and comm_stream is not None

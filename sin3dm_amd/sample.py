@@ -104,7 +104,7 @@ def main(argv=None):
     all_paths = sorted(p for ps in parallel.gather_objects(paths) for p in ps)
     if rank == 0:
         print(f"wrote {len(all_paths)} samples under {os.path.join(args.tag, args.output)}")
-    parallel.barrier()
+    parallel.shutdown()                              # barrier + destroy_process_group
     return all_paths
 
 

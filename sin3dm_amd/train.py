@@ -70,6 +70,22 @@ def stage1_marker(tag):
     return os.path.join(tag, ".stage1_done_" + parallel.launch_token())
 
 
+def _marker_launcher_alive(path):
+    """The marker's name ends in the launcher's pid (parallel.launch_token): a marker whose launcher still runs belongs to a live
+    launch on the same --tag whose ranks may still be waiting for it — only the markers of dead launchers are stale."""
+    try:
+        pid = int(os.path.basename(path).rsplit("_", 1)[-1])
+    except ValueError:
+        return False
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    return True
+
+
 def main(argv=None, confirm=input):
     rank, local, world = parallel.env_rank_world()
     args = train_args(argv, confirm=confirm, write=rank == 0)        # rank 0 alone creates directories / symlink / args.json
@@ -87,7 +103,7 @@ def main(argv=None, confirm=input):
         if world > 1:                                # markers of launches that died between writing and removing theirs
             import glob
             for stale in glob.glob(os.path.join(args.tag, ".stage1_done_*")):
-                if stale != marker:
+                if stale != marker and not _marker_launcher_alive(stale):     # (a second launch on this --tag must not take a live launch's marker)
                     try:
                         os.remove(stale)
                     except OSError:
@@ -105,7 +121,7 @@ def main(argv=None, confirm=input):
     if rank == 0 and world > 1:
         os.remove(marker)                            # every rank is past its wait
     train_diffusion(args, rank)
-    parallel.barrier()
+    parallel.shutdown()                              # barrier + destroy_process_group: no rank exits with a live group
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ t = parallel.max_over_ranks(0.25 + rank)            # rank 1 is the slow one
 allp = parallel.gather_objects({"rank": rank, "mine": mine, "noise": noise})
 if rank == 0:
     print("RESULT " + json.dumps({"t": t, "all": allp}))
-parallel.barrier()
+parallel.shutdown()
 """
 
 
@@ -111,7 +111,7 @@ s.update_with_local_losses(torch.tensor([rank, 3]), torch.tensor([1.0 + rank, 5.
 out = parallel.gather_objects({"p": p.tolist(), "g": g.tolist(), "counts": s._loss_counts.tolist(), "hist": s._loss_history.tolist()})
 if rank == 0:
     print("RESULT " + json.dumps(out))
-parallel.barrier()
+parallel.shutdown()
 """
 
 
@@ -162,7 +162,7 @@ res = {"equal": bool(torch.equal(whole, chunked)), "covered_once": bool((covered
 out = parallel.gather_objects(res)
 if rank == 0:
     print("RESULT " + json.dumps(out))
-parallel.barrier()
+parallel.shutdown()
 """
 
 
@@ -265,7 +265,7 @@ res = {"equal": bool(torch.equal(a, b)), "sum": float(a.double().sum()), "moved"
 out = parallel.gather_objects(res)
 if rank == 0:
     print("RESULT " + json.dumps(out))
-parallel.barrier()
+parallel.shutdown()
 """
 
 
@@ -336,11 +336,18 @@ def test_train_cli_ranks_wait_for_stage1_outside_any_collective(tmp_path):
     """python -m sin3dm_amd.train on N ranks: rank 0 runs the auto-encoder stage (src/train.py:8-29) before torch.distributed is
     initialised; the other ranks wait for its marker file — not in a barrier whose watchdog would abort the job when stage 1
     outlasts the collective timeout (25 000 iterations x 6.3 ms is already 160 s).  The marker is removed once every
-    rank is past its wait, and a stale one of an earlier launch is cleared by rank 0."""
+    rank is past its wait, and a stale one of an earlier launch — one whose launcher pid is gone — is cleared by rank 0 (ADVICE r4);
+    the marker of a launch whose launcher is still alive (a second job on the same --tag) is left alone."""
     os.makedirs(tmp_path / "EXP")
-    stale = tmp_path / "EXP" / ".stage1_done_run_1_1"
+    gone = subprocess.Popen([sys.executable, "-c", "pass"])
+    gone.wait()
+    stale = tmp_path / "EXP" / f".stage1_done_run_1_{gone.pid}"
     stale.write_text("")
+    live = tmp_path / "EXP" / f".stage1_done_run_2_{os.getpid()}"
+    live.write_text("")
     exp, procs, outs = _run_stage1(tmp_path, only_enc=False)
+    assert live.exists()
+    live.unlink()
     for p, (o, err) in zip(procs, outs):
         assert p.returncode == 0, err[-3000:]
     waits = {int(l.split()[1]): float(l.split()[2]) for o, _ in outs for l in o.splitlines() if l.startswith("RESULT ")}
