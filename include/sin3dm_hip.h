@@ -47,6 +47,8 @@ S3D_API int s3d_abi_version(void);
  * selected THEN current.
  *   WINO          24 (default) mixed Winograd F(2x4,3x3) | 4, 2: F(2x2) | 0: direct MFMA convolution          (rounding differs)
  *   WINO24W       unset: by launch size | 0 never | 1 always the 64-output-channel block                    (bit-identical)
+ *   WINO24G       1: the mixed Winograd kernel with its halo staged by LDS-DMA and persistent blocks (default: off — measured on
+ *                 par with or behind the register-staged kernels, profiles/r06_wino_glds.txt)                (bit-identical)
  *   VCAT          0: materialise upsample + concat in the output blocks (default: virtual concat)            (rounding differs)
  *   WGRAD_WINO    0: direct 3x3 weight gradient (default: Winograd)                                          (rounding differs)
  *   RANK1_SLICES  0: one K slice of the rollout tables (default: two from 256 channels)                      (rounding differs)

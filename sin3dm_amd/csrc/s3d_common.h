@@ -90,7 +90,7 @@ int upload(DevBuf& dst, const void* host, size_t bytes);
 // S3D_<NAME> (read once, at the first query of that option); before that the default (kOptUnset for the choices the library
 // makes by launch size).  Queries are a table read: cheap enough for every launch.
 enum Opt { OPT_WINO = 0, OPT_WINO24W, OPT_VCAT, OPT_WGRAD_WINO, OPT_RANK1_SLICES, OPT_RANK1_BATCH, OPT_CONV_IMPL, OPT_CONV1X1_T,
-           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_GNB_FUSED, OPT_COUNT };
+           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_GNB_FUSED, OPT_WINO24G, OPT_COUNT };
 constexpr int kOptUnset = -1;
 int opt(Opt o);                       // kOptUnset when neither set nor in the environment
 inline bool opt_on(Opt o) { return opt(o) != 0; }      // switches that default to on: anything but an explicit 0
@@ -265,6 +265,7 @@ size_t pack_wino24s_weights(std::vector<float>& stage, const float* W, int cout,
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st);
 int launch_conv_wino24_narrow(ConvArgs& a, hipStream_t st);     // k_conv_wino24s, whatever the launch size
 int launch_conv_wino24_wide(ConvArgs& a, hipStream_t st);       // k_conv_wino24w (cout % 64 == 0)
+int launch_conv_wino24_glds(ConvArgs& a, hipStream_t st);       // k_conv_wino24g: halo by LDS-DMA, persistent blocks (S3D_WINO24G=1)
 
 // GroupNorm-apply (+FiLM) + SiLU, writing y and (optionally) row/col partial sums of y for the rollout means.
 struct ActArgs {

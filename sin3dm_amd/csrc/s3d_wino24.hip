@@ -39,7 +39,9 @@ __device__ __forceinline__ int x_edge_variant(int idx, int n) { return n == 1 ? 
 #ifdef W24_TIMING
 __device__ unsigned long long* g_w24time;     // tools/wino24_ubench.hip: per-block wall-clock stamps (entry, halo in LDS, first MFMA, last MFMA, images written, exit)
                                               // + the shader-clock counter at the two ends of the k-loop (slots 6, 7; tools/clock_probe.hip)
-#define W24_STAMP(k) if (threadIdx.x == 0) { g_w24time[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); \
+__device__ unsigned* g_w24id;                 // ... and where the block ran: XCC_ID << 16 | (HW_ID: CU 11:8, SH 12, SE 15:13)
+#define W24_WHERE() ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 16) | (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) & 0xFFFF))
+#define W24_STAMP(k) if (threadIdx.x == 0) { if ((k) == 0 && g_w24id) g_w24id[blockIdx.x] = W24_WHERE(); g_w24time[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); \
         if ((k) == 2) g_w24time[size_t(blockIdx.x) * 8 + 6] = clock64(); if ((k) == 3) g_w24time[size_t(blockIdx.x) * 8 + 7] = clock64(); }
 #else
 #define W24_STAMP(k)
@@ -58,6 +60,33 @@ constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image 
 #define W24S_GNB 1
 #include "s3d_wino24s_body.h"
 #undef W24S_GNB
+
+// ------------------------------------------------------------------ the LDS-DMA form: halo by buffer_load ... lds, persistent blocks
+// (see s3d_wino24g_body.h)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// One 1-KB LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at LDS byte lds_addr + 16 l (lds_addr wave-uniform).
+// M0 (the destination base) belongs to the compiler: saved and restored inside the statement.  Nothing here is visible to hipcc's
+// s_waitcnt bookkeeping: the caller retires the piece with a counted s_waitcnt vmcnt + a barrier before any lane reads it.
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+constexpr int G_SLOT = 12288;                                  // bytes of one ring slot: 12 DMA pieces (180 pixels x 64 B = 11 520 used)
+constexpr int G_GRED_FLOAT = 4 * G_SLOT / 4;                   // the GroupNorm cross-wave scratch behind the ring
+constexpr int G_SMEM_FLOATS = G_GRED_FLOAT + 256;
+#ifdef W24_TIMING
+#define W24G_STAMP(k) if (threadIdx.x == 0) { g_w24time[size_t(item) * 8 + (k)] = wall_clock64(); \
+        if ((k) == 2) g_w24time[size_t(item) * 8 + 6] = clock64(); if ((k) == 3) g_w24time[size_t(item) * 8 + 7] = clock64(); }
+#else
+#define W24G_STAMP(k)
+#endif
+#define W24G_GNB 0
+#include "s3d_wino24g_body.h"
+#undef W24G_GNB
+#define W24G_GNB 1
+#include "s3d_wino24g_body.h"
+#undef W24G_GNB
 
 // ------------------------------------------------------------------ the wide-block form: 64 output channels per block
 // VERDICT r3 item 1.  k_conv_wino24s repeats a pixel tile's halo fetch and B^T d B input transform in every one of its cout / 32
@@ -521,6 +550,34 @@ int launch_conv_wino24_wide(ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
+// k_conv_wino24g: at most three blocks per CU (a multiple of 8: whole XCD shares); more items than that -> persistent blocks
+static int glds_grid(int items) {
+    const int cap = (3 * conv_cus()) & ~7;
+    return items > cap && cap >= 8 ? cap : items;
+}
+int launch_conv_wino24_glds(ConvArgs& a, hipStream_t st) {
+    S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24g conv: bad arguments");
+    const int blocks = wino24s_layout(a, 32, "wino24g conv");
+    if (blocks < 0) return S3D_ERR_INVALID;
+    if (!blocks) return 0;
+    a.xcd_swizzle = 1 | 2;
+    conv_note_kernel("k_conv_wino24g mixed Winograd F(2x4,3x3), 8x16-pixel blocks, halo by LDS-DMA, persistent");
+    hipLaunchKernelGGL(k_conv_wino24g, dim3(glds_grid(blocks)), dim3(256), 0, st, a, blocks);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+int launch_conv_wino24_glds_gnb(ConvArgs& a, const GnbArgs& gb, hipStream_t st) {
+    S3D_CHECK(a.njobs == 3 && a.cin % C_KC == 0 && a.cout % 32 == 0 && gb.groups >= 1 && a.cout % gb.groups == 0, S3D_ERR_INVALID, "wino24g gnb conv: bad arguments");
+    const int blocks = wino24s_layout(a, 32, "wino24g gnb conv");
+    if (blocks < 0) return S3D_ERR_INVALID;
+    if (!blocks) return 0;
+    a.xcd_swizzle = 1 | 2;
+    conv_note_kernel("k_conv_wino24g_gnb mixed Winograd F(2x4,3x3) + GroupNorm-backward partial sums, halo by LDS-DMA, persistent");
+    hipLaunchKernelGGL(k_conv_wino24g_gnb, dim3(glds_grid(blocks)), dim3(256), 0, st, a, gb, blocks);
+    S3D_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_conv_wino24_narrow(ConvArgs& a, hipStream_t st) {
     S3D_CHECK(a.njobs >= 1 && a.njobs <= kMaxConvJobs && a.cin % C_KC == 0 && a.cout % 4 == 0, S3D_ERR_INVALID, "wino24s conv: bad arguments");
     const int blocks = wino24s_layout(a, 32, "wino24s conv");
@@ -547,8 +604,12 @@ int launch_conv_wino24_gnb(ConvArgs& a, const GnbArgs& gb, hipStream_t st) {
     return 0;
 }
 
+// S3D_WINO24G=1: every launch of the mixed Winograd kernel takes the LDS-DMA / persistent form (bit-identical; measured on par with
+// or behind the register-staged kernels on every shape: profiles/r06_wino_glds.txt — not a default).
 int launch_conv_wino24s(ConvArgs& a, hipStream_t st) {
-    if (a.gnb) return launch_conv_wino24_gnb(a, *a.gnb, st);
+    const bool glds = opt(OPT_WINO24G) == 1;
+    if (a.gnb) return glds ? launch_conv_wino24_glds_gnb(a, *a.gnb, st) : launch_conv_wino24_gnb(a, *a.gnb, st);
+    if (glds) return launch_conv_wino24_glds(a, st);
     return takes_wide(a) ? launch_conv_wino24_wide(a, st) : launch_conv_wino24_narrow(a, st);
 }
 

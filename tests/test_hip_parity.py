@@ -156,13 +156,16 @@ def _r1_forward(mc, B, hwd, seed, rank1_name=False):
     return ys[0].cpu().numpy(), model.profile_kernel(0)
 
 
-@pytest.mark.parametrize("switch,value,other,default", [("S3D_WINO24W", "1", "k_conv_wino24w", "k_conv_wino24s")])
+@pytest.mark.parametrize("switch,value,other,default", [("S3D_WINO24W", "1", "k_conv_wino24w", "k_conv_wino24s"),
+                                                        ("S3D_WINO24G", "1", "k_conv_wino24g", "k_conv_wino24")])
 def test_switched_conv_forms_are_bit_identical_and_reported(tmp_path, switch, value, other, default):
     """The two blockings of the mixed Winograd 3x3 kernel (TriplaneConv, unet_triplane.py:27-58) do the same arithmetic in the
     same order: k_conv_wino24w (8x16 pixels x 64 output channels per block, two n32 sub-blocks sharing one halo + input transform;
     S3D_WINO24W=1 forces it onto every launch whose cout is a multiple of 64) against k_conv_wino24s (x 32; S3D_WINO24W=0), each
     in its own process (the switch is read once).  Whole-UNet outputs are bit-identical — the convolution outputs AND the
-    GroupNorm partial sums their epilogues leave — repeated calls agree, and the library reports which kernel ran."""
+    GroupNorm partial sums their epilogues leave — repeated calls agree, and the library reports which kernel ran.
+    S3D_WINO24G=1: the LDS-DMA form (k_conv_wino24g: halo by buffer_load ... lds into a swizzled unpadded ring, persistent blocks when a
+    launch has more tiles than co-resident blocks — the last two cases) against the library's default choice, same bar."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -615,3 +615,36 @@ def test_groupnorm_backward_sums_from_the_dgrad_epilogue_agree_with_the_read_pas
             # (the gate of the golden-gradient tests; the FiLM / affine gradients ARE these sums, each a cancelling sum of thousands of terms)
             assert float((a - b).norm()) <= 2e-4 * scale, (mc, name, float((a - b).norm()), scale)
         assert not torch.equal(out[None][1], out[0][1]) or mc == 0          # (another summation order: not the same bits)
+
+
+def test_lds_dma_conv_form_gives_the_same_gradient_bits():
+    """S3D_WINO24G = 1: every mixed-Winograd launch of the training step — forward, input gradient, and the input gradient with the
+    GroupNorm-backward epilogue (k_conv_wino24g_gnb) — takes the LDS-DMA / persistent form (TriplaneConv forward and transpose,
+    src/diffusion/unet_triplane.py:27-58).  Same products and sums in the same order: losses and the whole flat gradient are the
+    same bits as with the default kernels, and the library names the kernel that ran."""
+    import torch
+    from sin3dm_amd import _lib
+    diffusion = _diffusion()
+    dev = torch.device("cuda:0")
+    for mc, (H, W, D), B, ssn in ((64, (48, 64, 40), 3, True), (32, (9, 13, 7), 2, False)):
+        x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 430)).clamp(-1, 1).to(dev)
+        noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 431)).to(dev)
+        t = torch.tensor([700, 3, 250][:B], device=dev)
+        w = torch.tensor([1.0, 0.5, 2.0][:B], device=dev)
+        kw = dict(H=H, W=W, D=D)
+        out = {}
+        try:
+            for mode in (None, 1):
+                _lib.set_option("WINO24G", mode)
+                m = _model(mc, ssn=ssn)
+                m.profile(1, classes=1)
+                terms, g = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                g = g.clone()
+                _, g2 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                assert torch.equal(g, g2), mode
+                m.profile_read()
+                out[mode] = (terms["loss"].clone(), g, m.profile_kernel(0))
+        finally:
+            _lib.set_option("WINO24G", None)
+        assert "k_conv_wino24g" in out[1][2] and "k_conv_wino24g" not in out[None][2], (out[None][2], out[1][2])
+        assert torch.equal(out[None][0], out[1][0]) and torch.equal(out[None][1], out[1][1]), mc

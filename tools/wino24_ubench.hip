@@ -9,12 +9,16 @@ namespace s3d { void set_error(const char*, ...) {} const char* get_error() { re
 #include "../sin3dm_amd/csrc/s3d_wino.hip"
 #include "../sin3dm_amd/csrc/s3d_wino24.hip"
 #include <chrono>
+#include <cstring>
+#include <map>
+#include <algorithm>
 #include <cstdlib>
 using namespace s3d;
 static double g_warm_s = 0.3;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 #ifdef W24_TIMING
 static unsigned long long* g_tb = nullptr;
+static unsigned* g_idb = nullptr;
 #endif
 static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     const size_t npix = size_t(3) * hw * hw * B;
@@ -28,11 +32,12 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     CK(hipMemcpy(wgt, hw_.data(), hw_.size() * 4, hipMemcpyHostToDevice));
     { std::vector<float> r(npix * cout); for (auto& v : r) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(res, r.data(), r.size() * 4, hipMemcpyHostToDevice));
       std::vector<float> t(size_t(B) * hw * 4 * cout); for (auto& v : t) v = float(rand()) / RAND_MAX - 0.5f; CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice)); }
-    const char* names[3] = {"wino4   F(2x2) 8x16 px x 32", "wino24s F(2x4) 8x16 px x 32", "wino24w F(2x4) 8x16 px x 64"};
-    const double frac[3] = {4.0 / 9, 1.0 / 3, 1.0 / 3};
+    const char* names[4] = {"wino4   F(2x2) 8x16 px x 32", "wino24s F(2x4) 8x16 px x 32", "wino24w F(2x4) 8x16 px x 64", "wino24g F(2x4) LDS-DMA persist"};
+    const double frac[4] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3};
     std::vector<float> ref_out;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 4; ++k) {
         if (k == 2 && cout % 64) continue;
+        if (getenv("UB_ONLY") && !strchr(getenv("UB_ONLY"), '0' + k) && k != 1) continue;
         ConvArgs a; memset(&a, 0, sizeof a);
         a.B = B; a.cin = cin; a.cout = cout; a.njobs = 3;
         for (int p = 0; p < 3; ++p) {
@@ -40,14 +45,19 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
             a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
             if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
         }
-        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24_narrow(a, 0) : launch_conv_wino24_wide(a, 0)); };
+        auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24_narrow(a, 0) : (k == 2 ? launch_conv_wino24_wide(a, 0) : launch_conv_wino24_glds(a, 0))); };
         if (k >= 1) {                // the wide form must reproduce k_conv_wino24s bit for bit
             CK(hipMemset(out, 0xFF, npix * cout * 4));
             launch(); CK(hipDeviceSynchronize());
             std::vector<float> o(npix * cout);
             CK(hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost));
             if (k == 1) ref_out.swap(o);
-            else printf("    wino24w vs wino24s: %s\n", memcmp(o.data(), ref_out.data(), o.size() * 4) == 0 ? "bit-identical" : "MISMATCH");
+            else {
+                size_t nbad = 0, first = 0;
+                for (size_t i = 0; i < o.size(); ++i) if (memcmp(&o[i], &ref_out[i], 4)) { if (!nbad) first = i; ++nbad; }
+                printf("    %s vs wino24s: %s", k == 2 ? "wino24w" : "wino24g", nbad ? "MISMATCH" : "bit-identical\n");
+                if (nbad) printf(" (%zu of %zu elements, first at %zu: %g vs %g)\n", nbad, o.size(), first, o[first], ref_out[first]);
+            }
         }
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         {   // steady state: the chip is power-limited under this kernel (profiles/r04_clock.txt) — measure after ~0.3 s of it, not on a cold ramp
@@ -74,13 +84,33 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
                 for (int q = 0; q < 5; ++q) ph[late][q] += (t[i * 8 + q + 1] - t[i * 8 + q]) * 0.01;
                 ++n[late];
             }
-            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : "wino24w", (t5 - t0) * 0.01);
+            if (k == 1 && getenv("UB_WHERE")) {   // where does a block's time depend on? per XCD and per CU durations of the launch's blocks
+                std::vector<unsigned> id(blocks);
+                CK(hipMemcpy(id.data(), g_idb, size_t(blocks) * 4, hipMemcpyDeviceToHost));
+                double xs[8] = {0}, xe[8] = {0}; int xn[8] = {0};
+                std::map<unsigned, std::vector<double>> cu;
+                for (int i = 0; i < blocks; ++i) {
+                    const int x = (id[i] >> 16) & 7; const double d = double(t[i * 8 + 5] - t[i * 8]) * 0.01;
+                    xs[x] += d; xe[x] = std::max(xe[x], double(t[i * 8 + 5] - t0) * 0.01); ++xn[x];
+                    cu[(id[i] >> 16 & 7) << 16 | (id[i] & 0xFF00)].push_back(d);
+                }
+                printf("    per XCD: block duration mean / last end:");
+                for (int x = 0; x < 8; ++x) printf("  [%d] %.1f / %.1f", x, xn[x] ? xs[x] / xn[x] : 0.0, xe[x]);
+                std::vector<double> cm;
+                for (auto& kv : cu) { double s_ = 0; for (double v : kv.second) s_ += v; cm.push_back(s_ / kv.second.size()); }
+                std::sort(cm.begin(), cm.end());
+                printf("\n    per CU (%zu CUs seen): mean block duration min %.1f  10%% %.1f  median %.1f  90%% %.1f  max %.1f us; blocks per CU min %zu max %zu\n", cm.size(), cm.front(), cm[cm.size() / 10],
+                       cm[cm.size() / 2], cm[cm.size() * 9 / 10], cm.back(),
+                       std::min_element(cu.begin(), cu.end(), [](auto& a, auto& b) { return a.second.size() < b.second.size(); })->second.size(),
+                       std::max_element(cu.begin(), cu.end(), [](auto& a, auto& b) { return a.second.size() < b.second.size(); })->second.size());
+            }
+            printf("    %s phases, span %.1f us:", k == 1 ? "wino24s" : (k == 2 ? "wino24w" : "wino24g"), (t5 - t0) * 0.01);
             for (int l = 0; l < 2; ++l)
                 if (n[l]) printf("  [%s %d blocks] halo->LDS %.1f | first operands %.1f | k-loop %.1f | barrier + share images + operand loads %.1f | finish + stores %.1f us",
                                  l ? "later" : "first-wave", n[l], ph[l][0] / n[l], ph[l][1] / n[l], ph[l][2] / n[l], ph[l][3] / n[l], ph[l][4] / n[l]);
             printf("\n");
             // a grid of ONE block per CU (and, wide form, exactly two): what a block's phases take when it has the CU's matrix pipe to itself
-            for (int per_cu = 1; per_cu <= (k == 2 ? 2 : 3); ++per_cu) {
+            for (int per_cu = 1; k != 3 && per_cu <= (k == 2 ? 2 : 3); ++per_cu) {
                 const int nb = 256 * per_cu;
                 if (nb > blocks) break;
                 CK(hipMemset(tb, 0, size_t(blocks) * 64));
@@ -104,6 +134,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
 int main(int argc, char** argv) {          // arguments: indices of the cases to run (default: all)
 #ifdef W24_TIMING
     CK(hipMalloc(&g_tb, size_t(1 << 16) * 64)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_w24time), &g_tb, sizeof g_tb));
+    CK(hipMalloc(&g_idb, size_t(1 << 16) * 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_w24id), &g_idb, sizeof g_idb));
 #endif
     if (getenv("UB_WARM_S")) g_warm_s = atof(getenv("UB_WARM_S"));
     const int NC = 19;
