@@ -41,7 +41,12 @@ __device__ unsigned long long* g_w24time;     // tools/wino24_ubench.hip: per-bl
                                               // + the shader-clock counter at the two ends of the k-loop (slots 6, 7; tools/clock_probe.hip)
 __device__ unsigned* g_w24id;                 // ... and where the block ran: XCC_ID << 16 | (HW_ID: CU 11:8, SH 12, SE 15:13)
 #define W24_WHERE() ((__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 16) | (__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) & 0xFFFF))
-#define W24_STAMP(k) if (threadIdx.x == 0) { if ((k) == 0 && g_w24id) g_w24id[blockIdx.x] = W24_WHERE(); g_w24time[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); \
+#ifdef W24_WHERE_ID                           // (its own build: the extra registers at a block's start make k_conv_wino24s spill, 1.5x slower)
+#define W24_NOTE_WHERE(k) if ((k) == 0 && g_w24id) g_w24id[blockIdx.x] = W24_WHERE();
+#else
+#define W24_NOTE_WHERE(k)
+#endif
+#define W24_STAMP(k) if (threadIdx.x == 0) { W24_NOTE_WHERE(k) g_w24time[size_t(blockIdx.x) * 8 + (k)] = wall_clock64(); \
         if ((k) == 2) g_w24time[size_t(blockIdx.x) * 8 + 6] = clock64(); if ((k) == 3) g_w24time[size_t(blockIdx.x) * 8 + 7] = clock64(); }
 #else
 #define W24_STAMP(k)

@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256, 3) void k_conv_wino24g(ConvArgs args, int tota
         lds_dma16(dst_ + 2048u, (GOFF)[2], DESC, unsigned(P) * 64u); }
 #define G_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
     // (the library shuffle's lane arithmetic is a loop invariant of the item loop — spilled across the k-loop; this one uses the item's opaque lane id)
-#define G_SHFL_XOR(v, off) __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((etid & 63) ^ (off)) << 2, __builtin_bit_cast(int, (v))))
+    // (a function of a float BY VALUE: __builtin_bit_cast applied to a vector-element lvalue reads element 0 whatever the index)
+    auto shfl_xor_f = [](float v, int lane_, int off) -> float {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane_ ^ off) << 2, __builtin_bit_cast(int, v)));
+    };
+#define G_SHFL_XOR(v, off) shfl_xor_f((v), etid & 63, (off))
 #define C_LDS4(off) (*static_cast<const f32x4*>(__builtin_assume_aligned(reinterpret_cast<const char*>(smem) + (off), 16)))
 #define C_PIN(v) asm volatile("" : "+v"(v))
 

@@ -1,6 +1,6 @@
 // Stand-alone timing of the 3x3 kernels on the network's layer shapes (tuning / profiles/r04_wino_ubench.txt):
 //   k_conv_wino4 (F(2x2), s3d_wino.hip), k_conv_wino24s and k_conv_wino24w (F(2x4), s3d_wino24.hip), random data, three square planes.
-//   -DW24_TIMING: per-block phase stamps; -DW24W_RING=N: weight-fragment ring depth of the wide kernel
+//   -DW24_TIMING: per-block phase stamps (+ -DW24_WHERE_ID and UB_WHERE=1: block durations per XCD / per CU — its own build, it slows k_conv_wino24s); -DW24W_RING=N: weight-fragment ring depth of the wide kernel
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino24_ubench.hip -o tools/ub_wino24
 #include "../sin3dm_amd/csrc/s3d_common.h"
 #include "ub_stubs.h"
@@ -35,6 +35,11 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
     const char* names[4] = {"wino4   F(2x2) 8x16 px x 32", "wino24s F(2x4) 8x16 px x 32", "wino24w F(2x4) 8x16 px x 64", "wino24g F(2x4) LDS-DMA persist"};
     const double frac[4] = {4.0 / 9, 1.0 / 3, 1.0 / 3, 1.0 / 3};
     std::vector<float> ref_out;
+    // GroupNorm partial records of the epilogue (one per tile and subgroup), compared bit for bit as well
+    const int tiles = ((hw + 7) / 8) * ((hw + 15) / 16), sg = cout >= 32 ? gn_subgroup(cout) : 1, nsub = cout / sg;
+    const size_t gn_n = size_t(B) * 3 * nsub * tiles * 2;
+    double* gn; CK(hipMalloc(&gn, gn_n * 8));
+    std::vector<double> ref_gn;
     for (int k = 0; k < 4; ++k) {
         if (k == 2 && cout % 64) continue;
         if (getenv("UB_ONLY") && !strchr(getenv("UB_ONLY"), '0' + k) && k != 1) continue;
@@ -44,11 +49,29 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
             a.job[p].in = in + size_t(p) * hw * hw * B * cin; a.job[p].wgt = wgt + p * wsz;
             a.job[p].out = out + size_t(p) * hw * hw * B * cout; a.job[p].h = hw; a.job[p].w = hw;
             if (extras) { a.job[p].res = res + size_t(p) * hw * hw * B * cout; a.job[p].rrow = tab; a.job[p].rcol = tab; }
+            if (extras && k >= 1) { a.job[p].gn_part = gn + size_t(p) * tiles * nsub * 2; a.gn_sg = sg; a.gn_nsub = nsub; a.gn_maxparts = tiles; }
         }
         auto launch = [&]() { return k == 0 ? launch_conv_wino(a, 0) : (k == 1 ? launch_conv_wino24_narrow(a, 0) : (k == 2 ? launch_conv_wino24_wide(a, 0) : launch_conv_wino24_glds(a, 0))); };
         if (k >= 1) {                // the wide form must reproduce k_conv_wino24s bit for bit
-            CK(hipMemset(out, 0xFF, npix * cout * 4));
+            CK(hipMemset(out, 0xFF, npix * cout * 4)); CK(hipMemset(gn, 0xFF, gn_n * 8));
             launch(); CK(hipDeviceSynchronize());
+            std::vector<double> og(gn_n); CK(hipMemcpy(og.data(), gn, gn_n * 8, hipMemcpyDeviceToHost));
+            if (k == 1) ref_gn = og;
+            else if (extras) {
+                size_t nb_ = 0, first_ = 0;
+                for (size_t i = 0; i < gn_n; ++i) if (memcmp(&og[i], &ref_gn[i], 8)) { if (!nb_) first_ = i; ++nb_; }
+                if (nb_) {
+                    printf("    GroupNorm partials MISMATCH: %zu of %zu doubles, first at %zu: %g vs %g\n", nb_, gn_n, first_, og[first_], ref_gn[first_]);
+                    std::vector<float> oo(npix * cout); CK(hipMemcpy(oo.data(), out, oo.size() * 4, hipMemcpyDeviceToHost));
+                    for (int sub = 0; sub < 3 && sub < nsub; ++sub) {          // plane 0, sample 0, tile 0: the sums from the output tensor itself
+                        double s1 = 0, s2 = 0;
+                        for (int y = 0; y < 8 && y < hw; ++y) for (int x = 0; x < 16 && x < hw; ++x) for (int c = sub * sg; c < (sub + 1) * sg; ++c) { const double v = oo[(size_t(y) * hw + x) * cout + c]; s1 += v; s2 += v * v; }
+                        const size_t at = (size_t(sub) * tiles + 0) * 2;
+                        printf("      tile 0 subgroup %d: from the output %g %g | this kernel %g %g | wino24s %g %g\n", sub, s1, s2, og[at], og[at + 1], ref_gn[at], ref_gn[at + 1]);
+                    }
+                }
+                else printf("    GroupNorm partials: bit-identical\n");
+            }
             std::vector<float> o(npix * cout);
             CK(hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost));
             if (k == 1) ref_out.swap(o);
@@ -129,7 +152,7 @@ static void run(int cin, int cout, int hw, int B, int iters, bool extras) {
         printf("%s cin=%4d cout=%4d hw=%3d B=%d extras=%d blocks=%5d: %8.1f us  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
                names[k], cin, cout, hw, B, extras, blocks, us, fl / us / 1e6, fl * frac[k] / us / 1e6, fl * frac[k] / us / 1e6 / 157.3);
     }
-    CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
+    CK(hipFree(gn)); CK(hipFree(in)); CK(hipFree(wgt)); CK(hipFree(out)); CK(hipFree(res)); CK(hipFree(tab));
 }
 int main(int argc, char** argv) {          // arguments: indices of the cases to run (default: all)
 #ifdef W24_TIMING
@@ -137,7 +160,7 @@ int main(int argc, char** argv) {          // arguments: indices of the cases to
     CK(hipMalloc(&g_idb, size_t(1 << 16) * 4)); CK(hipMemcpyToSymbol(HIP_SYMBOL(s3d::g_w24id), &g_idb, sizeof g_idb));
 #endif
     if (getenv("UB_WARM_S")) g_warm_s = atof(getenv("UB_WARM_S"));
-    const int NC = 19;
+    const int NC = 25;
     const int cases[NC][5] = {{128, 128, 128, 1, 20},     // 0 input_blocks.0 / output_blocks.1.0.out_layers.2
                               {128, 256, 64, 1, 20},      // 1 input_blocks.1.1.in_layers.2
                               {256, 256, 64, 1, 20},      // 2 the three half-resolution 256 -> 256 layers
@@ -148,7 +171,9 @@ int main(int argc, char** argv) {          // arguments: indices of the cases to
                               {128, 128, 128, 2, 10}, {128, 256, 64, 2, 10}, {256, 256, 64, 2, 10}, {384, 128, 128, 2, 10},     // 7-10 batch 2
                               {128, 128, 128, 4, 10}, {128, 256, 64, 4, 10}, {256, 256, 64, 4, 10}, {384, 128, 128, 4, 10},     // 11-14 batch 4
                               {128, 256, 64, 8, 5}, {384, 128, 128, 8, 5},                                                      // 15-16 the other two shapes at batch 8
-                              {64, 64, 96, 4, 10}, {64, 128, 48, 4, 10}};                                                      // 17-18 the training tier's widths (64-channel UNet, batch 4)
+                              {64, 64, 96, 4, 10}, {64, 128, 48, 4, 10},                                                       // 17-18 the training tier's widths (64-channel UNet, batch 4)
+                              {32, 32, 20, 2, 10}, {96, 32, 20, 2, 10}, {32, 64, 10, 3, 10}, {160, 96, 52, 2, 10},            // 19-22 two- and six-piece items, ragged planes, odd widths
+                              {64, 64, 200, 2, 5}, {96, 36, 100, 3, 5}};                                                      // 23-24 ... in persistent launches                                                      // 17-18 the training tier's widths (64-channel UNet, batch 4)
     for (int c = 0; c < NC; ++c) {
         bool on = argc < 2;
         for (int i = 1; i < argc; ++i) on |= atoi(argv[i]) == c;
