@@ -339,7 +339,7 @@ def measure_traffic_in_run(config):
             d = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "t", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--profile-every", "0",
-                   "--prewarm", "4", "--traffic", "off", "--chains", "0", "--config", config]
+                   "--prewarm", "4", "--traffic", "off", "--chains", "0", "--overlap", "off", "--config", config]
             env = dict(os.environ, TMPDIR=tmp)
             r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -364,6 +364,55 @@ def measure_traffic_in_run(config):
     return bytes_per_launch, ("measured_in_run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE children of this command (separate passes, "
                               "--kernel-trace only, 6 steps each), per-launch mean over the k_conv_wino24* launches, read side x2 "
                               f"(gfx950 FETCH_SIZE correction); the two passes took {time.time() - t_start:.1f} s before the benchmark touched the GPU")
+
+
+def measure_side_stream_overlap(config):
+    """--config c4: does the backward pass's side stream (weight gradients beside the input-gradient chain) really run beside it?
+    HIP maps streams onto a few hardware queues; a process whose side stream shares the main stream's queue loses the overlap
+    silently — performance, not bits.  A short fresh child of this script under `rocprofv3 --kernel-trace`
+    (no counters), started before this process touches the GPU: the fraction of the traced span with 0 / 1 / >= 2 kernels in
+    flight, the hardware queues seen, and the sum of the positive gaps of the busiest queue per step."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return {"error": "rocprofv3 not found"}
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {"error": "this process is itself being profiled"}
+    tmp = tempfile.mkdtemp(prefix="s3d_ovl_")
+    steps = 12
+    try:
+        cmd = ["rocprofv3", "--kernel-trace", "-d", tmp, "-o", "t", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "4", "--no-cpu-baseline", "--profile-every", "0",
+               "--prewarm", "8", "--traffic", "off", "--chains", "0", "--overlap", "off", "--config", config]
+        r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, text=True, timeout=300)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": f"rocprofv3 --kernel-trace child failed (rc {r.returncode}): {r.stderr[-200:]!r}"}
+        ev = sorted((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), row.get("Queue_Id", "?")) for f in files for row in csv.DictReader(open(f)))
+        ev = ev[len(ev) * 2 // 3:]                                  # the last third: the timed steps, not model construction / warm-up
+        span = ev[-1][1] - ev[0][0]
+        pts = sorted([(s, 1) for s, _, _ in ev] + [(e, -1) for _, e, _ in ev])
+        depth, last, hist = 0, pts[0][0], [0, 0, 0]
+        for t, d in pts:
+            hist[min(depth, 2)] += t - last
+            depth += d; last = t
+        queues = {}
+        for s_, e_, q in ev:
+            queues.setdefault(q, []).append((s_, e_))
+        main = max(queues.values(), key=lambda v: sum(e_ - s_ for s_, e_ in v))
+        gaps = sum(max(0, b[0] - a[1]) for a, b in zip(main, main[1:]))
+        return {"kernels_in_flight_0_frac": round(hist[0] / span, 4), "kernels_in_flight_1_frac": round(hist[1] / span, 4),
+                "kernels_in_flight_2_frac": round(hist[2] / span, 4), "hardware_queues_seen": len(queues),
+                "main_queue_gap_frac": round(gaps / span, 4), "kernels": len(ev), "span_ms": round(span / 1e6, 3),
+                "how": f"rocprofv3 --kernel-trace child of this command ({steps} steps, last third of its kernels), measured before this process touched the GPU; "
+                       "under the tracer the host issues kernels more slowly than in the timed region: the idle fraction is an upper bound"}
+    except Exception as e:                                          # never cost the benchmark line
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_chains(torch, model, diffusion, shape, kw, chains, rounds):
@@ -619,6 +668,7 @@ def worker(args):
             "f_dense_gflop_per_step": round(fd / 1e9, 2),
             "effective_dense_tflops": round(fd / (ms_step * 1e-3) / 1e12 * 1.0, 2),
             "roofline": roof, "chains2": chains2, "s3d_switches": switches,
+            "side_stream_overlap": getattr(args, "overlap_measured", None),
             "ranks": ranks, "per_rank_ms": [r["ms_per_step"] for r in ranks], "devices_verified_distinct": bool(verifiable) if world > 1 else None,
             "rccl_world_size": backend_world if dist_on else None, "dist_backend": backend if dist_on else None}
     if args.dry_run:
@@ -653,6 +703,9 @@ def main():
     ap.add_argument("--prewarm", type=int, default=PREWARM, help="untimed steps before --warmup (a fresh box needs them to reach steady clocks)")
     ap.add_argument("--traffic", choices=["auto", "off"], default="auto",
                     help="auto: measure roofline.traffic in this run with two rocprofv3 --pmc child passes (N = 1 only)")
+    ap.add_argument("--overlap", choices=["auto", "off"], default="auto",
+                    help="auto (--config c4, N = 1): report whether the backward pass's side stream overlaps the main chain (field `side_stream_overlap`, "
+                         "from a rocprofv3 --kernel-trace child of this command)")
     ap.add_argument("--chains", type=int, default=2, help="also report the c2 workload as this many independent chains in flight (field `chains2`; 0/1 = off)")
     ap.add_argument("--force-dist", action="store_true", help="create the RCCL process group even at --gpus 1: barrier / all-reduce / gather "
                     "(and --config c4's parameter broadcast + gradient all-reduce) execute at world size 1")
@@ -664,6 +717,8 @@ def main():
         return spawn_workers(args, sys.argv[1:])
     if args.traffic == "auto" and args.gpus == 1 and not args.dry_run and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not s3d_switches():
         args.traffic_measured = measure_traffic_in_run(args.config)       # BEFORE this process touches the GPU
+    if args.overlap == "auto" and args.config == "c4" and args.gpus == 1 and not args.dry_run and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        args.overlap_measured = measure_side_stream_overlap(args.config)
     return worker(args)
 
 

@@ -734,7 +734,7 @@ ORC_API int orc_has_param(const orc_params* pr, const char* name) { return has_p
  * environment: PARITY WITH IT IS UNPINNED.  The case table is generated by tools/gen_mc_tables.py; vertices are emitted
  * per cut edge in (axis, vertex index) order and triangles per cell in index order, which is also the device order.
  * ------------------------------------------------------------------------------------------------ */
-#include "../sin3dm_amd/csrc/s3d_mc_tables.h"
+#include "_gen/s3d_mc_tables.h"      /* generated by oracle/Makefile (tools/gen_mc_tables.py): the checker's own copy */
 static float mc_s(const float* v, int X, int Y, int Z, int stride, int pad, float padv, int x, int y, int z) {
     x -= pad; y -= pad; z -= pad;
     if (x < 0 || y < 0 || z < 0 || x >= X || y >= Y || z >= Z) return padv;

@@ -165,6 +165,11 @@ class GaussianDiffusion:
         to original indices, respace.py:123-128)."""
         return self._scale_timesteps(t)
 
+    def _model_timesteps_host(self, idx):
+        """_model_timesteps for indices known on the HOST (numpy int array) -> float32 numpy array, the same floats."""
+        v = np.asarray(idx).astype(np.float32)
+        return v * np.float32(1000.0 / self.num_timesteps) if self.rescale_timesteps else v
+
     def _noise(self, x):
         return th.randn_like(x) if self.noise_fn is None else self.noise_fn(x)
 
@@ -498,17 +503,20 @@ class GaussianDiffusion:
         terms["loss"] = terms["mse_xy"] + terms["mse_xz"] + terms["mse_yz"]
         return terms
 
-    def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None, grad_marks=None):
+    def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None, grad_marks=None,
+                                  t_model=None):
         """Fast path of TrainLoop.forward_backward (train_util.py:205-236) without an autograd graph:
         loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`).
         Torch launches nothing here besides the noise draw: the batch is read where it lies (an expanded triplane included),
         the per-sample loss — (xy + xz) + yz, the reference's order (:851) — is the fourth column of the terms kernel, the
-        weights / N of the mean are applied inside the gradient kernel."""
+        weights / N of the mean are applied inside the gradient kernel.
+        noise / t_model (float32 device tensor = _model_timesteps(t)): handed in by a caller that prepared them ahead of the step
+        (TrainLoop draws step k + 1's inputs while step k's backward runs) — then no torch kernel is launched here at all."""
         if noise is None:
             noise = th.randn(x_start.shape, device=x_start.device, dtype=th.float32)
         H, W, D = (int(model_kwargs[k]) for k in "HWD")
         x_t = self.q_sample_hip(x_start, t, noise)
-        out = model.forward_train(x_t, self._model_timesteps(t), H, W, D)
+        out = model.forward_train(x_t, self._model_timesteps(t) if t_model is None else t_model, H, W, D)
         target = self._training_target(x_start, x_t, t, noise)
         mse = _mse_terms(out, target, H, W, D)                                          # [N, 4]
         wgt = weights.to(out.device, th.float32).contiguous()                            # [N]

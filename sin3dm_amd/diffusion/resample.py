@@ -19,14 +19,21 @@ def create_named_schedule_sampler(name, diffusion):
 
 
 class ScheduleSampler:
+    # True: the draw for step k + 1 does not depend on step k's losses — TrainLoop may make it (and upload it) while step k runs
+    prefetchable = False
+
     def weights(self):
         raise NotImplementedError
 
-    def sample(self, batch_size, device):
+    def sample_host(self, batch_size):
+        """(timesteps int64 [B], importance weights float64 [B]) as numpy arrays: the reference's draw (resample.py:33-48)."""
         w = self.weights()
         p = w / np.sum(w)
         idx = np.random.choice(len(p), size=(batch_size,), p=p)
-        weights = 1 / (len(p) * p[idx])
+        return idx, 1 / (len(p) * p[idx])
+
+    def sample(self, batch_size, device):
+        idx, weights = self.sample_host(batch_size)
         t, w = th.from_numpy(idx).long(), th.from_numpy(weights).float()
         if th.device(device).type == "cuda":
             # pinned + non_blocking: a pageable host-to-device copy would drain the GPU queue in every training step
@@ -35,6 +42,8 @@ class ScheduleSampler:
 
 
 class UniformSampler(ScheduleSampler):
+    prefetchable = True
+
     def __init__(self, diffusion):
         self.diffusion = diffusion
         self._weights = np.ones([diffusion.num_timesteps])

@@ -91,6 +91,11 @@ class SpacedDiffusion(GaussianDiffusion):
         ts = m[t]
         return ts * (1000.0 / self.original_num_steps) if self.rescale_timesteps else ts
 
+    def _model_timesteps_host(self, idx):
+        """The same floats for indices known on the host (numpy): the map lookup and the fp32 x fp32 scaling of _mapped."""
+        v = np.asarray(self.timestep_map, dtype=np.float32)[np.asarray(idx)]
+        return v * np.float32(1000.0 / self.original_num_steps) if self.rescale_timesteps else v
+
 
 class _WrappedModel:
     """Maps respaced indices back to original ones before calling the denoiser (:116-128)."""

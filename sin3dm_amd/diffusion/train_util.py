@@ -124,6 +124,10 @@ class TrainLoop:
         # until a multi-GPU RCCL run has compared both.
         self.overlap_allreduce = os.environ.get("S3D_OVERLAP_ALLREDUCE", "0") == "1"
         self._marks = self._comm = self._groups = self._staging = None
+        # Step inputs drawn AHEAD (S3D_PREFETCH_INPUTS=0: at the start of their step, as the reference): see _draw_inputs
+        self.prefetch_inputs = os.environ.get("S3D_PREFETCH_INPUTS", "1") != "0"
+        self._next_inputs = None
+        self._stage = None
 
     # ------------------------------------------------------------------ resume
     def _load_optimizer_and_ema(self):
@@ -159,10 +163,51 @@ class TrainLoop:
         self._anneal_lr()
         self.log_step()
 
+    # ------------------------------------------------------------------ step inputs
+    _STAGE_RING = 4
+
+    def _draw_inputs(self, shape, dev):
+        """One step's random inputs, with as little on the GPU's critical path as possible: timesteps (int64), the model's
+        timestep values (float32: the timestep_map lookup + scaling done on the host) and the importance weights travel in ONE
+        pinned staging row and one asynchronous copy — instead of two copies, a gather and a cast launched at the start of the
+        step — and the noise is drawn with them.  Same values as the reference order (np.random for the timesteps, the device
+        generator for the noise: each generator is still consumed once per step, in step order)."""
+        B = int(shape[0])
+        idx, w = self.schedule_sampler.sample_host(B)
+        if self._stage is None or self._stage["B"] != B or self._stage["dev"] != dev:
+            host = th.empty((self._STAGE_RING, 16 * B), dtype=th.uint8).pin_memory()
+            self._stage = {"B": B, "dev": dev, "host": host, "dev_rows": th.empty((self._STAGE_RING, 16 * B), dtype=th.uint8, device=dev),
+                           "events": [None] * self._STAGE_RING, "k": 0}
+        st = self._stage
+        k = st["k"]; st["k"] = (k + 1) % self._STAGE_RING
+        if st["events"][k] is not None:
+            st["events"][k].synchronize()                 # (the copy of four draws ago: long complete)
+        row = st["host"][k]
+        row[:8 * B].view(th.int64).copy_(th.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)))
+        row[8 * B:12 * B].view(th.float32).copy_(th.from_numpy(np.ascontiguousarray(self.diffusion._model_timesteps_host(idx), dtype=np.float32)))
+        row[12 * B:].view(th.float32).copy_(th.from_numpy(np.ascontiguousarray(w, dtype=np.float32)))
+        drow = st["dev_rows"][k]
+        drow.copy_(row, non_blocking=True)
+        ev = th.cuda.Event(); ev.record(); st["events"][k] = ev
+        noise = th.randn(tuple(shape), device=dev, dtype=th.float32)
+        return {"shape": tuple(shape), "t": drow[:8 * B].view(th.int64), "t_model": drow[8 * B:12 * B].view(th.float32),
+                "weights": drow[12 * B:].view(th.float32), "noise": noise}
+
     def forward_backward(self, batch, cond):
         dev = self.model.flat_parameters.device
         micro = batch.to(dev)
-        t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
+        ahead = (self.prefetch_inputs and micro.is_cuda and getattr(self.schedule_sampler, "prefetchable", False)
+                 and hasattr(self.diffusion, "_model_timesteps_host"))
+        extra = {}
+        if ahead:
+            inp = self._next_inputs
+            if inp is None or inp["shape"] != tuple(micro.shape):
+                inp = self._draw_inputs(micro.shape, dev)
+            self._next_inputs = None
+            t, weights = inp["t"], inp["weights"]
+            extra = {"noise": inp["noise"], "t_model": inp["t_model"]}
+        else:
+            t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
         if self.dist_on and self.overlap_allreduce:
             # loss = mean over the GLOBAL batch.  The backward pass fills the flat gradient from the output blocks towards
             # the input; the groups that are final early are all-reduced on a communication stream while the rest of it
@@ -175,11 +220,16 @@ class TrainLoop:
                     self._marks = [th.cuda.Event(), th.cuda.Event()]
                     self._comm = th.cuda.Stream(device=dev)
             losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad,
-                                                                    grad_marks=self._marks)
+                                                                    grad_marks=self._marks, **extra)
             parallel.average_flat_groups_(grad, self._groups, self._marks, self._comm, staging=self._staging)
         else:
-            losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad)
+            losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad, **extra)
             parallel.average_flat_(grad)                  # one all-reduce of the whole flat vector per step
+        if ahead:
+            # the next step's inputs, enqueued behind this step's backward pass: by the time the GPU gets to them the host is a
+            # whole backward pass ahead, and the next step starts with its first UNet kernels instead of 114 us of launch gaps
+            # around four small torch kernels (profiles/r05_train_timeline.txt)
+            self._next_inputs = self._draw_inputs(micro.shape, dev)
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
         if self.step % 10 == 0:

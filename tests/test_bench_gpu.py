@@ -45,6 +45,11 @@ def test_bench_line_contract_and_live_roofline(config, launches_per_step, kernel
         assert d["chains2"] is None
         w = r["wgrad3x3"]                                               # the 3x3 weight-gradient launches: eight per training step
         assert w["launches_timed"] == 4 * 8 and "k_wgrad_wino" in w["kernel"] and 0.02 < w["frac"] < 1.0
+        # the side stream's overlap, from the line's own trace child: a lost hardware queue would show as kernels_in_flight_2_frac ~ 0
+        o = d["side_stream_overlap"]
+        assert "error" not in o, o
+        assert abs(o["kernels_in_flight_0_frac"] + o["kernels_in_flight_1_frac"] + o["kernels_in_flight_2_frac"] - 1.0) < 1e-3
+        assert o["hardware_queues_seen"] >= 2 and o["kernels_in_flight_2_frac"] > 0.05, o
 
 
 def test_bench_chains_can_be_switched_off():

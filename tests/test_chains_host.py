@@ -113,3 +113,17 @@ def test_sample_cli_chain_count_rule(monkeypatch):
     assert sample_chains(8, 1) == 1
     monkeypatch.setenv("S3D_SAMPLE_CHAINS", "4")
     assert sample_chains(8, 8) == 4 and sample_chains(3, 1) == 3
+
+
+def test_model_timesteps_for_host_known_indices_are_the_device_path_floats():
+    """TrainLoop uploads the denoiser's timestep values computed on the HOST (_model_timesteps_host: the timestep_map lookup and the
+    fp32 scaling of respace.py:123-128) instead of gathering them on the device in every step: bit-equal to _model_timesteps."""
+    import numpy as np
+    import torch
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    for kw in (dict(), dict(rescale_timesteps=True), dict(timestep_respacing="100"), dict(timestep_respacing="ddim50", rescale_timesteps=True)):
+        d = create_gaussian_diffusion(steps=1000, predict_xstart=True, **kw)
+        idx = np.array([0, 1, d.num_timesteps // 3, d.num_timesteps - 1, 5], dtype=np.int64)
+        dev_path = d._model_timesteps(torch.from_numpy(idx)).float().numpy()
+        host = d._model_timesteps_host(idx)
+        assert host.dtype == np.float32 and np.array_equal(host, dev_path), kw

@@ -648,3 +648,45 @@ def test_lds_dma_conv_form_gives_the_same_gradient_bits():
             _lib.set_option("WINO24G", None)
         assert "k_conv_wino24g" in out[1][2] and "k_conv_wino24g" not in out[None][2], (out[None][2], out[1][2])
         assert torch.equal(out[None][0], out[1][0]) and torch.equal(out[None][1], out[1][1]), mc
+
+
+def test_step_inputs_drawn_ahead_give_the_same_training_run():
+    """TrainLoop draws step k + 1's timesteps, importance weights and noise while step k's backward pass runs (one pinned staging
+    row + one asynchronous copy, the timestep_map lookup done on the host; src/diffusion/train_util.py:198-232,
+    resample.py:33-48, respace.py:93-96).  Each generator is still consumed once per step in step order: four run_steps end with
+    the same parameter and EMA bits as with every input drawn at the start of its own step (S3D_PREFETCH_INPUTS=0), for the plain
+    and for a respaced + rescaled diffusion (whose model timesteps are map[t] * 1000 / T)."""
+    import os
+    import torch
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    from sin3dm_amd.diffusion.train_util import TrainLoop
+    dev = torch.device("cuda:0")
+    H, W, D = 20, 28, 12
+    x0 = torch.from_numpy(T.synthetic_noise((12, H + D, W + D), 400)).clamp(-1, 1).to(dev)
+    batch, cond = x0.unsqueeze(0).expand(3, -1, -1, -1), dict(H=H, W=W, D=D)
+
+    def data():
+        while True:
+            yield batch, cond
+
+    for dkw in (dict(), dict(timestep_respacing="250", rescale_timesteps=True)):
+        ends = {}
+        for mode in ("0", "1"):
+            os.environ["S3D_PREFETCH_INPUTS"] = mode
+            try:
+                torch.manual_seed(77); np.random.seed(77)
+                m = _model(32)
+                loop = TrainLoop(model=m, diffusion=create_gaussian_diffusion(steps=1000, predict_xstart=True, **dkw), data=data(),
+                                 batch_size=3, microbatch=-1, lr=1e-3, ema_rate="0.99", log_interval=10 ** 9, save_interval=10 ** 9,
+                                 resume_checkpoint=False, lr_anneal_steps=10, log_dir=None)
+                assert loop.prefetch_inputs == (mode == "1")
+                for _ in range(4):
+                    loop.run_step(batch, cond)
+                    loop.step += 1
+                torch.cuda.synchronize()
+                assert (loop._next_inputs is not None) == (mode == "1")
+                ends[mode] = (m.flat_parameters.clone(), loop.opt.ema[0].clone())
+            finally:
+                os.environ.pop("S3D_PREFETCH_INPUTS", None)
+        assert torch.isfinite(ends["0"][0]).all()
+        assert torch.equal(ends["0"][0], ends["1"][0]) and torch.equal(ends["0"][1], ends["1"][1]), dkw

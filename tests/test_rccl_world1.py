@@ -165,7 +165,7 @@ def test_rccl_world1_trainloop_exchange_on_off_and_no_group_same_bits(tmp_path):
 def _bench(*extra):
     env = {k: v for k, v in os.environ.items() if k not in _STRIP}
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--prewarm", "20",
-                        "--profile-every", "0", "--no-cpu-baseline", "--traffic", "off", "--chains", "0", *extra],
+                        "--profile-every", "0", "--no-cpu-baseline", "--traffic", "off", "--chains", "0", "--overlap", "off", *extra],
                        cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

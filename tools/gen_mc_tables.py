@@ -109,7 +109,11 @@ def main():
     # complementary cases cut the same edges
     for c in range(256):
         assert sorted(set(e for t in table[c] for e in t)) == sorted(set(e for t in table[255 - c] for e in t))
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sin3dm_amd", "csrc", "s3d_mc_tables.h")
+    import sys
+    # default: the product's table; with a path argument: another copy (oracle/Makefile builds the CHECKER's own, so that the C
+    # oracle never reads a file of the product tree)
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sin3dm_amd", "csrc", "s3d_mc_tables.h")
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     with open(out, "w") as f:
         f.write("// Generated by tools/gen_mc_tables.py (constructed from first principles, see there). Do not edit.\n")
         f.write("// Corner c = (c&1, (c>>1)&1, (c>>2)&1); edge e joins corners MC_EDGE[e][0..1] along axis MC_EDGE_AXIS[e].\n")
