@@ -60,6 +60,9 @@ S3D_API int s3d_abi_version(void);
  *                 auto-encoder's two nets as two chains)                                                     (bit-identical)
  *   GNB_FUSED     0: the GroupNorm backward's two per-channel sums always from its own read pass (default: from the epilogue of
  *                 the input-gradient convolution in front of it where that is the mixed Winograd kernel)     (rounding differs)
+ *   EDGE_SIGNAL   how the backward pass's side stream learns that the edge sums are done: 1 an event on the launch's own completion
+ *                 signal (default outside profilers), 0 a plain event record behind it (default under rocprofv3, whose tracing
+ *                 makes the first form crawl); committed traces state which form they ran                    (bit-identical)
  * s3d_get_option: the current value, -1 when unset. */
 S3D_API int s3d_set_option(const char* name, const char* value);
 S3D_API int s3d_get_option(const char* name, int* value);

@@ -408,6 +408,12 @@ __global__ __launch_bounds__(256) void k_wgrad_mfma(WgArgs args) {
 constexpr int WW_TH = 8, WW_TW = 16, WW_HH = WW_TH + 2, WW_HW = WW_TW + 2, WW_LD = 36;
 struct WgwJob { const float* dy; const float* a; float* part; int h, w, tiles_x, regions; int block_begin; };
 struct WgwArgs { WgwJob job[3]; int B, cin, cout, a_cstride, ksplit, n_co, n_ci, njobs; };
+#ifdef WGW_TIMING
+__device__ unsigned long long* g_wgwtime;   // tools/wgrad_ubench.hip: per block {entry, exit, sum over regions of (operands in LDS - request), sum of (last MFMA issued - operands in LDS)}, 10-ns ticks
+#define WGW_NOW() wall_clock64()
+#else
+#define WGW_NOW() 0ull
+#endif
 __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
     __shared__ __attribute__((aligned(16))) float sx[WW_HH * WW_HW * WW_LD];
     __shared__ __attribute__((aligned(16))) float sdy[WW_TH * WW_TW * WW_LD];
@@ -484,13 +490,18 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
         for (int x = 0; x < 2; ++x) { o.d0[x] = pd[x * WW_LD]; o.d1[x] = pd[(WW_TW + x) * WW_LD]; }
     };
     // (measured and dropped: starting the CU's three blocks a third of a region period apart with s_sleep — 60 us against 57)
+    const unsigned long long wt_entry = WGW_NOW();
+    unsigned long long wt_stage = 0, wt_mfma = 0;
+    (void)wt_entry;
     for (long long rr = r_begin; rr < r_end; ++rr) {
+        const unsigned long long wt0 = WGW_NOW();
         // no register prefetch of the next region (40 VGPRs that made the allocator spill): with three blocks per CU the
         // other waves of the SIMD keep the matrix pipe busy while this one waits for its loads
         load_region(rr);
         __syncthreads();                                  // everyone is done with the previous region
         store_region();
         __syncthreads();
+        const unsigned long long wt1 = WGW_NOW();
         Ops cur, nxt;
         lds_step(0, cur);
 #pragma unroll
@@ -510,7 +521,11 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
         }
+        wt_stage += wt1 - wt0; wt_mfma += WGW_NOW() - wt1;
     }
+#ifdef WGW_TIMING
+    const unsigned long long wt_loop_end = WGW_NOW();
+#endif
     // dg = G^T dU G of THIS slice before it leaves the block (9 values per channel pair instead of 16: the partials are what
     // this launch writes and the reduce kernel reads — 50 MB each way at 768 blocks, a fifth of the two kernels' time).
     // Column pass in registers (v: 4 -> 3, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]); row pass across the four waves
@@ -539,6 +554,12 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
             dst[0] = t0 + (h1 + h2); dst[tap_stride] = h1 - h2; dst[2 * tap_stride] = (h1 + h2) + t3;
         }
     }
+#ifdef WGW_TIMING
+    if (tid == 0 && g_wgwtime) {
+        unsigned long long* o = g_wgwtime + size_t(blockIdx.x) * 8;
+        o[0] = wt_entry; o[1] = WGW_NOW(); o[2] = wt_stage; o[3] = wt_mfma; o[4] = wt_loop_end; o[5] = (unsigned long long)(r_end - r_begin);
+    }
+#endif
 }
 // adds the slices' dg in slice order and scatters to OIHW
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };

@@ -90,7 +90,7 @@ int upload(DevBuf& dst, const void* host, size_t bytes);
 // S3D_<NAME> (read once, at the first query of that option); before that the default (kOptUnset for the choices the library
 // makes by launch size).  Queries are a table read: cheap enough for every launch.
 enum Opt { OPT_WINO = 0, OPT_WINO24W, OPT_VCAT, OPT_WGRAD_WINO, OPT_RANK1_SLICES, OPT_RANK1_BATCH, OPT_CONV_IMPL, OPT_CONV1X1_T,
-           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_GNB_FUSED, OPT_WINO24G, OPT_COUNT };
+           OPT_GN_FUSED, OPT_BWD_SIDE, OPT_GNB_FUSED, OPT_WINO24G, OPT_EDGE_SIGNAL, OPT_COUNT };
 constexpr int kOptUnset = -1;
 int opt(Opt o);                       // kOptUnset when neither set nor in the environment
 inline bool opt_on(Opt o) { return opt(o) != 0; }      // switches that default to on: anything but an explicit 0

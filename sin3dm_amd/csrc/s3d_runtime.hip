@@ -35,7 +35,7 @@ int upload(DevBuf& dst, const void* host, size_t bytes) {
 // ---- options
 struct OptDef { const char* name; bool is_impl; };
 static const OptDef kOpts[OPT_COUNT] = {{"WINO", false}, {"WINO24W", false}, {"VCAT", false}, {"WGRAD_WINO", false}, {"RANK1_SLICES", false},
-                                        {"RANK1_BATCH", false}, {"CONV_IMPL", true}, {"CONV1X1_T", false}, {"GN_FUSED", false}, {"BWD_SIDE", false}, {"GNB_FUSED", false}, {"WINO24G", false}};
+                                        {"RANK1_BATCH", false}, {"CONV_IMPL", true}, {"CONV1X1_T", false}, {"GN_FUSED", false}, {"BWD_SIDE", false}, {"GNB_FUSED", false}, {"WINO24G", false}, {"EDGE_SIGNAL", false}};
 static std::atomic<int> g_opt[OPT_COUNT];
 static std::atomic<int> g_opt_state[OPT_COUNT];          // 0: not looked at yet, 1: resolved (environment or unset), 2: set through the ABI
 static int parse_opt(int o, const char* v) { return kOpts[o].is_impl ? (strcmp(v, "naive") == 0 ? 1 : 0) : atoi(v); }

@@ -133,8 +133,11 @@ struct Bwd {
             // the side stream waits for the edge sums (and dy before them): the event rides on the launch's own completion signal
             // — a hipEventRecord behind it is a barrier packet of its own in front of the chain's next kernel (2.867 -> 2.850 ms/step)
             // (under rocprofv3 an event on a dispatch's completion signal makes the waiting queue crawl — a traced step took 3.8 ms
-            // instead of 2.9 —: a plain record there, so that traces keep their shape)
-            static const bool traced = getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROFILER_LIBRARY_CTOR");
+            // instead of 2.9 —: a plain record there, so that traces keep their shape.  Option EDGE_SIGNAL: 1 / 0 force either form,
+            // unset = plain under a profiler's environment, on-signal otherwise; profiles/r06_train_* name the form they traced.)
+            static const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("HSA_TOOLS_LIB") || getenv("ROCPROFILER_LIBRARY_CTOR");
+            const int edge_opt = opt(OPT_EDGE_SIGNAL);
+            const bool traced = edge_opt == kOptUnset ? profiled : edge_opt == 0;
             if (traced && st != sw) {
                 S3D_TRY(launch_edge_sums(dy, B, R, Cs, st));
                 S3D_TRY(edge(st, sw));

@@ -413,7 +413,13 @@ class GaussianDiffusion:
         next_run = 0
         active = {}
         results = {}
+        # the chains share the denoiser's ONE packed weight image: parameters must stay frozen while more than one is in flight
+        stamp_of = getattr(model, "parameter_stamp", None) if nch > 1 else None
+        stamp0 = stamp_of() if stamp_of is not None else None
         while next_run < n_runs or active:
+            if stamp0 is not None and stamp_of() != stamp0:
+                raise RuntimeError("sample_loop_chains: the denoiser's parameters changed while several chains were in flight "
+                                   "(they share one packed weight image; a repack is ordered on ONE chain's stream only)")
             for c in range(nch):
                 if c not in active:
                     if next_run >= n_runs:

@@ -158,8 +158,18 @@ class _TriplaneUNetBase(nn.Module):
         _lib.check(lib.s3d_unet_select_lane(self._handle, k))
         self._lane = k
 
+    def parameter_stamp(self):
+        """What _ensure_handle compares to decide that the packed weight image is stale.  Chains in flight on several lanes share
+        that image and only the issuing lane's stream would see a repack: GaussianDiffusion.sample_loop_chains_progressive
+        snapshots this at its start and fails loudly if it moves before the last chain has finished."""
+        if self._plist is None:
+            named = dict(self.named_parameters())
+            self._plist = [named[n] for n in self._param_names]
+        return (tuple(p._version for p in self._plist), bool(self._flat_dirty))
+
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)      # .to(), .cuda(), .float(): the parameter storage moves
+        self._lane = 0                                  # (a handle created after this starts on lane 0)
         self._film_cache = {}
         self._film_sched = None
         self._synced = None
@@ -359,7 +369,8 @@ class _TriplaneUNetBase(nn.Module):
         with th.cuda.device(t.device):
             _lib.check(lib.s3d_unet_film(self._handle, _lib.ptr(t), len(values), _lib.ptr(film), _lib.stream_ptr()))
         # tables are produced on the stream that is current NOW; a later forward on another stream waits for this event
-        # (s3d_unet_film's scratch is shared per handle: calls on one handle are expected to be issued from one stream at a time)
+        # (s3d_unet_film's scratch exists once per workspace LANE: calls on one lane are expected to be issued from one stream at a
+        # time; chains on different lanes need no edge between them — but they share ONE packed weight image: see parameter_stamp)
         mark = self._film_mark(t.device)
         for k, v in enumerate(values):
             self._film_cache[(dkey, v)] = (film[k:k + 1], mark)

@@ -153,6 +153,6 @@ def test_options_through_the_abi_and_environment_fallback():
                        env={k: v for k, v in os.environ.items() if not k.startswith("S3D_")})
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
     names = re.findall(r"^ \*   ([A-Z][A-Z0-9_]+)  ", open(os.path.join(REPO, "include", "sin3dm_hip.h")).read(), flags=re.M)
-    assert len(names) == 12                                  # every documented option exists
+    assert len(names) == 13                                  # every documented option exists
     for n in names:
         _lib.get_option(n)

@@ -127,3 +127,23 @@ def test_model_timesteps_for_host_known_indices_are_the_device_path_floats():
         dev_path = d._model_timesteps(torch.from_numpy(idx)).float().numpy()
         host = d._model_timesteps_host(idx)
         assert host.dtype == np.float32 and np.array_equal(host, dev_path), kw
+
+
+def test_chains_fail_loudly_when_the_shared_weights_change_mid_run():
+    """Chains on several lanes share the denoiser's ONE packed weight image; a repack would be ordered on one chain's stream only
+    (ADVICE r5).  The loop snapshots model.parameter_stamp() and raises as soon as it moves while chains are in flight."""
+    import pytest
+    diff = create_gaussian_diffusion(steps=1000)
+    log = []
+    fake_loops(diff, log, steps=4)
+    m = FakeModel()
+    m.stamp = 0
+    m.parameter_stamp = lambda: m.stamp
+    it = diff.sample_loop_chains_progressive(m, (1, 2), 2, chains=2, generators=[1, 2], device="cpu", streams=fake_streams(2))
+    next(it)
+    m.stamp = 1                                        # an optimizer step / load_state_dict between two rounds
+    with pytest.raises(RuntimeError, match="parameters changed"):
+        next(it)
+    # one chain at a time: nothing is shared, nothing is checked
+    it = diff.sample_loop_chains_progressive(m, (1, 2), 2, chains=1, generators=[1, 2], device="cpu")
+    next(it); m.stamp = 2; next(it)
