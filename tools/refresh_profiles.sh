@@ -1,8 +1,8 @@
 #!/bin/bash
 # Regenerate the measured artefacts behind DESIGN.md on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r05'
+#   gpurun --timeout 2400 -- 'tools/refresh_profiles.sh r06'
 # Everything lands in gpurun_out/refresh/ as <round>_*; copy what should be judged into profiles/.
-R=${1:-r05}
+R=${1:-r06}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh
 mkdir -p $OUT
@@ -66,4 +66,32 @@ python3 $ROOT/tools/trace_timeline.py $(find /tmp/p7 -name "*kernel_trace.csv" |
 rm -rf /tmp/p8 && S3D_BWD_SIDE=0 rocprofv3 --kernel-trace --stats -d /tmp/p8 -o t --output-format csv -- python3 $ROOT/tools/bench_train.py --steps 20 --warmup 3 > /tmp/p8.log 2>&1
 { echo "S3D_BWD_SIDE=0 (every launch on one stream: per-kernel times without sharing the chip)"; grep "^{" /tmp/p8.log | cut -c1-220; python3 $ROOT/tools/prof_summary.py $(find /tmp/p8 -name "*kernel_trace.csv" | head -1) 23; } > $OUT/${R}_train_kernel_summary_inline.txt
 cd $ROOT
+# 9. RCCL at world size 1: the same command with and without a forced process group, c4 (every step then contains
+#    a real RCCL all-reduce of the 28-MB flat gradient + the start broadcast) and c2 (barrier / MAX all-reduce / object gather only)
+{ echo "# bench.py --gpus 1 [--force-dist]: ms_per_step, rccl_world_size, dist_backend (same box, alternating)";
+  for rep in 1 2; do for F in "" "--force-dist"; do for C in c4 c2; do
+    python3 bench.py --gpus 1 --config $C $F --steps $([ $C == c4 ] && echo 200 || echo 300) --warmup 10 --no-cpu-baseline --traffic off --overlap off --chains 0 --profile-every 0 2>/dev/null | tail -1 |
+      python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$C', '${F:-no process group}', 'ms_per_step', round(d['ms_per_step'],4), 'rccl_world_size', d['rccl_world_size'], 'dist_backend', d['dist_backend'])"
+  done; done; done; } > $OUT/${R}_rccl_world1.txt
+# 10. the 3x3 weight-gradient kernel alone: time, per-region stamps, SQ counters
+[ -x tools/ub_wgrad ] && timeout 300 tools/ub_wgrad > $OUT/${R}_wgrad_ubench.txt 2>&1
+[ -x tools/ub_wgrad_t ] && timeout 300 tools/ub_wgrad_t 2>&1 | cut -c1-420 > $OUT/${R}_wgrad_phases.txt
+if [ -x tools/ub_wgrad ]; then
+  cd /tmp && rm -rf /tmp/p10 && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d /tmp/p10 -o t --output-format csv -- $ROOT/tools/ub_wgrad > /tmp/p10.log 2>&1
+  { echo "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -- tools/ub_wgrad (all six shapes together)";
+    python3 $ROOT/tools/pmc_sq_summary.py $(find /tmp/p10 -name "*counter_collection.csv" | head -1); } > $OUT/${R}_wgrad_pmc.txt
+  rm -rf /tmp/p11 && rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace -d /tmp/p11 -o t --output-format csv -- $ROOT/tools/ub_wgrad > /tmp/p11.log 2>&1
+  python3 - $(find /tmp/p11 -name "*counter_collection.csv" | head -1) >> $OUT/${R}_wgrad_pmc.txt <<'PY'
+import collections, csv, sys
+agg = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Kernel_Name"].replace("s3d::", "").replace("void ", "").split("(")[0][:70]
+    agg.setdefault(n, collections.Counter())[r["Counter_Name"]] += float(r["Counter_Value"])
+print("LDS bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE):")
+for n, c in agg.items():
+    if c["SQ_LDS_IDX_ACTIVE"] > 0:
+        print(f"  {n:60s} {c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']:.3f}")
+PY
+  cd $ROOT
+fi
 ls -la $OUT
