@@ -687,6 +687,11 @@ def worker(args):
                 line["over_eager_gpu"] = round(value / line["eager_gpu_baseline"]["value"], 2)
             except Exception as e:
                 line["eager_gpu_baseline"] = {"error": repr(e)}
+    try:                                       # (RCCL writes its version banner to the C stdout, flushed at exit: keep the JSON line the LAST line)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(line), flush=True)
     return 0
 

@@ -50,7 +50,8 @@ S3D_API int s3d_abi_version(void);
  *   WINO24G       1: the mixed Winograd kernel with its halo staged by LDS-DMA and persistent blocks (default: off — measured on
  *                 par with or behind the register-staged kernels, profiles/r06_wino_glds.txt)                (bit-identical)
  *   VCAT          0: materialise upsample + concat in the output blocks (default: virtual concat)            (rounding differs)
- *   WGRAD_WINO    0: direct 3x3 weight gradient (default: Winograd)                                          (rounding differs)
+ *   WGRAD_WINO    0: direct 3x3 weight gradient (rounding differs) | default (1): Winograd F(2x2) | 2: the same with the operands of
+ *                 half regions double-buffered by LDS-DMA (measured slower, profiles/r06_wgrad.txt)         (1, 2: bit-identical)
  *   RANK1_SLICES  0: one K slice of the rollout tables (default: two from 256 channels)                      (rounding differs)
  *   RANK1_BATCH   0: k_rank1, one sample per block (default: k_rank1b / two-sample blocks)                   (bit-identical)
  *   CONV_IMPL     "naive": one-thread-per-output reference kernels (tests)                                   (rounding differs)

@@ -561,6 +561,150 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_wino(WgwArgs args) {
     }
 #endif
 }
+// ------------------------------------------------------------------ k_wgrad_wino with its operands staged by LDS-DMA (round 6)
+// profiles/r06_wgrad.txt: a region of k_wgrad_wino is request -> wait -> LDS store -> barrier (1.8 us, nothing of this block on the
+// matrix pipe) followed by 16 MFMA steps (4.9 us with the SIMD's three waves taking turns) — 0.77 of the pipe inside the loop.
+// Here a region is cut into its two HALVES of tile rows (steps 0..7 / 8..15 of the same step order: the SAME products are added in
+// the SAME order — bit-identical partials), each half has its own LDS buffer (6 halo rows + 4 dy rows, 23.5 KB; the two together are
+// what one region took before), and half h + 1 arrives by LDS-DMA (buffer_load ... lds: no staging registers — the 40 that a
+// register prefetch needs made the allocator spill —, no ds_write pass) while half h is multiplied.  The kernel has no other
+// vector-memory traffic in its loop, so retiring a half is a plain vmcnt(0) + the barrier that also frees the other buffer.
+// LDS image (lane-linear per DMA instruction, so no padding): pixel slot of halo column hx = 2 hx (hx < 8), 2 (hx - 8) + 1
+// (8 <= hx < 16), 16 / 18 (hx = 16 / 17) in rows of 20 slots — the two lane halves of a ds_read_b32 take tiles 8 pixels apart, and
+// slots of opposite parity put their 128-byte rows on the two halves of the 64 banks; dy columns likewise (x < 8: 2 x, else 2 (x - 8) + 1).
+constexpr int WD_XROWS = 6, WD_XSLOTS = 20, WD_DYROWS = 4, WD_DYSLOTS = 16;
+constexpr int WD_X_FLOATS = WD_XROWS * WD_XSLOTS * 32, WD_DY_FLOATS = WD_DYROWS * WD_DYSLOTS * 32, WD_HALF_FLOATS = WD_X_FLOATS + WD_DY_FLOATS;
+constexpr int WD_X_INSTR = WD_XROWS * WD_XSLOTS / 8, WD_DY_INSTR = WD_DYROWS * WD_DYSLOTS / 8, WD_INSTR = WD_X_INSTR + WD_DY_INSTR;     // 15 + 8 DMA instructions of 1 KB
+__global__ __launch_bounds__(256, 3) void k_wgrad_wino_dma(WgwArgs args) {
+    __shared__ __attribute__((aligned(16))) float sm[2 * WD_HALF_FLOATS];           // 47 104 B: two half-region buffers; the epilogue's 16-KB scratch afterwards
+    static_assert(2 * WD_HALF_FLOATS >= 4 * 16 * 64, "row-pass scratch");
+    int p = 0;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) p += (k < args.njobs && int(blockIdx.x) >= args.job[k].block_begin) ? 1 : 0;
+    const WgwJob& J = args.job[p];
+    int local = blockIdx.x - J.block_begin;
+    const int ks = local % args.ksplit; local /= args.ksplit;
+    const int tci = local % args.n_ci, tco = local / args.n_ci;
+    const int co0 = tco * 32, ci0 = tci * 32;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, half = lane >> 5;
+    const int u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xrow = u == 0 ? 0 : (u == 2 ? 2 : 1), yrow = u == 2 ? 1 : (u == 3 ? 3 : 2);
+    const float sgn = u == 1 ? 1.f : -1.f;
+    const float c0 = u == 3 ? 0.f : 1.f, c1 = u == 0 ? 0.f : (u == 1 ? 1.f : -1.f);
+    f32x16 acc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+    const long long total = (long long)J.regions * args.B;
+    const long long r_begin = total * ks / args.ksplit, r_end = total * (ks + 1) / args.ksplit;
+    const int n_halves = int(r_end - r_begin) * 2;
+    const unsigned lds0 = unsigned(size_t((__attribute__((address_space(3))) float*)sm));
+    // request half hidx (region r_begin + hidx / 2, tile rows 2 (hidx & 1) .. + 1) into buffer hidx & 1: wave u issues DMA instructions u, u + 4, ...
+    auto request_half = [&](int hidx) {
+        const long long rr = r_begin + (hidx >> 1);
+        const int hh = hidx & 1;
+        const int b = int(rr / J.regions), reg = int(rr % J.regions);
+        const int ty0 = (reg / J.tiles_x) * WW_TH, tx0 = (reg % J.tiles_x) * WW_TW;
+        const i32x4 da = lds_dma_desc(J.a + size_t(b) * J.h * J.w * args.a_cstride, unsigned(J.h) * unsigned(J.w) * unsigned(args.a_cstride) * 4u);
+        const i32x4 dd = lds_dma_desc(J.dy + size_t(b) * J.h * J.w * args.cout, unsigned(J.h) * unsigned(J.w) * unsigned(args.cout) * 4u);
+        const unsigned buf = lds0 + unsigned((hidx & 1) * WD_HALF_FLOATS * 4);
+#pragma unroll
+        for (int k = 0; k < (WD_INSTR + 3) / 4; ++k) {
+            const int n = u + 4 * k;                                  // wave-uniform
+            if (n >= WD_INSTR) break;
+            const int slot = 8 * (n < WD_X_INSTR ? n : n - WD_X_INSTR) + (lane >> 3), q = lane & 7;
+            unsigned off;
+            if (n < WD_X_INSTR) {
+                const int row = slot / WD_XSLOTS, s = slot - row * WD_XSLOTS, kk = s >> 1;
+                const int hx = (s & 1) ? (kk < 8 ? 8 + kk : -1) : (kk < 8 ? kk : 8 + kk);          // slots 17, 19: nothing
+                const int gy = ty0 - 1 + 4 * hh + row, gx = tx0 - 1 + hx;
+                const bool ok = hx >= 0 && gy >= 0 && gy < J.h && gx >= 0 && gx < J.w;
+                off = ok ? unsigned((gy * J.w + gx) * args.a_cstride + ci0 + q * 4) * 4u : 0x80000000u;
+                lds_dma16(buf + unsigned(n * 1024), off, da, 0u);
+            } else {
+                const int row = slot / WD_DYSLOTS, s = slot - row * WD_DYSLOTS;
+                const int xx = (s & 1) ? 8 + (s >> 1) : (s >> 1);
+                const int y = ty0 + 4 * hh + row, x = tx0 + xx;
+                const bool ok = y < J.h && x < J.w;
+                off = ok ? unsigned((y * J.w + x) * args.cout + co0 + q * 4) * 4u : 0x80000000u;
+                lds_dma16(buf + unsigned(WD_X_FLOATS * 4 + (n - WD_X_INSTR) * 1024), off, dd, 0u);
+            }
+        }
+    };
+    struct Ops { float x[4], y[4], d0[2], d1[2]; };
+    // operands of MFMA step st (0..7 within a half: tile row st >> 2, tile columns (st & 3) + 4 * lane half) from buffer `base`
+    // Every read is one of two per-lane bases + a compile-time offset: columns hx0 < 8 sit at slot 2 hx0 + (lane half), i.e. at float
+    // 64 hx0 + lane of their row; columns 8 / 9 (the last tile column's third and fourth patch column) at slot 1 / 3 for lane half 0
+    // and 16 / 18 for lane half 1.
+    const int lb = lane, lb2 = half ? i + 16 * 32 : i + 32;
+    auto lds_step = [&](const float* base, int st, Ops& o) {
+        const int trl = st >> 2, t4 = st & 3;
+        const float* sxb = base;
+        const float* sdb = base + WD_X_FLOATS;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int hx0 = 2 * t4 + b;                               // the column of lane half 0; half 1: hx0 + 8
+            const int col = hx0 < 8 ? lb + 64 * hx0 : lb2 + 64 * (hx0 - 8);
+            o.x[b] = sxb[(2 * trl + xrow) * WD_XSLOTS * 32 + col];
+            o.y[b] = sxb[(2 * trl + yrow) * WD_XSLOTS * 32 + col];
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int col = lb + 64 * (2 * t4 + x);                   // column 2 t4 + x (+ 8 for lane half 1): slot 2 (2 t4 + x) + half
+            o.d0[x] = sdb[(2 * trl) * WD_DYSLOTS * 32 + col];
+            o.d1[x] = sdb[(2 * trl + 1) * WD_DYSLOTS * 32 + col];
+        }
+    };
+    if (n_halves > 0) request_half(0);
+    for (int hidx = 0; hidx < n_halves; ++hidx) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of half hidx have landed (nothing else is in flight)
+        __syncthreads();                                    // ... everyone's have, and everyone is done with the other buffer
+        if (hidx + 1 < n_halves) request_half(hidx + 1);
+        const float* base = sm + (hidx & 1) * WD_HALF_FLOATS;
+        Ops cur, nxt;
+        lds_step(base, 0, cur);
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            if (st + 1 < 8) lds_step(base, st + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            float t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[b] = fmaf(sgn, cur.y[b], cur.x[b]);
+            const float V[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+            const float r0 = c0 * cur.d0[0] + c1 * cur.d1[0], r1 = c0 * cur.d0[1] + c1 * cur.d1[1];
+            const float M[4] = {r0, r0 + r1, r0 - r1, -r1};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] = __builtin_amdgcn_mfma_f32_32x32x2f32(M[v], V[v], acc[v], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    }
+    // dg = G^T dU G of this slice: k_wgrad_wino's epilogue, verbatim
+    float* red = sm;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float h1 = 0.5f * acc[1][r], h2 = 0.5f * acc[2][r];
+            const float t = j == 0 ? acc[0][r] + (h1 + h2) : (j == 1 ? h1 - h2 : (h1 + h2) + acc[3][r]);
+            red[(u * 16 + r) * 64 + lane] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = u * 4 + rr;
+            const float t0 = red[(0 * 16 + r) * 64 + lane], t1 = red[(1 * 16 + r) * 64 + lane];
+            const float t2 = red[(2 * 16 + r) * 64 + lane], t3 = red[(3 * 16 + r) * 64 + lane];
+            const float h1 = 0.5f * t1, h2 = 0.5f * t2;
+            const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* dst = J.part + ((size_t(ks) * 9 + j) * args.cout + co) * args.cin + ci0 + i;
+            const size_t tap_stride = size_t(3) * args.cout * args.cin;
+            dst[0] = t0 + (h1 + h2); dst[tap_stride] = h1 - h2; dst[2 * tap_stride] = (h1 + h2) + t3;
+        }
+    }
+}
 // adds the slices' dg in slice order and scatters to OIHW
 struct WgwRedArgs { const float* part[3]; float* dW[3]; int ksplit, cout, cin, ctot, cin_store; };
 template <class Args>                                    // WgwRedArgs, or the WgRedArgs of a batched job (same fields)
@@ -724,7 +868,11 @@ int launch_wgrad(const WgradArgs& w, hipStream_t st, DeferredTail* tail) {
             blocks += a.n_co * a.n_ci * a.ksplit;
         }
         if (!blocks || !w.B) return 0;
-        hipLaunchKernelGGL(k_wgrad_wino, dim3(blocks), dim3(256), 0, st, a);
+        // WGRAD_WINO = 2: operands by LDS-DMA, half regions double-buffered (bit-identical; measured 6-7 % SLOWER than the
+        // register-staged kernel on every shape, profiles/r06_wgrad.txt: the launch is bound by the operand traffic, and the halves'
+        // shared halo rows add a fifth to it) — not the default
+        if (opt(OPT_WGRAD_WINO) == 2) hipLaunchKernelGGL(k_wgrad_wino_dma, dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(k_wgrad_wino, dim3(blocks), dim3(256), 0, st, a);
         S3D_HIP(hipGetLastError());
         if (tail) { queue_reduce(*tail, w, 1); return 0; }
         WgwRedArgs r;

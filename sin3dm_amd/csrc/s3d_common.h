@@ -97,6 +97,25 @@ inline bool opt_on(Opt o) { return opt(o) != 0; }      // switches that default 
 // compute units of the CURRENT device (cached per device index: one process may drive several)
 int device_cus();
 
+// ------------------------------------------------------------------ LDS-DMA (device code only)
+#if defined(__HIPCC__)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// One 1-KB LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at LDS byte lds_addr + 16 l (lds_addr wave-uniform);
+// an out-of-range offset (bit 31) lands as ZEROS, exec-masked lanes write nothing (tools/glds_probe.hip).
+// M0 (the destination base) belongs to the compiler: saved and restored inside the statement.  Nothing here is visible to hipcc's
+// s_waitcnt bookkeeping: the caller retires the piece with its own s_waitcnt vmcnt + a barrier before any lane reads it.
+__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// buffer descriptor of `bytes` bytes at p (raw dword addressing, out-of-range reads return 0)
+__device__ __forceinline__ i32x4 lds_dma_desc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return i32x4{int(unsigned(a)), int(unsigned(a >> 32) & 0xFFFF), int(bytes), 0x00020000};
+}
+#endif
+
 // ------------------------------------------------------------------ plane geometry
 // The three planes of a triplane: xy[H,W], xz[H,D], yz[W,D]  (src/utils/triplane_util.py:20-25)
 struct Geo {

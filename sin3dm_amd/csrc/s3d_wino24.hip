@@ -68,15 +68,6 @@ constexpr int C_IMG = (C_TH / 2) * C_TW * 32;                // one share image 
 
 // ------------------------------------------------------------------ the LDS-DMA form: halo by buffer_load ... lds, persistent blocks
 // (see s3d_wino24g_body.h)
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-// One 1-KB LDS-DMA piece: lane l's 16 bytes at buffer offset voff + soff land at LDS byte lds_addr + 16 l (lds_addr wave-uniform).
-// M0 (the destination base) belongs to the compiler: saved and restored inside the statement.  Nothing here is visible to hipcc's
-// s_waitcnt bookkeeping: the caller retires the piece with a counted s_waitcnt vmcnt + a barrier before any lane reads it.
-__device__ __forceinline__ void lds_dma16(unsigned lds_addr, unsigned voff, i32x4 rsrc, unsigned soff) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
 constexpr int G_SLOT = 12288;                                  // bytes of one ring slot: 12 DMA pieces (180 pixels x 64 B = 11 520 used)
 constexpr int G_GRED_FLOAT = 4 * G_SLOT / 4;                   // the GroupNorm cross-wave scratch behind the ring
 constexpr int G_SMEM_FLOATS = G_GRED_FLOAT + 256;

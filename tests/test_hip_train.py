@@ -690,3 +690,34 @@ def test_step_inputs_drawn_ahead_give_the_same_training_run():
                 os.environ.pop("S3D_PREFETCH_INPUTS", None)
         assert torch.isfinite(ends["0"][0]).all()
         assert torch.equal(ends["0"][0], ends["1"][0]) and torch.equal(ends["0"][1], ends["1"][1]), dkw
+
+
+def test_weight_gradient_operands_by_lds_dma_give_the_same_gradient_bits():
+    """The 3x3 weight gradient (the transpose of TriplaneConv's dense part in the own channels, src/diffusion/unet_triplane.py:27-58) on
+    k_wgrad_wino_dma (WGRAD_WINO = 2: half regions double-buffered in LDS, filled by buffer_load ... lds while the previous half is
+    multiplied; round 6, measured slower and not the default) against k_wgrad_wino (load -> registers -> ds_write, one region at a time): the same
+    products added in the same order, so the whole flat gradient is the same bits; ragged planes and a 96-channel layer (three
+    32-channel tiles) included."""
+    import torch
+    from sin3dm_amd import _lib
+    diffusion = _diffusion()
+    dev = torch.device("cuda:0")
+    for mc, (H, W, D), B in ((64, (48, 64, 40), 3), (32, (9, 13, 7), 2), (32, (20, 28, 12), 2)):
+        x0 = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 440)).clamp(-1, 1).to(dev)
+        noise = torch.from_numpy(T.synthetic_noise((B, 12, H + D, W + D), 441)).to(dev)
+        t = torch.tensor([700, 3, 250][:B], device=dev)
+        w = torch.tensor([1.0, 0.5, 2.0][:B], device=dev)
+        kw = dict(H=H, W=W, D=D)
+        out = {}
+        try:
+            for mode in (None, 2):
+                _lib.set_option("WGRAD_WINO", mode)
+                m = _model(mc)
+                _, g = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                g = g.clone()
+                _, g2 = diffusion.training_losses_and_grads(m, x0, t, w, kw, noise=noise)
+                assert torch.equal(g, g2), mode
+                out[mode] = g
+        finally:
+            _lib.set_option("WGRAD_WINO", None)
+        assert torch.isfinite(out[None]).all() and torch.equal(out[None], out[2]), (mc, float((out[None] - out[2]).abs().max()))

@@ -70,7 +70,7 @@ cd $ROOT
 #    a real RCCL all-reduce of the 28-MB flat gradient + the start broadcast) and c2 (barrier / MAX all-reduce / object gather only)
 { echo "# bench.py --gpus 1 [--force-dist]: ms_per_step, rccl_world_size, dist_backend (same box, alternating)";
   for rep in 1 2; do for F in "" "--force-dist"; do for C in c4 c2; do
-    python3 bench.py --gpus 1 --config $C $F --steps $([ $C == c4 ] && echo 200 || echo 300) --warmup 10 --no-cpu-baseline --traffic off --overlap off --chains 0 --profile-every 0 2>/dev/null | tail -1 |
+    python3 bench.py --gpus 1 --config $C $F --steps $([ $C == c4 ] && echo 200 || echo 300) --warmup 10 --no-cpu-baseline --traffic off --overlap off --chains 0 --profile-every 0 2>/dev/null | grep "^{" | tail -1 |
       python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$C', '${F:-no process group}', 'ms_per_step', round(d['ms_per_step'],4), 'rccl_world_size', d['rccl_world_size'], 'dist_backend', d['dist_backend'])"
   done; done; done; } > $OUT/${R}_rccl_world1.txt
 # 10. the 3x3 weight-gradient kernel alone: time, per-region stamps, SQ counters

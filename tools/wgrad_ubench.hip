@@ -33,6 +33,17 @@ static void run(int cin, int cout, int H, int W, int D, int B, int iters) {
         w.part[p] = part + p * pf; w.dW[p] = dW + size_t(p) * cout * cin * 9;
     }
     auto launch = [&]() { return launch_wgrad(w, 0, nullptr); };
+    std::vector<float> ref;
+    for (int mode = 2; mode >= 1; --mode) {              // 2: k_wgrad_wino (register staging, the default), 1: k_wgrad_wino_dma
+    setenv("S3D_WGRAD_WINO", mode == 2 ? "1" : "2", 1);
+    {
+        CK(hipMemset(dW, 0xFF, size_t(3) * cout * cin * 9 * 4));
+        launch(); CK(hipDeviceSynchronize());
+        std::vector<float> o(size_t(3) * cout * cin * 9);
+        CK(hipMemcpy(o.data(), dW, o.size() * 4, hipMemcpyDeviceToHost));
+        if (mode == 2) ref.swap(o);
+        else printf("    k_wgrad_wino_dma vs k_wgrad_wino: %s\n", memcmp(o.data(), ref.data(), o.size() * 4) == 0 ? "bit-identical" : "MISMATCH");
+    }
     const auto w0 = std::chrono::steady_clock::now();
     do { for (int i = 0; i < 10; ++i) launch(); CK(hipDeviceSynchronize()); } while (std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count() < 0.3);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -42,10 +53,10 @@ static void run(int cin, int cout, int H, int W, int D, int B, int iters) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / iters, fl = 2.0 * 9 * cin * cout * double(npix);
     const int blocks = 3 * (cout / 32) * (cin / 32) * w.ksplit;
-    printf("wgrad 3x3 Winograd F(2x2) cin=%4d cout=%4d planes (%d,%d,%d) B=%d ksplit=%3d blocks=%5d: %7.1f us (kernel + reduction)  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
-           cin, cout, H, W, D, B, w.ksplit, blocks, us, fl / us / 1e6, fl * 4 / 9 / us / 1e6, fl * 4 / 9 / us / 1e6 / 157.3);
+    printf("%s cin=%4d cout=%4d planes (%d,%d,%d) B=%d ksplit=%3d blocks=%5d: %7.1f us (kernel + reduction)  direct-equiv %6.1f TF  executed %6.1f TF (%.3f of 157.3)\n",
+           mode == 2 ? "k_wgrad_wino     3x3 Winograd F(2x2)" : "k_wgrad_wino_dma 3x3 Winograd F(2x2)", cin, cout, H, W, D, B, w.ksplit, blocks, us, fl / us / 1e6, fl * 4 / 9 / us / 1e6, fl * 4 / 9 / us / 1e6 / 157.3);
 #ifdef WGW_TIMING
-    {
+    if (mode == 2) {
         launch(); CK(hipDeviceSynchronize());
         std::vector<unsigned long long> t(size_t(blocks) * 8);
         CK(hipMemcpy(t.data(), g_tb, t.size() * 8, hipMemcpyDeviceToHost));
@@ -63,6 +74,7 @@ static void run(int cin, int cout, int H, int W, int D, int B, int iters) {
                (t1 - t0) * 0.01, regions / blocks, dur / blocks, pre / blocks, stage / regions, mfma / regions, mf_region, 3 * mf_region, post / blocks);
     }
 #endif
+    }
     CK(hipFree(a)); CK(hipFree(dy)); CK(hipFree(part)); CK(hipFree(dW));
 }
 int main(int argc, char** argv) {
