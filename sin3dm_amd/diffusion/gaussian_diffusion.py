@@ -510,19 +510,23 @@ class GaussianDiffusion:
         return terms
 
     def training_losses_and_grads(self, model, x_start, t, weights, model_kwargs, noise=None, grad_out=None, grad_marks=None,
-                                  t_model=None):
+                                  t_model=None, after_forward=None):
         """Fast path of TrainLoop.forward_backward (train_util.py:205-236) without an autograd graph:
         loss = (terms["loss"] * weights).mean(); returns (terms, flat gradient vector of `model.flat_parameters`).
         Torch launches nothing here besides the noise draw: the batch is read where it lies (an expanded triplane included),
         the per-sample loss — (xy + xz) + yz, the reference's order (:851) — is the fourth column of the terms kernel, the
         weights / N of the mean are applied inside the gradient kernel.
         noise / t_model (float32 device tensor = _model_timesteps(t)): handed in by a caller that prepared them ahead of the step
-        (TrainLoop draws step k + 1's inputs while step k's backward runs) — then no torch kernel is launched here at all."""
+        (TrainLoop draws step k + 1's inputs during step k) — then no torch kernel is launched here at all.
+        after_forward: called once the forward pass is enqueued and before the backward pass is — the place where a caller's small
+        launches cost nothing: the host is a whole forward pass ahead of the GPU there, at neither end of the step."""
         if noise is None:
             noise = th.randn(x_start.shape, device=x_start.device, dtype=th.float32)
         H, W, D = (int(model_kwargs[k]) for k in "HWD")
         x_t = self.q_sample_hip(x_start, t, noise)
         out = model.forward_train(x_t, self._model_timesteps(t) if t_model is None else t_model, H, W, D)
+        if after_forward is not None:
+            after_forward()
         target = self._training_target(x_start, x_t, t, noise)
         mse = _mse_terms(out, target, H, W, D)                                          # [N, 4]
         wgt = weights.to(out.device, th.float32).contiguous()                            # [N]

@@ -205,7 +205,14 @@ class TrainLoop:
                 inp = self._draw_inputs(micro.shape, dev)
             self._next_inputs = None
             t, weights = inp["t"], inp["weights"]
-            extra = {"noise": inp["noise"], "t_model": inp["t_model"]}
+
+            def draw_next():
+                # the next step's inputs, enqueued between this step's forward and backward pass: the host is a whole forward pass
+                # ahead of the GPU there, so the two small launches (one copy, one randn) open no gap — at the end of the step they sat
+                # between the last weight-gradient reduction and the optimizer kernel, at its start (round 5) around four torch
+                # kernels with 114 us of launch gaps (profiles/r05_train_timeline.txt)
+                self._next_inputs = self._draw_inputs(micro.shape, dev)
+            extra = {"noise": inp["noise"], "t_model": inp["t_model"], "after_forward": draw_next}
         else:
             t, weights = self.schedule_sampler.sample(micro.shape[0], dev)
         if self.dist_on and self.overlap_allreduce:
@@ -225,10 +232,7 @@ class TrainLoop:
         else:
             losses, grad = self.diffusion.training_losses_and_grads(self.model, micro, t, weights, cond, grad_out=self._grad, **extra)
             parallel.average_flat_(grad)                  # one all-reduce of the whole flat vector per step
-        if ahead:
-            # the next step's inputs, enqueued behind this step's backward pass: by the time the GPU gets to them the host is a
-            # whole backward pass ahead, and the next step starts with its first UNet kernels instead of 114 us of launch gaps
-            # around four small torch kernels (profiles/r05_train_timeline.txt)
+        if ahead and self._next_inputs is None:           # (a diffusion object without the hook)
             self._next_inputs = self._draw_inputs(micro.shape, dev)
         if isinstance(self.schedule_sampler, LossAwareSampler):
             self.schedule_sampler.update_with_local_losses(t, losses["loss"].detach())
