@@ -198,6 +198,19 @@ S3D_API int s3d_sampler_step(const s3d_sampler_args* a, void* stream);
  * ignored).  Same arithmetic in the same order as s3d_unet_forward_film followed by s3d_sampler_step: identical bits. */
 S3D_API int s3d_unet_step_film(s3d_unet* m, const float* film, int film_stride, int B, int H, int W, int D,
                        const s3d_sampler_args* step, float* model_out, void* stream);
+/* The same step when the caller knows what follows it (round 6; SURVEY.md section 2b lists K8 + K9 + K2 as one fusion).  in_conv is
+ * TriplaneConv(in_channels, ch, 1, padding=0, is_rollout=False) (src/diffusion/unet_triplane.py:378, applied first thing in forward,
+ * :482): a pointwise map of x_t with no timestep in it.  In a sampling loop the next step's x_t is this step's sample (:533-534), so
+ *   - S3D_CARRY_OUT: the output head also evaluates the NEXT step's in_conv (+ its GroupNorm partial sums) on the x_{t-1} values it has
+ *                  just formed and leaves it in the lane's workspace — same products, same order, same thread mapping as the in_conv
+ *                  kernel: the same bits;
+ *   - S3D_CARRY_IN: the caller vouches that step->x is the previous step's sample, UNMODIFIED since that call: its in_conv launch is
+ *                  skipped when the previous call on this lane was an S3D_CARRY_OUT step of the same shape whose sample is step->x and
+ *                  nothing (another forward, a parameter change, a workspace reallocation) came between; otherwise the flag is ignored.
+ * carry_flags = 0 is s3d_unet_step_film.  Results are identical bits either way (tests/test_hip_parity.py). */
+enum { S3D_CARRY_OUT = 1, S3D_CARRY_IN = 2 };
+S3D_API int s3d_unet_step_film_carry(s3d_unet* m, const float* film, int film_stride, int B, int H, int W, int D,
+                       const s3d_sampler_args* step, float* model_out, void* stream, int carry_flags);
 
 /* ------------------------------------------------------------------------------------------
  * Leaf operators, exported so the parity tests can pin each kernel to the reference op it replaces

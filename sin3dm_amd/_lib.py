@@ -16,7 +16,9 @@ c_i64p = C.POINTER(C.c_int64)
 
 ABI_VERSION = 4
 TAB_ROWS = ("sqrt_recip", "sqrt_recipm1", "coef1", "coef2", "logvar", "acp", "acp_prev")
+CARRY_OUT, CARRY_IN = 1, 2          # s3d_unet_step_film_carry flags
 STEP_DDPM, STEP_DDIM, STEP_MEAN_ONLY = 0, 1, 2
+CARRY_OUT, CARRY_IN = 1, 2               # s3d_unet_step_film_carry flags (include/sin3dm_hip.h)
 MEAN_START_X, MEAN_EPSILON = 0, 1
 ERR_INVALID, ERR_MISSING, ERR_HIP, ERR_UNSUPPORTED = -1, -2, -3, -4
 MAX_LANES = 16
@@ -81,6 +83,8 @@ SIGNATURES = {
     "s3d_sampler_step": (C.c_int, [C.POINTER(SamplerArgs), C.c_void_p]),
     "s3d_unet_step_film": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(SamplerArgs), C.c_void_p, C.c_void_p]),
+    "s3d_unet_step_film_carry": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(SamplerArgs), C.c_void_p, C.c_void_p, C.c_int]),
     "s3d_op_triplane_conv": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.c_void_p]),

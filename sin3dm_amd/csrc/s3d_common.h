@@ -342,9 +342,14 @@ int launch_copy_slice(const float* in, int B, int C, int h, int w, float* out, i
 // out head: GN + SiLU + 1x1 conv (C -> Cout small) + compose into NCHW [B,Cout,H+D,W+D] with zero corner
 // fuse != null: + the sampler update of the step on the model output (in the same launch when out_head_fuses_sampler(); then
 // `out` may be null and the model output is never stored)
+// carry (fused steps only): the head also evaluates the NEXT step's in_conv — TriplaneConv(in, ch, 1, is_rollout =
+// False), a pointwise map of x_{t-1}, unet_triplane.py:378, 482 — on the x_{t-1} values it has just formed, with k_in_conv_lds's
+// arithmetic, thread mapping and GroupNorm-partial order (same bits), into the workspace tensors the next forward will read
+struct InConvCarry { const float* wT; const float* bias; float* out[3]; double* part; int maxparts, Cin; };
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& a, const float* w /*[3][Cout][C]*/,
                     const float* bias /*[3][Cout]*/, int Cout, int H, int W, int D, float* out, hipStream_t st,
-                    const s3d_sampler_args* fuse = nullptr, const GnPartials* part = nullptr);
+                    const s3d_sampler_args* fuse = nullptr, const GnPartials* part = nullptr, const InConvCarry* carry = nullptr);
+bool out_head_can_carry(int C, int Cin, int Cout_head);  // the pixel-chunk head of this width can run the in_conv tail
 bool out_head_fuses_sampler(int C, int Cout, int B);     // the update happens inside the head's launch (else: head, then k_sampler)
 bool out_head_px_takes(int C, int Cout);                 // the pixel-chunk head serves this width (it can add GroupNorm partials itself)
 // part (with stats.mr == null): the head adds its input's GroupNorm partials itself — no k_gn_finalize launch before it

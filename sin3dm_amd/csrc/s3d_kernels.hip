@@ -1207,8 +1207,11 @@ constexpr int kOhPx = 64;
 // read and x_{t-1} + pred_xstart written with the same coalesced NCHW accesses; the D x D corner takes the update with a model
 // output of exactly 0 (compose_featmaps' zero fill, src/utils/triplane_util.py:7-18).  Same arithmetic in the same order as
 // k_out_head_px<CQ, false> followed by k_sampler: bit-identical results.
-template <int CQ, bool FUSED>                              // channel quads per pixel: 16, 32 or 64
-__global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2, s3d_sampler_args sa) {
+// CARRY (FUSED only): the block then runs the NEXT step's in_conv on the 64 x_{t-1} pixels it has just formed —
+// k_in_conv_lds<32, CQ>'s body twice (its blocks own 32 pixels), fed from LDS instead of from memory: the same products in the same
+// order, the same thread mapping and the same per-block GroupNorm partial sums, written to the tensors the next forward reads.
+template <int CQ, bool FUSED, bool CARRY = false>          // channel quads per pixel: 16, 32 or 64
+__global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0, int segs1, int segs2, s3d_sampler_args sa, InConvCarry cy = InConvCarry()) {
     constexpr int C = 4 * CQ, CPW = C / 4, LANES = 256 / CQ, LD = C + 4;
     __shared__ __attribute__((aligned(16))) float sx[kOhPx * LD];
     __shared__ float sp[4][16][kOhPx];
@@ -1233,7 +1236,9 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
         if (i < n_corner) {
             const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
             corner_o[u] = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
-            if (FUSED) { corner_x[u] = sa.x[corner_o[u]]; if (sa.noise) corner_n[u] = sa.noise[corner_o[u]]; }
+            // (CARRY: requested behind the output loop instead — their latency then runs under the in_conv tail; kept from here they
+            // were live across the whole kernel and spilled behind a vmcnt(0) at its very start)
+            if (FUSED && !CARRY) { corner_x[u] = sa.x[corner_o[u]]; if (sa.noise) corner_n[u] = sa.noise[corner_o[u]]; }
         }
     }
     const int h = a.h[p], w = a.wd[p];
@@ -1336,6 +1341,19 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
         }
     }
     __syncthreads();
+    float xnext[kOutIts];
+#pragma unroll
+    for (int k = 0; k < kOutIts; ++k) xnext[k] = 0.f;
+    // CARRY: the next in_conv's weight rows for input channels 0..7 are requested now (their latency runs under the output loop), the
+    // other eight once the x_{t-1} values are staged
+    float4 wA[8], wB[8];
+    float4 biasn = make_float4(0, 0, 0, 0);
+    if (FUSED && CARRY) {
+        const float4* wq0 = reinterpret_cast<const float4*>(cy.wT + size_t(p) * cy.Cin * C) + tid % CQ;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) wA[ci] = ci < cy.Cin ? wq0[size_t(ci) * CQ] : make_float4(0, 0, 0, 0);
+        biasn = reinterpret_cast<const float4*>(cy.bias + size_t(p) * C)[tid % CQ];
+    }
 #pragma unroll
     for (int k = 0; k < kOutIts; ++k) {
         const int it = tid + 256 * k, co = it >> 6, e = it & 63;
@@ -1344,15 +1362,105 @@ __global__ __launch_bounds__(256, 3) void k_out_head_px(OutHeadArgs a, int segs0
         const int sy = p == 2 ? a.H + line : line, sx0 = p == 1 ? a.W + s0 : s0;
         const size_t o = ((size_t(b) * a.Cout + co) * Hc + sy) * Wc + sx0 + e;
         if (!FUSED || a.out) a.out[o] = v;
-        if (FUSED) sampler_element(sa, sc, (long long)o, v, pre_x[k], pre_n[k]);
+        if (FUSED) {
+            const float xprev = sampler_element(sa, sc, (long long)o, v, pre_x[k], pre_n[k]);
+            if (CARRY) xnext[k] = xprev;
+        }
     }
+    if (FUSED && CARRY) {
+#pragma unroll
+        for (int u = 0; u < CU_; ++u) {
+            const long long i = (long long)blockIdx.x * 256 + tid + u * corner_stride;
+            if (i < n_corner) {
+                const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
+                corner_o[u] = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
+                corner_x[u] = sa.x[corner_o[u]]; if (sa.noise) corner_n[u] = sa.noise[corner_o[u]];
+            }
+        }
+        // ---- the next step's in_conv on this block's x_{t-1} (k_in_conv_lds<32, CQ>, twice).  sx is dead since the barrier above.
+        constexpr int LANES_I = 256 / CQ, PXI = 32;
+        float (*sxn)[16] = reinterpret_cast<float (*)[16]>(sx);                        // [64 pixels][16 input channels]
+        float (*sred)[LANES_I][C] = reinterpret_cast<float (*)[LANES_I][C]>(sx + kOhPx * 16);      // [sum | sumsq][pixel lane][channel]
+        static_assert(kOhPx * 16 + 2 * LANES_I * C <= kOhPx * LD, "carry scratch inside the staging area");
+#pragma unroll
+        for (int k = 0; k < kOutIts; ++k) {
+            const int it = tid + 256 * k, co = it >> 6, e = it & 63;
+            sxn[e][co] = (co < cy.Cin && s0 + e < len) ? xnext[k] : 0.f;               // (channels Cin..15 and pixels past the line: zeros, as k_in_conv_lds stages them)
+        }
+        const int q = tid % CQ, lp = tid / CQ;
+        const float4* wq = reinterpret_cast<const float4*>(cy.wT + size_t(p) * cy.Cin * C) + q;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) wB[ci] = 8 + ci < cy.Cin ? wq[size_t(8 + ci) * CQ] : make_float4(0, 0, 0, 0);
+        const int nseg_in = (len + PXI - 1) / PXI;
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < kOhPx / PXI; ++hh) {
+            const int s0i = s0 + hh * PXI;
+            if (s0i >= len) break;                                                     // (block-uniform: no such in_conv block)
+            // every output's chain is bias, then input channels 0..15 in order (k_in_conv_lds's)
+            constexpr int NK = PXI / LANES_I;
+            float4 acc[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) acc[k] = biasn;
+#pragma unroll
+            for (int half8 = 0; half8 < 2; ++half8) {
+                const float4* wvn = half8 ? wB : wA;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const int e = k * LANES_I + lp;
+#pragma unroll
+                    for (int c4 = 0; c4 < 2; ++c4) {
+                        const float4 v = *reinterpret_cast<const float4*>(&sxn[hh * PXI + e][(half8 * 2 + c4) * 4]);
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 ww = wvn[c4 * 4 + j];
+                            acc[k].x = fmaf(vv[j], ww.x, acc[k].x); acc[k].y = fmaf(vv[j], ww.y, acc[k].y);
+                            acc[k].z = fmaf(vv[j], ww.z, acc[k].z); acc[k].w = fmaf(vv[j], ww.w, acc[k].w);
+                        }
+                    }
+                }
+            }
+            float gs[4] = {0.f, 0.f, 0.f, 0.f}, gss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int e = k * LANES_I + lp;
+                if (s0i + e >= len) continue;
+                const int y = p == 2 ? s0i + e : line, xx = p == 2 ? line : s0i + e;
+                reinterpret_cast<float4*>(cy.out[p] + ((size_t(b) * h + y) * w + xx) * C)[q] = acc[k];
+                gs[0] += acc[k].x; gs[1] += acc[k].y; gs[2] += acc[k].z; gs[3] += acc[k].w;
+                gss[0] = fmaf(acc[k].x, acc[k].x, gss[0]); gss[1] = fmaf(acc[k].y, acc[k].y, gss[1]); gss[2] = fmaf(acc[k].z, acc[k].z, gss[2]); gss[3] = fmaf(acc[k].w, acc[k].w, gss[3]);
+            }
+            if (cy.part) {
+                if (hh) __syncthreads();                                               // the previous half's partial sums have been read
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { sred[0][lp][4 * q + k] = gs[k]; sred[1][lp][4 * q + k] = gss[k]; }
+                __syncthreads();
+                if (tid < 32) {
+                    constexpr int cg = C / 32;
+                    const int g = tid;
+                    double S = 0, SS = 0;
+                    for (int l = 0; l < LANES_I; ++l)
+#pragma unroll
+                        for (int k = 0; k < cg; ++k) { S += sred[0][l][cg * g + k]; SS += sred[1][l][cg * g + k]; }
+                    const int blk_in = line * nseg_in + s0i / PXI;
+                    double* o = cy.part + (((size_t(b) * 3 + p) * 32 + g) * cy.maxparts + blk_in) * 2;
+                    o[0] = S; o[1] = SS;
+                }
+            }
+        }
+    }
+    // (the corner index again from an opaque thread id: kept from the top of the kernel it was a 64-bit value live across the CARRY tail — spilled)
+    int tid_c = threadIdx.x;
+    if (CARRY) asm volatile("" : "+v"(tid_c));
+    const long long corner_i1 = CARRY ? (long long)blockIdx.x * 256 + tid_c : corner_i0;
 #pragma unroll
     for (int u = 0; u < CU_; ++u) {
-        if (corner_i0 + u * corner_stride >= n_corner) continue;
+        if (corner_i1 + u * corner_stride >= n_corner) continue;
         if (!FUSED || a.out) a.out[corner_o[u]] = 0.f;
         if (FUSED) sampler_element(sa, sc, (long long)corner_o[u], 0.f, corner_x[u], corner_n[u]);
     }
-    for (long long i = corner_i0 + CU_ * corner_stride; i < n_corner; i += corner_stride) {      // (shapes with D*D > 2 x the plane pixels)
+    for (long long i = corner_i1 + CU_ * corner_stride; i < n_corner; i += corner_stride) {      // (shapes with D*D > 2 x the plane pixels)
         const int dx = int(i % a.D), dy = int((i / a.D) % a.D), co = int(i / a.D / a.D);
         const size_t o = ((size_t(b) * a.Cout + co) * Hc + a.H + dy) * Wc + a.W + dx;
         if (!FUSED || a.out) a.out[o] = 0.f;
@@ -1375,8 +1483,10 @@ long long out_head_px_blocks(const Geo& g, int B) {
     return n * B;
 }
 bool out_head_adds_parts(const GnPartials& part, int C, int Cout) { return out_head_px_form(C, Cout) && gn_act_can_add_parts(part, C); }
+bool out_head_can_carry(int C, int Cin, int Cout_head) { return out_head_px_form(C, Cout_head) && Cin <= 16 && Cin == Cout_head; }
 int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const float* w, const float* bias,
-                    int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse, const GnPartials* part) {
+                    int Cout, int H, int W, int D, float* out, hipStream_t st, const s3d_sampler_args* fuse, const GnPartials* part,
+                    const InConvCarry* carry) {
     OutHeadArgs a;
     int maxpix = D * D ? 1 : 0;
     for (int p = 0; p < 3; ++p) {
@@ -1402,7 +1512,13 @@ int launch_out_head(const Tri& x, int B, GnStats stats, const ActArgs& aa, const
         const dim3 grid(segs[0] + segs[1] + segs[2], B);
         s3d_sampler_args sa;
         memset(&sa, 0, sizeof sa);
-        if (fuse_here) {
+        if (carry) S3D_CHECK(fuse_here && out_head_can_carry(x.C, carry->Cin, Cout) && fuse->mode != S3D_STEP_MEAN_ONLY, S3D_ERR_INVALID, "out head: this step cannot carry the next in_conv");
+        if (fuse_here && carry) {
+            sa = *fuse;
+            if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16, true, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa, *carry);
+            else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32, true, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa, *carry);
+            else hipLaunchKernelGGL((k_out_head_px<64, true, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa, *carry);
+        } else if (fuse_here) {
             sa = *fuse;
             if (x.C == 64) hipLaunchKernelGGL((k_out_head_px<16, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);
             else if (x.C == 128) hipLaunchKernelGGL((k_out_head_px<32, true>), grid, dim3(256), 0, st, a, segs[0], segs[1], segs[2], sa);

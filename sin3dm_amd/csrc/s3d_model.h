@@ -98,10 +98,16 @@ struct s3d_unet {
     // Workspace lanes (s3d_unet_select_lane): independent sample chains on different HIP streams through ONE handle — the weights
     // are shared, everything a forward writes (the activation arena, the timestep MLP's scratch, the measured-shape key) exists
     // once per lane.  The fields above ARE the selected lane; the others are parked here.
+    // The next step's in_conv, left in this lane's workspace by the previous fused step's output head (s3d_unet_step_film_carry):
+    // valid for exactly one following step on the tensor `sample` of that shape; any other forward, a workspace reallocation or
+    // a parameter change drops it.
+    struct CarryState { bool valid = false; const float* sample = nullptr; long long key[4] = {-1, -1, -1, -1}; };
+    CarryState carry;
     struct LaneState {
         DevBuf arena_buf, film_ws;
         size_t off = 0, high = 0, inf_high = 0;
         long long inf_key[4] = {-1, -1, -1, -1};
+        CarryState carry;
     };
     std::vector<std::unique_ptr<LaneState>> lanes;       // lanes[k] holds lane k's state while another lane is selected
     int cur_lane = 0;
@@ -111,7 +117,9 @@ struct s3d_unet {
         std::swap(film_ws.p, L.film_ws.p); std::swap(film_ws.cap, L.film_ws.cap);
         std::swap(inf_high, L.inf_high);
         for (int k = 0; k < 4; ++k) std::swap(inf_key[k], L.inf_key[k]);
+        std::swap(carry, L.carry);
     }
+    void drop_carries() { carry.valid = false; for (auto& L : lanes) if (L) L->carry.valid = false; }
 
     // training tier: caller-owned flat master parameters (reference layouts, specs order, tightly packed), the
     // device-side repack plan and the activation tape of the last forward_train
@@ -200,7 +208,8 @@ int launch_repack_generic(const PackDesc* descs_dev, int ndesc, int blocks, cons
 // fuse != null: one denoising step — the sampler update is applied to the model output by the output head; `out` may then be
 // null (the model output is not stored)
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape, const float* ext_film = nullptr, int ext_film_stride = 0, const s3d_sampler_args* fuse = nullptr);
+                Tape* tape, const float* ext_film = nullptr, int ext_film_stride = 0, const s3d_sampler_args* fuse = nullptr,
+                int carry_flags = 0);
 
 struct Fwd {
     s3d_unet* m;

@@ -36,10 +36,11 @@ __device__ __forceinline__ SamplerCoef sampler_coef(const s3d_sampler_args& a, i
 }
 
 // element i of the step: mo = the model's output there, xt = x_t[i], nv = the step's eps there (0 when the step has none).
-// Writes sample / pred_xstart / mean as the mode asks.
-__device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo, float xt, float nv) {
+// Writes sample / pred_xstart / mean as the mode asks; returns the value written to `sample` (x_{t-1}; 0 for MEAN_ONLY).
+__device__ __forceinline__ float sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo, float xt, float nv) {
 #pragma clang fp contract(off)
     float x0 = mo;
+    float xprev = 0.f;
     if (a.mean_type == S3D_MEAN_EPSILON) {                                                                  // _predict_xstart_from_eps (:329-335)
         const float p1 = c.sr * xt, p2 = c.srm1 * mo;
         x0 = p1 - p2;
@@ -58,18 +59,20 @@ __device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const
         const float m1 = x0 * c.ca, m2 = c.cb * eps;
         const float mean_pred = m1 + m2;
         const float nzs = (c.nz * c.sigma) * nv;
-        a.sample[i] = mean_pred + nzs;
+        xprev = mean_pred + nzs;
+        a.sample[i] = xprev;
         a.pred_xstart[i] = x0;
     } else {
         const float m1 = c.c1 * x0, m2 = c.c2 * xt;                                                         // q_posterior_mean_variance (:218-221)
         const float mean = m1 + m2;
         if (a.mean) a.mean[i] = mean;
         a.pred_xstart[i] = x0;
-        if (a.mode == S3D_STEP_DDPM) { const float nzs = c.sig_ddpm * nv; a.sample[i] = mean + nzs; }
+        if (a.mode == S3D_STEP_DDPM) { const float nzs = c.sig_ddpm * nv; xprev = mean + nzs; a.sample[i] = xprev; }
     }
+    return xprev;
 }
-__device__ __forceinline__ void sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo) {
-    sampler_element(a, c, i, mo, a.x[i], a.noise ? a.noise[i] : 0.f);
+__device__ __forceinline__ float sampler_element(const s3d_sampler_args& a, const SamplerCoef& c, long long i, float mo) {
+    return sampler_element(a, c, i, mo, a.x[i], a.noise ? a.noise[i] : 0.f);
 }
 
 }  // namespace s3d

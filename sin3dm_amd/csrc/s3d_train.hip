@@ -462,6 +462,7 @@ int s3d_unet_train_attach(s3d_unet* m, float* params, int64_t numel) {
 
 int s3d_unet_repack(s3d_unet* m, void* stream) {
     S3D_CHECK(m && m->flat, S3D_ERR_INVALID, "repack: call s3d_unet_train_attach first");
+    m->drop_carries();                              // (a carried in_conv was formed with the old weights)
     return launch_repack(m, static_cast<hipStream_t>(stream));
 }
 

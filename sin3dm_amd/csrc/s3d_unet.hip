@@ -232,7 +232,7 @@ int pack_all(s3d_unet* m) {
 // ------------------------------------------------------------------ forward
 
 int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, hipStream_t st,
-                Tape* tape, const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse) {
+                Tape* tape, const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse, int carry_flags) {
     const s3d_unet_cfg& c = m->cfg;
     const int mc = c.model_channels, ted = 4 * mc;
     Fwd f{m, B, st, nullptr};
@@ -258,11 +258,21 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
 
     Geo g0 = Geo::from_hwd(H, W, D);
     Tri h = f.alloc_tri(c.channel_mult[0] * mc, g0);
+    // The previous fused step's output head may have left THIS step's in_conv here (s3d_unet_step_film_carry; the workspace is
+    // bump-allocated in a fixed order, so the tensor and its GroupNorm partials sit where this forward allocates them): taken when
+    // the caller vouches for the input (S3D_CARRY_IN) and it is that step's sample, same shape, same lane, nothing in between.
+    const long long ckey[4] = {B, H, W, D};
+    const bool take = !meas && !tape && (carry_flags & S3D_CARRY_IN) && m->carry.valid && m->carry.sample == x &&
+                      m->carry.key[0] == ckey[0] && m->carry.key[1] == ckey[1] && m->carry.key[2] == ckey[2] && m->carry.key[3] == ckey[3];
+    if (!meas) m->carry.valid = false;                             // consumed, or void: one step only
+    Tri h0 = h;
+    GnPartials part0{nullptr, 0, {0, 0, 0}, 0};
     {
         int np[3];
         if (in_conv_gn_parts(h.g, c.in_channels, h.C, np)) {        // the kernel leaves the GroupNorm partials of its output
             const Fwd::ChunkStats cs = f.chunk_stats(np);
-            if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st, &cs.part));
+            part0 = cs.part;
+            if (!meas && !take) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st, &cs.part));
             S3D_TRY(f.finish(cs, h));
         } else if (!meas) S3D_TRY(launch_in_conv(x, B, c.in_channels, H, W, D, m->dev(m->in_wT), m->dev(m->in_b), h.C, h, st));
     }
@@ -360,7 +370,18 @@ int run_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W
         ActArgs aa;
         for (int p = 0; p < 3; ++p) { aa.gamma[p] = m->dev(m->out_norm.gamma[p]); aa.beta[p] = m->dev(m->out_norm.beta[p]); }
         aa.film = nullptr; aa.film_stride = 0;
-        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st, fuse, head_adds ? &h.part : nullptr));
+        // S3D_CARRY_OUT: the head also runs the NEXT step's in_conv on the x_{t-1} it forms (unet_triplane.py:378, 482: a pointwise
+        // TriplaneConv) into h0 / part0 — dead since this step's first block consumed them
+        InConvCarry cy;
+        const bool give = (carry_flags & S3D_CARRY_OUT) && fuse && fuse->sample && fuse->mode != S3D_STEP_MEAN_ONLY && !tape && part0.p &&
+                          h.C == h0.C && out_head_fuses_sampler(h.C, c.out_channels, B) && out_head_can_carry(h.C, c.in_channels, c.out_channels);
+        if (give) {
+            cy.wT = m->dev(m->in_wT); cy.bias = m->dev(m->in_b); cy.part = part0.p; cy.maxparts = part0.maxparts; cy.Cin = c.in_channels;
+            for (int p = 0; p < 3; ++p) cy.out[p] = h0.p[p];
+        }
+        S3D_TRY(launch_out_head(h, B, stats, aa, m->dev(m->out_w), m->dev(m->out_b), c.out_channels, H, W, D, out, st, fuse, head_adds ? &h.part : nullptr,
+                                give ? &cy : nullptr));
+        if (give) { m->carry.valid = true; m->carry.sample = fuse->sample; for (int k = 0; k < 4; ++k) m->carry.key[k] = ckey[k]; }
     }
     return 0;
 }
@@ -414,7 +435,7 @@ int s3d_unet_set_param(s3d_unet* m, const char* name, const float* data, const i
 }
 
 static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
-                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse = nullptr);
+                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse = nullptr, int carry_flags = 0);
 
 int s3d_unet_forward(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream) {
     S3D_CHECK(m && x && t && out, S3D_ERR_INVALID, "unet_forward: null argument");
@@ -468,15 +489,28 @@ int s3d_unet_step_film(s3d_unet* m, const float* film, int film_stride, int B, i
               S3D_ERR_INVALID, "unet_step_film: incomplete sampler arguments");
     S3D_CHECK(step->batch == B && step->per_sample == (long long)m->cfg.out_channels * (H + D) * (W + D) && m->cfg.in_channels == m->cfg.out_channels,
               S3D_ERR_INVALID, "unet_step_film: the step's shape is not the model's");
-    return forward_impl(m, step->x, nullptr, B, H, W, D, model_out, stream, film, film_stride, step);
+    return forward_impl(m, step->x, nullptr, B, H, W, D, model_out, stream, film, film_stride, step, 0);
+}
+
+int s3d_unet_step_film_carry(s3d_unet* m, const float* film, int film_stride, int B, int H, int W, int D, const s3d_sampler_args* step,
+                             float* model_out, void* stream, int carry_flags) {
+    S3D_CHECK(m && film && step, S3D_ERR_INVALID, "unet_step_film_carry: null argument");
+    S3D_CHECK((carry_flags & ~(S3D_CARRY_OUT | S3D_CARRY_IN)) == 0, S3D_ERR_INVALID, "unet_step_film_carry: unknown flag bits %d", carry_flags);
+    S3D_CHECK(film_stride == 0 || film_stride == m->film_total, S3D_ERR_INVALID, "unet_step_film_carry: film_stride must be 0 or %d", m->film_total);
+    S3D_CHECK(step->x && step->t && step->tables && step->pred_xstart && (step->mode == S3D_STEP_MEAN_ONLY || step->sample) &&
+                  (step->mode != S3D_STEP_DDPM || step->noise),
+              S3D_ERR_INVALID, "unet_step_film_carry: incomplete sampler arguments");
+    S3D_CHECK(step->batch == B && step->per_sample == (long long)m->cfg.out_channels * (H + D) * (W + D) && m->cfg.in_channels == m->cfg.out_channels,
+              S3D_ERR_INVALID, "unet_step_film_carry: the step's shape is not the model's");
+    return forward_impl(m, step->x, nullptr, B, H, W, D, model_out, stream, film, film_stride, step, carry_flags);
 }
 
 }  // extern "C"
 
 static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int H, int W, int D, float* out, void* stream,
-                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse) {
+                        const float* ext_film, int ext_film_stride, const s3d_sampler_args* fuse, int carry_flags) {
     S3D_CHECK(B >= 1 && H >= 1 && W >= 1 && D >= 1, S3D_ERR_INVALID, "unet_forward: B,H,W,D must be >= 1");
-    if (!m->packed) S3D_TRY(pack_all(m));
+    if (!m->packed) { m->drop_carries(); S3D_TRY(pack_all(m)); }      // (new weights: a carried in_conv was formed with the old ones)
     m->tape.valid = false;                    // the workspace is shared with the training tape
     hipStream_t st = static_cast<hipStream_t>(stream);
     // pass 1: measure the workspace; grow it if needed (synchronising only when it really grows).  The walk is pure host
@@ -495,12 +529,13 @@ static int forward_impl(s3d_unet* m, const float* x, const float* t, int B, int 
         if (m->arena.high > m->arena.buf.cap) {
             S3D_HIP(hipStreamSynchronize(st));
             S3D_TRY(m->arena.buf.reserve(m->arena.high + (m->arena.high >> 3)));
+            m->carry.valid = false;                                // the workspace moved
         }
     }
     m->prof_now = m->prof_every > 0 && (m->fwd_count % m->prof_every) == 0;
     ++m->fwd_count;
     if (m->prof_now) ++m->prof_forwards;
-    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride, fuse);
+    rc = run_forward(m, x, t, B, H, W, D, out, st, nullptr, ext_film, ext_film_stride, fuse, carry_flags);
     m->prof_now = false;
     return rc;
 }

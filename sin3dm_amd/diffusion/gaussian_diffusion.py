@@ -184,10 +184,11 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ one fused update
     def _step(self, mode, model, x, t, clip_denoised, denoised_fn, model_kwargs, eta=0.0, y0=None, mask=None,
-              is_mask_t0=False, want_mean=False, fuse=False, noise=None):
+              is_mask_t0=False, want_mean=False, fuse=False, noise=None, carry=0):
         """fuse (the sampling loops): when the denoiser offers `denoise_step` and the timestep values are known on the host,
         the UNet's output head applies the update itself — one launch instead of head + sampler kernel, and the model output
-        never reaches memory (SURVEY.md section 2b, K8 + K9).  noise: this step's eps when the caller drew it ahead."""
+        never reaches memory (SURVEY.md section 2b, K8 + K9).  noise: this step's eps when the caller drew it ahead.
+        carry (fused steps of the loops only): _lib.CARRY_OUT / CARRY_IN of TriplaneUNetModelSmall.denoise_step."""
         _lib.require_gpu(x)
         if model_kwargs is None:
             model_kwargs = {}
@@ -233,7 +234,10 @@ class GaussianDiffusion:
                              sample=sample.data_ptr() if sample is not None else None, pred_xstart=pred.data_ptr(),
                              mean=mean.data_ptr() if mean is not None else None)
         if fused:
-            step_fn(x, ts, a, **model_kwargs)
+            if carry and getattr(model, "carries_in_conv", False):
+                step_fn(x, ts, a, carry=carry, **model_kwargs)
+            else:
+                step_fn(x, ts, a, **model_kwargs)
             return sample, pred, mean
         with th.cuda.device(x.device):
             _lib.check(_lib.load().s3d_sampler_step(a, _lib.stream_ptr()))
@@ -320,8 +324,14 @@ class GaussianDiffusion:
         for d in (shape if generator is None or isinstance(generator, th.Generator) else shape[1:]):     # (per-element generators: per SAMPLE)
             per_step *= int(d)
         chunk = max(1, min(self.num_timesteps, self._NOISE_AHEAD_BYTES // max(per_step, 1)))
+        # The next step's in_conv rides on this step's output head (s3d_unet_step_film_carry) when nobody touches the sample in
+        # between: CARRY_OUT on every step but the last; CARRY_IN when `img` still IS the tensor the previous step wrote — same
+        # object, same version counter (a consumer of this generator that replaces or edits out["sample"] switches it off).
+        last = self.num_timesteps - 1
+        prev_sample, prev_version = None, -1
         for n, i in enumerate(indices):
             t = HostTimesteps(all_t[i], (i,) * shape[0])
+            carry = (_lib.CARRY_OUT if n < last else 0) | (_lib.CARRY_IN if img is prev_sample and img._version == prev_version else 0)
             eps = None
             if self.noise_fn is None:
                 if ahead is None or ahead_k == ahead.shape[0]:
@@ -331,7 +341,8 @@ class GaussianDiffusion:
                 ahead_k += 1
             with th.no_grad():
                 sample, pred, _ = self._step(mode, model, img, t, clip_denoised, denoised_fn, model_kwargs, fuse=True,
-                                             noise=eps, **kw)
+                                             noise=eps, carry=carry, **kw)
+            prev_sample, prev_version = sample, (sample._version if sample is not None else -1)
             out = {"sample": sample, "pred_xstart": pred}
             yield out                 # (outside the no_grad block: a generator abandoned mid-loop must not unwind a context manager at interpreter exit)
             img = out["sample"]

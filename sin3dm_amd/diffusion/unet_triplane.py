@@ -14,6 +14,7 @@ that the optimizer / EMA / all-reduce can work on a single buffer; `.grad` of ev
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch as th
 import torch.nn as nn
@@ -336,11 +337,17 @@ class _TriplaneUNetBase(nn.Module):
         assert out.shape == x.shape or y is not None
         return out
 
-    def denoise_step(self, x, timesteps, step, H=None, W=None, D=None):
+    # denoise_step takes `carry` (GaussianDiffusion._loop asks); S3D_CARRY_IN_CONV=0: every step launches its own in_conv (A/B)
+    carries_in_conv = os.environ.get("S3D_CARRY_IN_CONV", "1") != "0"
+
+    def denoise_step(self, x, timesteps, step, H=None, W=None, D=None, carry=0):
         """One step of a sampling loop in one library call: this forward (host-known `timesteps`) with the sampler update
         `step` (_lib.SamplerArgs with x / noise / tables / outputs set; its model_out is ignored) applied by the output
         head's launch — src/diffusion/unet_triplane.py:465-510 + gaussian_diffusion.py:396-440 / 538-600.  The model output
-        is not materialised.  Results equal forward() followed by s3d_sampler_step bit for bit."""
+        is not materialised.  Results equal forward() followed by s3d_sampler_step bit for bit.
+        carry (_lib.CARRY_OUT | _lib.CARRY_IN, s3d_unet_step_film_carry): CARRY_OUT — this step's sample is the next step's input:
+        the head also leaves the next step's in_conv (a pointwise TriplaneConv, :378, 482) in the workspace; CARRY_IN — `x` is the
+        previous step's sample, untouched since: that in_conv is used instead of launching the kernel.  Same bits either way."""
         assert H is not None and W is not None and D is not None
         _lib.require_gpu(x)
         hv = getattr(timesteps, "host_values", None)
@@ -352,8 +359,12 @@ class _TriplaneUNetBase(nn.Module):
         t = timesteps.to(device=x.device, dtype=th.float32).contiguous()
         with th.cuda.device(x.device):
             film, stride = self._film_for(lib, hv, t)
-            _lib.check(lib.s3d_unet_step_film(self._handle, _lib.ptr(film), stride, B, int(H), int(W), int(D), C.byref(step),
-                                              None, _lib.stream_ptr()))
+            if carry:
+                _lib.check(lib.s3d_unet_step_film_carry(self._handle, _lib.ptr(film), stride, B, int(H), int(W), int(D), C.byref(step),
+                                                        None, _lib.stream_ptr(), int(carry)))
+            else:
+                _lib.check(lib.s3d_unet_step_film(self._handle, _lib.ptr(film), stride, B, int(H), int(W), int(D), C.byref(step),
+                                                  None, _lib.stream_ptr()))
 
     def prepare_timesteps(self, values, t_dev):
         """The FiLM tables of a whole schedule (host values + the same values on the device) in one batched launch (three

@@ -448,6 +448,44 @@ def test_fused_denoise_step_equals_forward_plus_sampler_kernel(mc, B):
     assert torch.isfinite(z).all() and float(z[..., H:, W:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mc,B,hwd,ddim", [(64, 1, (40, 24, 56), False), (64, 2, (12, 9, 7), True), (128, 1, (64, 48, 32), False), (32, 2, (10, 14, 6), False)])
+def test_next_steps_in_conv_carried_by_the_output_head_is_the_same_bits(mc, B, hwd, ddim):
+    """in_conv is TriplaneConv(in, ch, 1, padding=0, is_rollout=False) (src/diffusion/unet_triplane.py:378, 482): a pointwise map of x_t
+    with no timestep in it, and in a sampling loop x_t IS the previous step's sample (gaussian_diffusion.py:533-534).  The loops let the
+    output head of step n also evaluate step n + 1's in_conv and its GroupNorm partial sums on the x_{t-1} it has just formed
+    (s3d_unet_step_film_carry: SURVEY.md section 2b, K8 + K9 + K2) — k_in_conv_lds's products in its order and thread
+    mapping.  Every step's sample and pred_xstart equal the loop that launches in_conv each step, bit for bit: ragged planes whose
+    rows are not multiples of the head's 64-pixel or in_conv's 32-pixel segments, batch 2, DDPM and DDIM, the widths of the
+    pixel-chunk head (64 / 128; at 32 channels the generic head takes the step and nothing is carried).  A consumer of the
+    progressive loop that edits out["sample"] in place switches the carry off for that step (version counter): still equal."""
+    from sin3dm_amd.diffusion.script_util import create_gaussian_diffusion
+    H, W, D = hwd
+    kw = dict(H=H, W=W, D=D)
+    shape = (B, 12, H + D, W + D)
+    diff = create_gaussian_diffusion(steps=1000, noise_schedule="linear", predict_xstart=True, timestep_respacing="ddim6" if ddim else "6")
+    loop = diff.ddim_sample_loop_progressive if ddim else diff.p_sample_loop_progressive
+
+    def run(carry, edit_at=None):
+        model = make_model(mc)
+        model.carries_in_conv = carry
+        torch.manual_seed(17)
+        outs = []
+        for n, out in enumerate(loop(model, shape, model_kwargs=kw)):
+            outs.append((out["sample"].clone(), out["pred_xstart"].clone()))
+            if n == edit_at:
+                out["sample"].mul_(0.5)                    # the reference's loop continues from whatever the consumer left in out["sample"]
+        return outs
+
+    a, b = run(False), run(True)
+    assert len(a) == 6
+    for n, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), (mc, B, hwd, ddim, n)
+    assert torch.isfinite(a[-1][0]).all()
+    a, b = run(False, edit_at=2), run(True, edit_at=2)
+    for n, (x, y) in enumerate(zip(a, b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]), ("edited", mc, n)
+
+
 @pytest.mark.parametrize("tag,resp,ddim", [("ddim10", "10", True), ("ddpm20", "20", False)])
 def test_trajectories_golden(tag, resp, ddim):
     g = golden("trajectories")
