@@ -198,10 +198,11 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs args) {
                     if (chunk + 1 < nchunks) {
                         float* Ad = Abase + ((chunk + 1) & 1) * CFG::A_ELEMS;
                         float* Bd = Bbase + ((chunk + 1) & 1) * CFG::B_ELEMS;
+                        // (S3D_ABLATE & 2, tools/conv_ubench.hip only: no ds_write pass — what staging by LDS-DMA could remove at most)
 #pragma unroll
-                        for (int it = 0; it < CFG::NA; ++it) *reinterpret_cast<f32x4*>(Ad + aDst[it]) = aOk[it] ? qa[d][it] : zero4;
+                        for (int it = 0; it < CFG::NA; ++it) if (!(S3D_ABLATE & 2)) *reinterpret_cast<f32x4*>(Ad + aDst[it]) = aOk[it] ? qa[d][it] : zero4; else asm volatile("" :: "v"(qa[d][it]));
 #pragma unroll
-                        for (int it = 0; it < CFG::NB; ++it) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? qb[d][it] : zero4;
+                        for (int it = 0; it < CFG::NB; ++it) if (!(S3D_ABLATE & 2)) *reinterpret_cast<f32x4*>(Bd + bDst[it]) = bOk[it] ? qb[d][it] : zero4; else asm volatile("" :: "v"(qb[d][it]));
                         const int ch = min(chunk + 1 + PF, nchunks - 1);
                         if (chunk + 1 + PF < nchunks) {
 #pragma unroll

@@ -2,7 +2,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DS3D_ABLATE=k] tools/conv_ubench.hip -o /tmp/ub && /tmp/ub
 #include "../sin3dm_amd/csrc/s3d_common.h"
 #include "ub_stubs.h"
-namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; } }
+namespace s3d { void set_error(const char*, ...) {} const char* get_error() { return ""; }
+  // (the Winograd side of launch_conv is not linked into this harness)
+  bool conv_use_wino24() { return false; } bool conv_use_wino() { return false; } void wino_gn_parts(const Geo&, int*) {} double wino_exec_fraction() { return 1.0; }
+  int launch_conv_wino24s(ConvArgs&, hipStream_t) { return -1; } int launch_conv_wino(ConvArgs&, hipStream_t) { return -1; } }
 #include "../sin3dm_amd/csrc/s3d_conv.hip"
 #include <vector>
 #include <cstdlib>
@@ -38,6 +41,11 @@ static double run(const char* name, int cin, int cout, int hw, int B, int iters)
     return us;
 }
 int main() {
+    // the 1x1 launches of the scored step (plain epilogue: no residual here)
+    run<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2, false>>("1x1 8x8 px x64 PF=2", 128, 128, 128, 1, 20);
+    run<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2, false>>("1x1 8x8 px x64 PF=2", 256, 128, 64, 1, 20);
+    run<ConvCfg<8, 8, 1, 1, 2, 2, 1, 1, 1, 2, false>>("1x1 8x8 px x64 PF=2", 128, 256, 64, 1, 20);
+    if (getenv("UB_1X1_ONLY")) return 0;
     run<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1, 2>>("8x8 px x64 KS=2", 128, 128, 128, 1, 20);
     run<ConvCfg<8, 8, 3, 3, 2, 2, 1, 1, 4>>("8x8 px x64 KS=4", 128, 128, 128, 1, 20);
     run<ConvCfg<8, 16, 3, 3, 4, 1, 1, 2, 2>>("8x16 px x64 KS=2", 128, 128, 128, 1, 20);
