@@ -584,6 +584,12 @@ def worker(args):
         dist.all_gather_object(ranks, mine)
         backend_world = dist.get_world_size()
         backend = dist.get_backend()
+        try:                                   # every rank empties its C stdout (RCCL's version banner sits there until exit) BEFORE the last
+            import ctypes                      # barrier: rank 0's JSON line, printed behind it, is then the last line of the job's output
+            ctypes.CDLL(None).fflush(None)
+            sys.stdout.flush()
+        except Exception:
+            pass
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
