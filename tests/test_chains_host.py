@@ -147,3 +147,33 @@ def test_chains_fail_loudly_when_the_shared_weights_change_mid_run():
     # one chain at a time: nothing is shared, nothing is checked
     it = diff.sample_loop_chains_progressive(m, (1, 2), 2, chains=1, generators=[1, 2], device="cpu")
     next(it); m.stamp = 2; next(it)
+
+
+def test_loop_sets_the_in_conv_carry_flags_by_identity_and_version():
+    """GaussianDiffusion._loop (gaussian_diffusion.py:488-536 in the reference) asks the denoiser to carry the next step's in_conv
+    (s3d_unet_step_film_carry): CARRY_OUT on every step but the last; CARRY_IN only when the tensor it continues from still IS the
+    previous step's sample — same object, same version counter.  A consumer that edits or replaces out["sample"] between two steps
+    gets a step without CARRY_IN (the library would otherwise use an in_conv of the unedited tensor)."""
+    from sin3dm_amd import _lib
+    diff = create_gaussian_diffusion(steps=1000, timestep_respacing="5")
+    seen = []
+
+    def fake_step(mode, model, x, t, clip, dfn, kw, fuse=False, noise=None, carry=0, **rest):
+        seen.append((carry, x))
+        return torch.zeros_like(x), torch.zeros_like(x), None
+    diff._step = fake_step
+    m = FakeModel()
+
+    def run(action):
+        seen.clear()
+        for n, out in enumerate(diff.p_sample_loop_progressive(m, (1, 2, 3, 3), noise=torch.zeros(1, 2, 3, 3), device="cpu")):
+            if n == 1 and action == "edit":
+                out["sample"].add_(1.0)
+            if n == 1 and action == "replace":
+                out["sample"] = out["sample"].clone()
+        return [c for c, _ in seen]
+
+    O, I = _lib.CARRY_OUT, _lib.CARRY_IN
+    assert run(None) == [O, O | I, O | I, O | I, I]
+    assert run("edit") == [O, O | I, O, O | I, I]           # step 2 continues from an edited tensor: no CARRY_IN there
+    assert run("replace") == [O, O | I, O, O | I, I]
